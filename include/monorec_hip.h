@@ -1,0 +1,157 @@
+/*
+ * monorec_hip.h - C ABI of libmonorec_hip.so: the MI355X (gfx950) kernels behind the MonoRec
+ * cost-volume inference path.
+ *
+ * The reference (Brummi/MonoRec) is pure Python on PyTorch; its "FFI" for this path is the set of
+ * ATen operator calls inside MonoRecModel.forward.  Each entry point below replaces one group of
+ * those calls; the comment on every function names the reference lines it stands in for
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints/floats and a `void* stream` (a hipStream_t); no torch types.
+ *   - the caller owns every buffer; all tensors are dense fp32 NCHW on the current HIP device.
+ *   - every launch is asynchronous on `stream`; nothing here allocates, frees or synchronises,
+ *     so all entry points may be recorded into a hipGraph (stream capture).
+ *   - return value: 0 on success, a positive hipError_t, or a negative MR_ERR_* code. Nothing throws
+ *     across the boundary. mr_error_string() maps a code to text.
+ */
+#ifndef MONOREC_HIP_H
+#define MONOREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_ABI_VERSION 1
+
+#define MR_ERR_BAD_ARGUMENT (-1)
+#define MR_ERR_UNSUPPORTED  (-2)
+#define MR_ERR_LDS_BUDGET   (-3)
+
+#define MR_MAX_SOURCES 3
+#define MR_MAX_FRAMES  8
+
+/* ---- activation codes for mr_conv2d_f32 (epilogue, applied after bias [+ residual]) ---- */
+enum {
+    MR_ACT_NONE = 0,
+    MR_ACT_RELU = 1,            /* torchvision BasicBlock relu                                   */
+    MR_ACT_LEAKY_RELU = 2,      /* LeakyReLU(slope = act_p0)  model/layers.py:303,330,391         */
+    MR_ACT_SIGMOID = 3,         /* MaskModule.classifier      model/monorec/monorec_model.py:342  */
+    MR_ACT_ABS_TANH_AFFINE = 4  /* |tanh(x)| then (1-p)*act_p0 + p*act_p1  monorec_model.py:556,717 */
+};
+
+/* ---- how the conv reads its (virtual) input plane from the stored source plane ---- */
+enum {
+    MR_IN_DIRECT = 0,     /* input == source                                                          */
+    MR_IN_UPSAMPLE2 = 1,  /* input(y,x) = source(y/2,x/2): nn.Upsample(scale_factor=2) layers.py:349   */
+    MR_IN_MAXPOOL2 = 2    /* input(y,x) = max of the 2x2 source block: nn.MaxPool2d(2) monorec_model.py:304 */
+};
+
+/* ---- value transform applied to in-bounds input samples while staging ---- */
+enum {
+    MR_TF_NONE = 0,
+    MR_TF_RESNET_NORM = 1 /* ((x + 0.5) - 0.45) / 0.225  monorec_model.py:691 + :120 */
+};
+
+/*
+ * One convolution launch.  Replaces nn.Conv2d / PadSameConv2d+Conv2d / Upsample+pad+Conv2d /
+ * MaxPool2d+Conv2d / one output phase of ConvTranspose2d(k4,s2) (+ folded eval BatchNorm, bias,
+ * residual add and activation) of model/layers.py:241-252,289-356,380-400 and the torchvision
+ * ResNet-18 trunk used by model/monorec/monorec_model.py:118-129.
+ *
+ * Input = channel concatenation (torch.cat(..., dim=1), monorec_model.py:372-380,531,541-545) of
+ * `num_src` NCHW sources sharing batch and plane size; they are read in place, never materialised.
+ * Output pixel (oy,ox) of the conv grid is written to plane position
+ * (oy*out_step_h + out_off_h, ox*out_step_w + out_off_w) of channel dst_channel_offset + co of a
+ * (batch, dst_total_channels, dst_plane_h, dst_plane_w) tensor - step 2 is used by the four phases of
+ * the transposed convolution.
+ */
+typedef struct mr_conv_desc {
+    /* input */
+    const float* src[MR_MAX_SOURCES];
+    int32_t src_channels[MR_MAX_SOURCES];
+    int32_t num_src;
+    int32_t batch;
+    int32_t src_h, src_w;            /* stored plane size of every source                      */
+    int32_t in_mode;                 /* MR_IN_*                                                */
+    int32_t in_transform;            /* MR_TF_*                                                */
+    /* filter geometry; taps read input (oy*stride_h - pad_top + ky, ox*stride_w - pad_left + kx), zero outside */
+    int32_t kh, kw, stride_h, stride_w, pad_top, pad_left;
+    int32_t out_h, out_w;            /* conv grid size                                          */
+    /* output placement */
+    float* dst;
+    int32_t out_channels;
+    int32_t dst_total_channels, dst_channel_offset;
+    int32_t dst_plane_h, dst_plane_w;
+    int32_t out_step_h, out_step_w, out_off_h, out_off_w;
+    /* parameters */
+    const float* packed_weights;     /* from mr_conv_pack_weights_f32 (device copy)              */
+    const float* bias;               /* out_channels floats or NULL                              */
+    const float* residual;           /* same geometry as dst (incl. channel offset) or NULL      */
+    int32_t activation;              /* MR_ACT_*                                                 */
+    float act_p0, act_p1;
+    /* schedule */
+    int32_t cout_blocks_per_wg;      /* MB: 16-channel output blocks per workgroup, one of 1,2,3,4,6 */
+    int32_t pixel_blocks_per_wave;   /* NB: 16-pixel row segments per wave, one of 1,2,4            */
+    int32_t split_k;                 /* >= 1; > 1 needs `workspace`                               */
+    float* workspace;                /* split_k * batch * ceil16(out_channels) * out_h * out_w floats */
+} mr_conv_desc;
+
+/* number of floats of the packed weight image for a conv with the given source split */
+size_t mr_conv_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                    int32_t kh, int32_t kw);
+
+/*
+ * Host-side repack of an (out_channels, sum(src_channels), kh, kw) fp32 weight (nn.Conv2d layout,
+ * row-major) into the MFMA A-fragment stream the kernel consumes. `dst` is host memory of
+ * mr_conv_packed_weight_floats() floats; upload it once per layer.
+ */
+int mr_conv_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels,
+                             int32_t num_src, int32_t kh, int32_t kw, float* dst);
+
+/* bytes of dynamic LDS the launch will request (for planning / tests); negative MR_ERR_* if invalid */
+int64_t mr_conv2d_lds_bytes(const mr_conv_desc* desc);
+
+/* launch (replaces the reference lines listed above mr_conv_desc) */
+int mr_conv2d_f32(const mr_conv_desc* desc, void* stream);
+
+/*
+ * Fused plane-sweep cost volume.  Replaces CostVolumeModule.forward per-pixel work,
+ * model/monorec/monorec_model.py:193-271 (+ model/layers.py:63-71 point_projection,
+ * :119-137 SSIM, F.grid_sample x2, F.conv3d), for use_mono, use_ssim=True, sfcv_mult_mask=True,
+ * patch_size=3.  The 4x4 pose/intrinsics algebra of :171,198,207 stays on the host:
+ *   kinv   : batch x 9      inverse(keyframe_intrinsics)[:3,:3], row-major
+ *   proj   : batch x F x 12 (K_f @ (inverse(pose_f) @ pose_kf))[:3,:4], row-major
+ *   depths : D depth hypotheses (1/linspace(inv_max, inv_min, D)), far to near
+ * keyframe: (batch,3,H,W); frames[f]: (batch,3,H,W), all in [-0.5,0.5].
+ * Outputs: cost_volume (batch,D,H,W); sfcv[f] (batch,D,H,W).
+ * D must be <= 64, F <= MR_MAX_FRAMES.
+ */
+int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                       const float* kinv, const float* proj, const float* depths,
+                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                       float alpha, const float* channel_weights /* 3 host floats */,
+                       float* cost_volume, float* const* sfcv, void* stream);
+
+/* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the torchvision ResNet stem (monorec_model.py:124) */
+int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in_h, int32_t in_w, void* stream);
+
+/* elementwise max over F stacked tensors: torch.max(cv_feats[i], x) (monorec_model.py:365).
+ * src is (F, count) contiguous. */
+int mr_max_over_frames_f32(const float* src, float* dst, int32_t num_frames, int64_t count, void* stream);
+
+/* cost_volume = (1 - cv_mask) * cost_volume (monorec_model.py:713); mask (batch,1,H,W), cv (batch,D,H,W).
+ * dst may alias cv. */
+int mr_apply_mask_f32(const float* cv, const float* mask, float* dst, int32_t batch, int32_t num_depths,
+                      int64_t plane, void* stream);
+
+int mr_abi_version(void);
+const char* mr_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOREC_HIP_H */

@@ -1,0 +1,349 @@
+// Fused plane-sweep cost volume for gfx950 (MI355X): one launch replaces
+// CostVolumeModule.forward's per-pixel work, reference model/monorec/monorec_model.py:193-271
+// (+ model/layers.py:63-71 point_projection, :119-137 SSIM, F.grid_sample x2, F.conv3d) - about 60
+// full-tensor ATen passes over (D*F,3,H,W) temporaries in the reference.
+//
+// Workgroup = one TY x TX keyframe tile of one sample (32x16 px / 512 threads for D <= 32,
+// 16x16 px / 256 threads for D <= 64), one thread per pixel.  For every source frame f and depth
+// hypothesis d the workgroup
+//   (a) projects the tile + 2 px halo into frame f and bilinearly samples RGB from HBM/L2 (the 1.5 MB
+//       source image is L2 resident; the footprint of a tile is data dependent so it is gathered,
+//       not LDS-windowed) -> warped tile in LDS,
+//   (b) evaluates the 3x3 SSIM distance on tile + 1 px halo (reflection at image borders), channel
+//       weighted -> LDS,
+//   (c) 3x3 box sum (zero padded) -> sad(f,d,pixel), kept in LDS for all d of the frame.
+// After the depth sweep of a frame the validity mask (all-depth AND of the warped border mask), the
+// soft-min frame weight and the weighted numerator are finished per pixel from LDS; the fused cost
+// volume and the F single-frame volumes are written exactly once (algorithmic HBM bytes only).
+//
+// Arithmetic follows the reference operation by operation with contraction disabled
+// (-ffp-contract=off) and explicit fmaf where the CPU reference fuses (MKL sgemm k-ascending FMA
+// chain; ATen grid_sampler unnormalise + bilinear FMA chain; see oracle/make_golden.py for the
+// bitwise pinning), so warped samples, SSIM values and the validity mask reproduce the CPU bits.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/monorec_hip.h"
+
+namespace {
+
+struct CvArgs {
+    const float* keyframe;
+    const float* frames[MR_MAX_FRAMES];
+    float* sfcv[MR_MAX_FRAMES];
+    const float* kinv;    // B x 9
+    const float* proj;    // B x F x 12
+    const float* depths;  // D
+    float* cv;
+    int F, B, D, H, W;
+    int tiles_x;
+    float alpha;
+    float cw[3];          // channel_weight / 9 (fp32 division, monorec_model.py:141)
+    float inv_dm1;        // fp32(1/(D-1)) (python double division, then cast; :258)
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // nn.ReflectionPad2d(1), layers.py:112
+    return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+}
+
+// One bilinear sample position of frame f at depth `depth` for keyframe pixel ray (r0,r1,r2).
+struct Sample {
+    int x0, y0;
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Sample project(float r0, float r1, float r2, float depth, const float* P, int H, int W) {
+    // cam point = depth * ray (monorec_model.py:200); pc = P[:, :3] X + P[:, 3] as MKL's k-ascending FMA chain
+    const float X0 = depth * r0, X1 = depth * r1, X2 = depth * r2;
+    const float pcx = fmaf(P[3], 1.0f, fmaf(P[2], X2, fmaf(P[1], X1, P[0] * X0)));
+    const float pcy = fmaf(P[7], 1.0f, fmaf(P[6], X2, fmaf(P[5], X1, P[4] * X0)));
+    const float pcz = fmaf(P[11], 1.0f, fmaf(P[10], X2, fmaf(P[9], X1, P[8] * X0)));
+    const float z = pcz + 1e-7f;                       // layers.py:66
+    float u = pcx / z, v = pcy / z;
+    u = u / (float)(W - 1);                            // layers.py:67
+    v = v / (float)(H - 1);                            // layers.py:68
+    u = fminf(fmaxf((u - 0.5f) * 2.0f, -2.0f), 2.0f);  // layers.py:69 + clamp(-2,2) monorec_model.py:208
+    v = fminf(fmaxf((v - 0.5f) * 2.0f, -2.0f), 2.0f);
+    // grid_sample(align_corners=False): unnormalise as fma(g + 1, size/2, -0.5) (ATen GridSamplerKernel)
+    const float sx = fmaf(u + 1.0f, (float)W * 0.5f, -0.5f);
+    const float sy = fmaf(v + 1.0f, (float)H * 0.5f, -0.5f);
+    const float fx = floorf(sx), fy = floorf(sy);
+    const float w = sx - fx, e = 1.0f - w, n = sy - fy, s = 1.0f - n;
+    Sample o;
+    o.x0 = (int)fx;
+    o.y0 = (int)fy;
+    o.nw = s * e; o.ne = s * w; o.sw = n * e; o.se = n * w;
+    return o;
+}
+
+__device__ __forceinline__ float bilinear(const float* img, const Sample& sp, int H, int W) {
+    const bool xl = sp.x0 >= 0 && sp.x0 < W, xr = sp.x0 + 1 >= 0 && sp.x0 + 1 < W;
+    const bool yt = sp.y0 >= 0 && sp.y0 < H, yb = sp.y0 + 1 >= 0 && sp.y0 + 1 < H;
+    const float* p = img + sp.y0 * W + sp.x0;
+    const float a = (xl && yt) ? p[0] : 0.f;
+    const float b = (xr && yt) ? p[1] : 0.f;
+    const float c = (xl && yb) ? p[W] : 0.f;
+    const float d = (xr && yb) ? p[W + 1] : 0.f;
+    return fmaf(d, sp.se, fmaf(c, sp.sw, fmaf(b, sp.ne, a * sp.nw)));
+}
+
+// bilinear sample of the border mask (ones with a 2 px zero frame, monorec_model.py:282-284) != 0
+__device__ __forceinline__ bool mask_hit(const Sample& sp, int H, int W) {
+    const float ml = (sp.x0 >= 2 && sp.x0 < W - 2) ? 1.f : 0.f, mr = (sp.x0 + 1 >= 2 && sp.x0 + 1 < W - 2) ? 1.f : 0.f;
+    const float mt = (sp.y0 >= 2 && sp.y0 < H - 2) ? 1.f : 0.f, mb = (sp.y0 + 1 >= 2 && sp.y0 + 1 < H - 2) ? 1.f : 0.f;
+    const float m = fmaf(mr * mb, sp.se, fmaf(ml * mb, sp.sw, fmaf(mr * mt, sp.ne, (ml * mt) * sp.nw)));
+    return m != 0.f;
+}
+
+template <int TX, int TY>
+__global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
+    constexpr int NT = TX * TY;
+    constexpr int HX = TX + 4, HY = TY + 4;   // warped / keyframe tile with 2 px halo
+    constexpr int SX = TX + 2, SY = TY + 2;   // SSIM tile with 1 px halo
+    constexpr int NHALO = HX * HY - NT;       // halo positions warped by the first NHALO threads
+    constexpr int NSS = (SX * SY + NT - 1) / NT;  // SSIM positions per thread (2)
+    static_assert(NHALO <= NT, "halo must fit one extra round");
+    static_assert(NSS == 2, "two SSIM rounds expected");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* kf = lds;                       // [3][HY][HX] keyframe + 0.5
+    float* wr = kf + 3 * HY * HX;          // [3][HY][HX] warped + 0.5
+    float* es = wr + 3 * HY * HX;          // [SY][SX]   channel-weighted SSIM distance
+    float* sadc = es + SY * SX;            // [D][NT]    sad of the current frame
+    float* num = sadc + a.D * NT;          // [D][NT]    sum_f w_f * sad_f
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, D = a.D;
+    const int b = blockIdx.y;
+    const int ty0 = (blockIdx.x / a.tiles_x) * TY, tx0 = (blockIdx.x % a.tiles_x) * TX;
+    const int HWp = H * W;
+    const float* kimg = a.keyframe + (long long)b * 3 * HWp;
+
+    // ---- keyframe tile (+0.5) ---------------------------------------------------------------------
+    for (int i = tid; i < 3 * HY * HX; i += NT) {
+        const int c = i / (HY * HX), r = i % (HY * HX);
+        const int gy = ty0 - 2 + r / HX, gx = tx0 - 2 + r % HX;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = kimg[c * HWp + gy * W + gx] + 0.5f;
+        kf[i] = v;
+    }
+
+    // ---- positions owned by this thread ---------------------------------------------------------------
+    // own pixel
+    const int oly = tid / TX, olx = tid % TX;
+    const int opy = ty0 + oly, opx = tx0 + olx;
+    const bool own_in = opy < H && opx < W;
+    // halo position (threads < NHALO): top 2 rows, bottom 2 rows, then 2+2 side columns
+    int hly = 0, hlx = 0;
+    bool has_halo = tid < NHALO;
+    if (has_halo) {
+        if (tid < 2 * HX) { hly = tid / HX; hlx = tid % HX; }
+        else if (tid < 4 * HX) { const int j = tid - 2 * HX; hly = TY + 2 + j / HX; hlx = j % HX; }
+        else { const int j = tid - 4 * HX; hly = 2 + (j >> 2); const int k = j & 3; hlx = k < 2 ? k : TX + k; }
+    }
+    const int hpy = ty0 - 2 + hly, hpx = tx0 - 2 + hlx;
+    has_halo = has_halo && hpy >= 0 && hpy < H && hpx >= 0 && hpx < W;
+
+    // pixel rays Kinv[:3,:3] @ [x,y,1] (monorec_model.py:199), MKL k-ascending FMA chain
+    const float* Ki = a.kinv + b * 9;
+    float ro[3], rh[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ro[i] = fmaf(Ki[3 * i + 2], 1.0f, fmaf(Ki[3 * i + 1], (float)opy, Ki[3 * i] * (float)opx));
+        rh[i] = fmaf(Ki[3 * i + 2], 1.0f, fmaf(Ki[3 * i + 1], (float)hpy, Ki[3 * i] * (float)hpx));
+    }
+
+    __syncthreads();
+
+    // ---- keyframe SSIM statistics of this thread's SSIM positions (registers) -----------------------------
+    int sly[NSS], slx[NSS];
+    bool s_in[NSS];
+    float kmu[NSS][3], ksg[NSS][3];
+#pragma unroll
+    for (int r = 0; r < NSS; ++r) {
+        const int idx = tid + r * NT;
+        sly[r] = idx / SX;
+        slx[r] = idx % SX;
+        const int qy = ty0 - 1 + sly[r], qx = tx0 - 1 + slx[r];
+        s_in[r] = idx < SX * SY && qy >= 0 && qy < H && qx >= 0 && qx < W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { kmu[r][c] = 0.f; ksg[r][c] = 0.f; }
+        if (s_in[r]) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float s1 = 0.f, s2 = 0.f;
+                bool first = true;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ly = reflect_idx(qy + dy, H) - (ty0 - 2), lx = reflect_idx(qx + dx, W) - (tx0 - 2);
+                        const float k = kf[(c * HY + ly) * HX + lx];
+                        const float kk = k * k;
+                        if (first) { s1 = k; s2 = kk; first = false; } else { s1 = s1 + k; s2 = s2 + kk; }
+                    }
+                const float mu = s1 / 9.0f;                     // AvgPool2d(3,1): sequential sum / 9
+                kmu[r][c] = mu;
+                ksg[r][c] = s2 / 9.0f - mu * mu;                // layers.py:130
+            }
+        }
+    }
+
+    const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;   // fp32(0.01**2), fp32(0.03**2)  layers.py:116-117
+    float wsum = 0.f;                                                   // sum_f weight_f (own pixel)
+    const bool own_border = own_in && opy >= 2 && opy < H - 2 && opx >= 2 && opx < W - 2;  // mask_to_warp[0]
+
+    for (int f = 0; f < a.F; ++f) {
+        const float* P = a.proj + ((long long)b * a.F + f) * 12;
+        const float* img = a.frames[f] + (long long)b * 3 * HWp;
+        bool valid = own_border;
+        float smin = INFINITY;
+        for (int d = 0; d < D; ++d) {
+            const float depth = a.depths[d];
+            // ---- (a) warp own pixel + one halo position ------------------------------------------
+            if (own_in) {
+                const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
+                valid = valid && mask_hit(sp, H, W);                       // monorec_model.py:218-219
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    wr[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+            }
+            if (has_halo) {
+                const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    wr[(c * HY + hly) * HX + hlx] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+            }
+            __syncthreads();
+            // ---- (b) SSIM distance on tile + 1 px halo -------------------------------------------
+#pragma unroll
+            for (int r = 0; r < NSS; ++r) {
+                if (tid + r * NT < SX * SY) {
+                    float e = 0.f;   // zero padding of the 3x3 box (conv3d padding, monorec_model.py:247)
+                    if (s_in[r]) {
+                        const int qy = ty0 - 1 + sly[r], qx = tx0 - 1 + slx[r];
+                        int lyy[3], lxx[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            lyy[t] = reflect_idx(qy + t - 1, H) - (ty0 - 2);
+                            lxx[t] = reflect_idx(qx + t - 1, W) - (tx0 - 2);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
+#pragma unroll
+                            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) {
+                                    const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
+                                    const float x = wr[li], k = kf[li];
+                                    const float xx = x * x, xk = x * k;
+                                    if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
+                                    else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
+                                }
+                            const float mu_x = sx1 / 9.0f, mu_y = kmu[r][c];
+                            const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
+                            const float sig_x = sx2 / 9.0f - mu_x_sq;
+                            const float sig_xy = sxy / 9.0f - mu_xy;
+                            const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
+                            const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
+                            const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
+                            e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
+                        }
+                    }
+                    es[sly[r] * SX + slx[r]] = e;
+                }
+            }
+            __syncthreads();
+            // ---- (c) 3x3 box sum -> sad ------------------------------------------------------------
+            {
+                float s = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = es[(oly + dy) * SX + olx + dx];
+                        s = (dy == 0 && dx == 0) ? v : s + v;
+                    }
+                sadc[d * NT + tid] = s;
+                smin = fminf(smin, s);
+            }
+        }
+        // ---- frame epilogue (own pixel): single-frame volume, soft-min weight, numerator -----------
+        if (own_in) {
+            const float vm = valid ? 1.f : 0.f;
+            float se = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float df = sadc[d * NT + tid] - smin;
+                const float ev = expf(-a.alpha * (df * df));                 // monorec_model.py:257
+                se = d == 0 ? ev : se + ev;
+            }
+            float wgt = 1.0f - a.inv_dm1 * (se - 1.0f);                      // :258
+            wgt = wgt * vm;                                                  // :260
+            wsum = f == 0 ? wgt : wsum + wgt;                                // :264
+            float* sf = a.sfcv[f] + (long long)b * D * HWp + opy * W + opx;
+            for (int d = 0; d < D; ++d) {
+                const float s = sadc[d * NT + tid];
+                sf[(long long)d * HWp] = (1.0f - s * 2.0f) * vm;             // :251
+                const float t = s * wgt;                                     // :262
+                num[d * NT + tid] = f == 0 ? t : num[d * NT + tid] + t;
+            }
+        }
+        // sadc of this frame is only re-read by its own thread; the next frame's (a)/(b)/(c) barriers
+        // order the shared wr/es buffers, so no extra barrier is needed here.
+    }
+    if (own_in) {
+        float* cvp = a.cv + (long long)b * D * HWp + opy * W + opx;
+        const bool nz = wsum != 0.f;
+        for (int d = 0; d < D; ++d) {
+            float v = 0.f;                                                   // :269
+            if (nz) v = 1.0f - 2.0f * (num[d * NT + tid] / wsum);            // :266,268
+            cvp[(long long)d * HWp] = v;
+        }
+    }
+}
+
+template <int TX, int TY>
+int launch_cv(const CvArgs& a, hipStream_t stream) {
+    constexpr int NT = TX * TY;
+    const size_t lds = sizeof(float) * (size_t)(2 * 3 * (TY + 4) * (TX + 4) + (TY + 2) * (TX + 2) + 2 * a.D * NT);
+    if (lds > 160 * 1024) return MR_ERR_LDS_BUDGET;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_kernel<TX, TY>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    CvArgs k = a;
+    k.tiles_x = (a.W + TX - 1) / TX;
+    const int tiles_y = (a.H + TY - 1) / TY;
+    hipLaunchKernelGGL((cost_volume_kernel<TX, TY>), dim3(k.tiles_x * tiles_y, a.B), dim3(NT), lds, stream, k);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                  const float* kinv, const float* proj, const float* depths,
+                                  int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                  float alpha, const float* channel_weights,
+                                  float* cost_volume, float* const* sfcv, void* stream) {
+    if (!keyframe || !frames || !kinv || !proj || !depths || !cost_volume || !sfcv || !channel_weights)
+        return MR_ERR_BAD_ARGUMENT;
+    if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
+    if (num_depths < 2 || num_depths > 64) return MR_ERR_UNSUPPORTED;
+    CvArgs a;
+    a.keyframe = keyframe;
+    for (int f = 0; f < MR_MAX_FRAMES; ++f) {
+        a.frames[f] = f < num_frames ? frames[f] : nullptr;
+        a.sfcv[f] = f < num_frames ? sfcv[f] : nullptr;
+        if (f < num_frames && (!a.frames[f] || !a.sfcv[f])) return MR_ERR_BAD_ARGUMENT;
+    }
+    a.kinv = kinv; a.proj = proj; a.depths = depths; a.cv = cost_volume;
+    a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
+    a.tiles_x = 0;
+    a.alpha = alpha;
+    for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / 9.0f;
+    a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
+    if (num_depths <= 32) return launch_cv<32, 16>(a, (hipStream_t)stream);
+    return launch_cv<16, 16>(a, (hipStream_t)stream);
+}

@@ -1,0 +1,137 @@
+"""Synthetic KITTI-shaped keyframe batches and deterministic weights.
+
+There is no dataset and no checkpoint offline, so parity tests, `bench.py` and
+`smoke()` all run on inputs produced here: smooth random textures (so SSIM is
+non-degenerate), KITTI-example intrinsics, keyframe pose = I and source poses that
+are +-0.8 m*k translations along the optical axis with 1 cm lateral jitter
+(10 Hz @ ~30 km/h).  `hard_pose=True` moves the whole rig to (-78, 0.6, 23) m to
+exercise the fp32 cancellation in inverse(pose_src) @ pose_kf that the reference
+has at monorec_model.py:171,207.
+
+Everything is generated with CPU `torch.Generator`s so the very same tensors are
+reproduced on the GPU box (same image, same torch build).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# reference example: 1226x370 KITTI seq 07 centre-cropped/resized to 256x512
+# (kitti_odometry_dataset.py:318-349) -> fx=fy=489.23, cx=248.31, cy=126.69
+_KITTI_K_256x512 = (489.23, 489.23, 248.31, 126.69)
+
+
+def make_intrinsics(height, width, batch):
+    sy, sx = height / 256.0, width / 512.0
+    fx, fy, cx, cy = _KITTI_K_256x512
+    k = torch.eye(4, dtype=torch.float32)
+    k[0, 0], k[1, 1], k[0, 2], k[1, 2] = fx * sx, fy * sy, cx * sx, cy * sy
+    return k.unsqueeze(0).repeat(batch, 1, 1).contiguous()
+
+
+def _texture(gen, batch, height, width):
+    low = torch.rand(batch, 3, max(height // 8, 2), max(width // 8, 2), generator=gen)
+    img = F.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)
+    img = img + 0.1 * torch.rand(batch, 3, height, width, generator=gen)
+    return (img.clamp_(0.0, 1.0) - 0.5).contiguous()
+
+
+def make_batch(batch=1, height=256, width=512, frames=2, seed=1, hard_pose=False, consistent=True):
+    """Input dict with the reference contract (kitti_odometry_dataset.py:260-269).
+
+    consistent=True renders the source frames as horizontally shifted copies of the
+    keyframe texture (plus noise) so that the cost volume has real minima; False gives
+    independent textures.
+    """
+    gen = torch.Generator().manual_seed(seed)
+    keyframe = _texture(gen, batch, height, width)
+    kf_pose = torch.eye(4).unsqueeze(0).repeat(batch, 1, 1)
+    if hard_pose:
+        kf_pose[:, 0, 3], kf_pose[:, 1, 3], kf_pose[:, 2, 3] = -78.0, 0.6, 23.0
+        ang = 0.3
+        rot = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+        kf_pose[:, :3, :3] = rot
+    frame_list, pose_list, intr_list = [], [], []
+    for i in range(frames):
+        k = i // 2 + 1
+        sign = -1.0 if i % 2 == 0 else 1.0
+        rel = torch.eye(4).unsqueeze(0).repeat(batch, 1, 1)
+        rel[:, 2, 3] = sign * 0.8 * k
+        rel[:, 0, 3] = 0.01 * (torch.rand(batch, generator=gen) - 0.5) * 2
+        rel[:, 1, 3] = 0.01 * (torch.rand(batch, generator=gen) - 0.5) * 2
+        pose = kf_pose @ rel
+        if consistent:
+            shift = int(round(sign * 3 * k))
+            img = torch.roll(keyframe, shifts=shift, dims=3) + 0.02 * (torch.rand(batch, 3, height, width, generator=gen) - 0.5)
+            img = img.clamp_(-0.5, 0.5).contiguous()
+        else:
+            img = _texture(gen, batch, height, width)
+        frame_list.append(img)
+        pose_list.append(pose.contiguous())
+        intr_list.append(make_intrinsics(height, width, batch))
+    return {
+        "keyframe": keyframe,
+        "keyframe_pose": kf_pose.contiguous(),
+        "keyframe_intrinsics": make_intrinsics(height, width, batch),
+        "frames": frame_list,
+        "poses": pose_list,
+        "intrinsics": intr_list,
+    }
+
+
+def clone_batch(batch, device=None):
+    def cv(v):
+        if isinstance(v, torch.Tensor):
+            return v.clone().to(device) if device is not None else v.clone()
+        if isinstance(v, list):
+            return [cv(x) for x in v]
+        return v
+    return {k: cv(v) for k, v in batch.items()}
+
+
+def seeded_state_dict(template_state_dict, seed=0):
+    """Deterministic, key-addressed weights for any state dict with the MonoRec key set.
+
+    Independent of module construction order (unlike torch.manual_seed + default init),
+    so the reference, the oracle and the HIP model can all be loaded with identical
+    numbers without sharing code.  Conv weights ~ U(+-sqrt(6/fan_in)) (He-uniform, keeps
+    activations O(1) through ~20 layers so parity tolerances stay meaningful - PyTorch's
+    default bound shrinks the signal by sqrt(3) per layer); biases ~ U(+-1/sqrt(fan_in));
+    BatchNorm gets non-trivial affine/statistics so that BN folding is actually exercised.
+    """
+    out = {}
+    for idx, key in enumerate(sorted(template_state_dict.keys())):
+        ref = template_state_dict[key]
+        gen = torch.Generator().manual_seed(1000003 * (seed + 1) + idx)
+        shape = tuple(ref.shape)
+        if key.endswith("num_batches_tracked"):
+            out[key] = torch.zeros(shape, dtype=ref.dtype)
+            continue
+        if key.endswith("running_var"):
+            out[key] = 0.5 + torch.rand(shape, generator=gen)
+            continue
+        if key.endswith("running_mean"):
+            out[key] = 0.4 * (torch.rand(shape, generator=gen) - 0.5)
+            continue
+        is_bn = ".bn" in key or ".downsample.1." in key
+        if is_bn and key.endswith("weight"):
+            # < 1 so the eight residual adds of ResNet-18 do not blow the features up
+            out[key] = 0.25 + 0.35 * torch.rand(shape, generator=gen)
+            continue
+        if is_bn and key.endswith("bias"):
+            out[key] = 0.4 * (torch.rand(shape, generator=gen) - 0.5)
+            continue
+        if len(shape) >= 2:
+            if "conv2d_t" in key:  # ConvTranspose2d weight is (Cin, Cout, kh, kw)
+                fan_in = shape[0] * 4  # k4/s2: every output pixel sees 2x2 taps of each input channel
+            else:
+                fan_in = 1
+                for s in shape[1:]:
+                    fan_in *= s
+            bound = math.sqrt(6.0 / fan_in)
+        else:
+            bound = 0.05
+        if ".predictors." in key or ".classifier." in key:
+            bound *= 0.5  # keep tanh / sigmoid heads out of saturation
+        out[key] = ((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(torch.float32)
+    return out

@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Benchmark of the MonoRec cost-volume inference path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one `MonoRecModel.forward` (cost volume -> ResNet-18 encoder -> MaskModule -> DepthModule,
+reference model/monorec/monorec_model.py:672-729) over one batch of synthetic keyframes that is already
+resident in HBM.  Default workload = BASELINE.json configs[1] ("c2"): single keyframe, 256x512, 2 source
+frames, 32 depth bins, fp32.  Multi-GPU: keyframes are independent, so every rank runs its own stream
+of keyframes (weak scaling, no data-path collective) and the ranks all-gather a tiny per-rank summary
+once at the end of the timed region (RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 with the whole-job keyframes/s, the roofline of the dominant kernel
+(the fp32-MFMA convolution, measured live with HIP events on the launch stream) and - at N=1 - the CPU
+baseline (the oracle port of the reference timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+NON_CONV_OPS = ("resnet.maxpool", "cost_volume", "mask.max", "apply_mask")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="keyframes per step per GPU (c2 = 1)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--depths", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-layers", default=None, help="write the per-launch timing table (JSON) here")
+    return ap.parse_args()
+
+
+def time_layers(model, batch_dev, plan_key, reps=5):
+    """Per-launch device time with HIP events on the stream the kernels are launched on."""
+    plan = model._plans[plan_key]
+    stream = torch.cuda.current_stream()
+    ops = plan.stages["encoder"] + plan.stages["main"]
+    acc = [0.0] * len(ops)
+    for _ in range(reps):
+        evs = []
+        for name, fn in ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn(stream.cuda_stream)
+            e1.record(stream)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(evs):
+            acc[i] += e0.elapsed_time(e1) * 1e-3 / reps
+    macs = {c["name"]: c for c in plan.conv_log}
+    rows = []
+    for (name, _), t in zip(ops, acc):
+        c = macs.get(name)
+        rows.append({"name": name, "seconds": t, "macs": c["macs"] if c else 0,
+                     "sched": [c["mb"], c["nb"], c["split_k"]] if c else None, "wgs": c["wgs"] if c else None,
+                     "tflops": (2 * c["macs"] / t / 1e12) if c and t > 0 else None})
+    return rows
+
+
+def cpu_baseline(sd, batch_cpu, depths, budget_s=25.0):
+    """The CPU oracle (restatement of the reference's torch-CPU path, oracle/monorec_oracle.py) on this
+    box's host cores: 1 warm-up + best of up to 5 forwards of the same keyframe batch."""
+    from oracle import monorec_oracle as orc
+    cores = torch.get_num_threads()
+    orc.forward(sd, batch_cpu, cv_depth_steps=depths)
+    best, n, t_all = None, 0, time.perf_counter()
+    while n < 5 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        ref = orc.forward(sd, batch_cpu, cv_depth_steps=depths)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        n += 1
+    b = batch_cpu["keyframe"].shape[0]
+    return {"value": b / best, "unit": "keyframes/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed forwards (best) + 1 warm-up of the same {b}-keyframe batch, torch CPU fp32"}, ref
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from monorec_amd import MonoRecModel, synth
+
+    model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=not args.no_graph)
+    sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    batch_cpu = synth.make_batch(args.batch, args.height, args.width, args.frames, seed=1 + rank)
+    batch_dev = synth.clone_batch(batch_cpu, dev)                # inputs resident in HBM before the timed region
+
+    def step():
+        with torch.no_grad():
+            return model(dict(batch_dev))
+
+    for _ in range(max(args.warmup, 3 if not args.no_graph else 1)):
+        out = step()
+    torch.cuda.synchronize()
+    summary = torch.zeros(2, dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    summary[0] = args.steps * args.batch
+    summary[1] = out["result"].double().mean()
+    if world > 1:   # the path's only collective: per-rank summaries, ~16 B per rank
+        gathered = [torch.zeros_like(summary) for _ in range(world)]
+        dist.all_gather(gathered, summary)
+    else:
+        gathered = [summary]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_keyframes = float(sum(g[0].item() for g in gathered))
+
+    if rank == 0:
+        plan_key = next(iter(model._plans))
+        rows = time_layers(model, batch_dev, plan_key)
+        conv_rows = [r for r in rows if r["macs"] > 0]
+        conv_s = sum(r["seconds"] for r in conv_rows)
+        conv_flops = 2.0 * sum(r["macs"] for r in conv_rows)
+        achieved = conv_flops / conv_s / 1e12
+        cv_row = next(r for r in rows if r["name"] == "cost_volume")
+        cv_bytes = 4.0 * args.batch * args.height * args.width * (3 + args.depths) * (1 + args.frames)
+        result = {
+            "metric": "frames/sec (keyframes/s), KITTI 256x512 2-src/32-bin cost-volume inference",
+            "value": total_keyframes / elapsed,
+            "unit": "keyframes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"c2: {args.batch} keyframe(s)/step/GPU, {args.height}x{args.width}, "
+                                   f"{args.frames} source frames, {args.depths} depth bins, fp32, random-init weights",
+                       "batch_per_gpu": args.batch, "hip_graph": not args.no_graph,
+                       "parallelism": f"dp{world} (independent keyframes per rank)"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4_f32)",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
+                         "algorithmic_gflop_per_step": conv_flops / 1e9, "conv_ms_per_step": conv_s * 1e3},
+            "cost_volume_kernel": {"bound": "hbm", "us": cv_row["seconds"] * 1e6, "algorithmic_MB": cv_bytes / 1e6,
+                                   "achieved_GBps": cv_bytes / cv_row["seconds"] / 1e9, "peak_GBps": 8000.0},
+            "device_ms_per_step_sum_of_kernels": sum(r["seconds"] for r in rows) * 1e3,
+        }
+        if args.dump_layers:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_layers)), exist_ok=True)
+            with open(args.dump_layers, "w") as f:
+                json.dump(rows, f, indent=1)
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref = cpu_baseline(sd, batch_cpu, args.depths)
+            result["cpu_baseline"] = base
+            with torch.no_grad():
+                out = model(dict(batch_dev))
+            result["depth_max_abs_err_vs_cpu"] = float((out["result"].cpu() - ref["result"]).abs().max())
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

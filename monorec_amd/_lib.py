@@ -1,0 +1,105 @@
+"""ctypes binding of libmonorec_hip.so (include/monorec_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or does not export the whole
+ABI, importing the kernels raises - the product path never silently runs on PyTorch/CPU ops.
+"""
+import ctypes
+import os
+
+MR_MAX_SOURCES = 3
+MR_MAX_FRAMES = 8
+
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_ABS_TANH_AFFINE = range(5)
+IN_DIRECT, IN_UPSAMPLE2, IN_MAXPOOL2 = range(3)
+TF_NONE, TF_RESNET_NORM = range(2)
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of `mr_conv_desc` (include/monorec_hip.h) - field order and types must match."""
+    _fields_ = [
+        ("src", ctypes.c_void_p * MR_MAX_SOURCES),
+        ("src_channels", ctypes.c_int32 * MR_MAX_SOURCES),
+        ("num_src", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("src_h", ctypes.c_int32), ("src_w", ctypes.c_int32),
+        ("in_mode", ctypes.c_int32),
+        ("in_transform", ctypes.c_int32),
+        ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
+        ("stride_h", ctypes.c_int32), ("stride_w", ctypes.c_int32),
+        ("pad_top", ctypes.c_int32), ("pad_left", ctypes.c_int32),
+        ("out_h", ctypes.c_int32), ("out_w", ctypes.c_int32),
+        ("dst", ctypes.c_void_p),
+        ("out_channels", ctypes.c_int32),
+        ("dst_total_channels", ctypes.c_int32), ("dst_channel_offset", ctypes.c_int32),
+        ("dst_plane_h", ctypes.c_int32), ("dst_plane_w", ctypes.c_int32),
+        ("out_step_h", ctypes.c_int32), ("out_step_w", ctypes.c_int32),
+        ("out_off_h", ctypes.c_int32), ("out_off_w", ctypes.c_int32),
+        ("packed_weights", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("activation", ctypes.c_int32),
+        ("act_p0", ctypes.c_float), ("act_p1", ctypes.c_float),
+        ("cout_blocks_per_wg", ctypes.c_int32),
+        ("pixel_blocks_per_wave", ctypes.c_int32),
+        ("split_k", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/monorec_hip.h declares: (restype, argtypes)
+ABI = {
+    "mr_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                                                       ctypes.c_int32, ctypes.c_int32]),
+    "mr_conv_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv2d_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(ConvDesc)]),
+    "mr_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "mr_cost_volume_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_float, _c_float_p,
+                                          ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "mr_maxpool3x3s2_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_void_p]),
+    "mr_max_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                              ctypes.c_void_p]),
+    "mr_apply_mask_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_abi_version": (ctypes.c_int, []),
+    "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmonorec_hip.so")
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library. Raises RuntimeError if it is missing/incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the gfx950 kernels first (python -m monorec_amd.build or "
+            "__graft_entry__.build()). monorec_amd has no CPU/PyTorch fallback for its hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in ABI.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mr_abi_version() != 1:
+        raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    """Turn a non-zero return code into a RuntimeError with hipGetErrorString / MR_ERR text."""
+    if code != 0:
+        msg = load().mr_error_string(int(code))
+        raise RuntimeError(f"{what}: {msg.decode() if msg else code} (code {code})")

@@ -1,0 +1,423 @@
+"""Launch plan for one (batch, H, W, frames, depth-steps) shape of the MonoRec inference path.
+
+The plan owns every activation buffer (allocated once, HBM resident), the repacked weights and an
+ordered list of C-ABI launches (include/monorec_hip.h).  It is the host-side replacement of the ATen
+call sequence inside `MonoRecModel.forward` (reference model/monorec/monorec_model.py:672-729):
+
+    stage "encoder" : ResnetEncoder.forward            (:118-129)   - independent of the poses
+    stage "main"    : CostVolumeModule (:193-271) -> MaskModule (:345-385) -> (1-mask)*cv (:713)
+                      -> DepthModule (:526-557) -> inverse-depth affine (:717)
+
+Because nothing in a stage allocates or synchronises, each stage can be recorded into a hipGraph
+(torch.cuda.CUDAGraph is the HIP graph API on ROCm) and replayed with ~10 us of host cost instead of
+~100 Python-driven launches.  The 4x4 pose algebra (:171,198,207) runs on the host between the two
+stages, overlapped with the encoder stage (see MonoRecModel._forward_hip).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (ACT_ABS_TANH_AFFINE, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, IN_DIRECT, IN_MAXPOOL2,
+                   IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM, ConvDesc)
+
+LEAKY_SLOPE = 0.1   # model/layers.py:290,318,381
+BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, used by torchvision's ResNet
+
+
+def same_pad(n, k, s):
+    """TF 'same' padding of PadSameConv2d (model/layers.py:249-251): (low, high), floor on the low side."""
+    total = s * (math.ceil(n / s) - 1) + k - n
+    return math.floor(total / 2), math.ceil(total / 2)
+
+
+def pack_conv_weight(weight, src_channels):
+    """(Cout, sum(src_channels), kh, kw) fp32 CPU tensor -> packed A-fragment stream (CPU tensor)."""
+    lib = _lib.load()
+    w = weight.detach().to(torch.float32).contiguous().cpu()
+    cout, cin, kh, kw = w.shape
+    assert cin == sum(src_channels), (cin, src_channels)
+    sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
+    n = lib.mr_conv_packed_weight_floats(cout, sc, len(src_channels), kh, kw)
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.mr_conv_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), kh, kw, out.data_ptr()),
+               "mr_conv_pack_weights_f32")
+    return out
+
+
+def fold_batchnorm(weight, sd, bn_prefix):
+    """Eval-mode BatchNorm2d folded into the preceding bias-free conv: returns (weight', bias')."""
+    g = sd[bn_prefix + ".weight"].double()
+    beta = sd[bn_prefix + ".bias"].double()
+    mean = sd[bn_prefix + ".running_mean"].double()
+    var = sd[bn_prefix + ".running_var"].double()
+    scale = g / torch.sqrt(var + BN_EPS)
+    w = (weight.double() * scale.view(-1, 1, 1, 1)).float()
+    b = (beta - mean * scale).float()
+    return w, b
+
+
+def transposed_phase_weights(wt):
+    """ConvTranspose2d(k=4, s=2) + centre crop of 1 (layers.Refine, model/layers.py:389-397) as four
+    2x2 stride-1 convolutions, one per output parity (py, px).
+
+    wt: (Cin, Cout, 4, 4).  Output row y = 2*yy + py reads input rows yy - pad_top + t (t = 0, 1):
+      py = 0: pad_top 1, taps ky = [3, 1];   py = 1: pad_top 0, taps ky = [2, 0]   (same for x).
+    Returns {(py, px): (weight (Cout, Cin, 2, 2), pad_top, pad_left)}."""
+    taps = {0: ([3, 1], 1), 1: ([2, 0], 0)}
+    out = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            ky, pt = taps[py]
+            kx, pl = taps[px]
+            w = wt[:, :, ky, :][:, :, :, kx]            # (Cin, Cout, 2, 2)
+            out[(py, px)] = (w.permute(1, 0, 2, 3).contiguous(), pt, pl)
+    return out
+
+
+def choose_schedule(cout, out_h, out_w, batch, nchunks, target_wgs=448):
+    """(MB, NB, split_k) for mr_conv2d_f32: biggest register tile that still fills the 256 CUs."""
+    cb = (cout + 15) // 16
+    best = None
+    for nb in (4, 2, 1):
+        twb = 2 if out_w >= 32 else 1
+        th = 4 * nb // twb
+        tiles = math.ceil(out_w / (twb * 16)) * math.ceil(out_h / th)
+        tile_eff = (out_h * out_w) / (tiles * th * twb * 16)
+        for mb in (6, 4, 3, 2, 1):
+            if mb > cb:
+                continue
+            groups = math.ceil(cb / mb)
+            cout_eff = cb / (groups * mb)
+            wgs = tiles * groups * batch
+            eff = tile_eff * cout_eff
+            # reuse/efficiency score: MFMAs per operand load grow with mb*nb/(mb+nb)
+            reuse = (mb * nb) / (mb + nb)
+            fill = min(1.0, wgs / target_wgs)
+            score = eff * fill * (0.55 + 0.45 * min(reuse, 2.4) / 2.4)
+            cand = (score, mb, nb, wgs)
+            if best is None or cand > best:
+                best = cand
+    _, mb, nb, wgs = best
+    split_k = 1
+    if wgs < 192 and nchunks >= 4:
+        split_k = int(min(8, nchunks // 2, max(1, 256 // wgs)))
+    return mb, nb, max(1, split_k)
+
+
+class Plan:
+    """Buffers + launch list for one input shape. `state` is a CPU state dict with the reference keys."""
+
+    def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
+                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True):
+        if build and (height % 32 or width % 32):
+            raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
+        if build and depth_steps % 4:
+            raise NotImplementedError("cv_depth_steps must be a multiple of 4 for the gfx950 kernels")
+        self.lib = _lib.load()
+        self.B, self.H, self.W, self.F, self.D = batch, height, width, num_frames, depth_steps
+        self.device = torch.device(device)
+        self.inv_depth_min_max = tuple(float(v) for v in inv_depth_min_max)
+        self.alpha = float(alpha)
+        self.cw = (ctypes.c_float * 3)(*[float(torch.tensor(c, dtype=torch.float32)) for c in channel_weights])
+        self.schedule_override = schedule_override or {}
+        self.sd = state
+        self.buf = {}
+        self.keep = []          # packed weights / biases (device tensors kept alive)
+        self.stages = {"encoder": [], "main": []}
+        self.conv_log = []      # (name, macs, mb, nb, split_k, wgs) for bench / tuning
+        self._ws_floats = 0
+        self._pending_ws = []
+        if build:
+            self._build()
+            self.finalize()
+
+    @classmethod
+    def bare(cls, device, state=None, schedule_override=None):
+        """Plan without the network: lets tests / micro-benchmarks launch single ops through the C ABI."""
+        return cls(state or {}, 1, 32, 32, 1, 4, (0.33, 0.0025), device, schedule_override=schedule_override, build=False)
+
+    def finalize(self):
+        """Allocate the shared split-K workspace once all launches are known."""
+        ws = torch.empty(max(self._ws_floats, 4), dtype=torch.float32, device=self.device)
+        self.buf["splitk_workspace"] = ws
+        for desc in self._pending_ws:
+            desc.workspace = ws.data_ptr()
+        self._pending_ws = []
+
+    # ------------------------------------------------------------------ buffers / parameters
+    def alloc(self, name, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        self.buf[name] = t
+        return t
+
+    def _dev(self, t):
+        d = t.detach().to(torch.float32).contiguous().to(self.device)
+        self.keep.append(d)
+        return d
+
+    # ------------------------------------------------------------------ op builders
+    def _launch_conv(self, desc, name):
+        lib = self.lib
+
+        def run(stream):
+            _lib.check(lib.mr_conv2d_f32(ctypes.byref(desc), stream), name)
+        return run
+
+    def conv(self, stage, name, srcs, weight, bias, out, *, stride=(1, 1), pad=(0, 0), grid=None,
+             act=ACT_NONE, p0=0.0, p1=0.0, in_mode=IN_DIRECT, tf=TF_NONE, residual=None,
+             out_step=(1, 1), out_off=(0, 0), out_ch_offset=0):
+        """Append one mr_conv2d_f32 launch. srcs: list of (N,C,Hs,Ws) tensors concatenated on channels."""
+        n, _, hs, ws = srcs[0].shape
+        src_channels = [int(s.shape[1]) for s in srcs]
+        for s in srcs:
+            assert s.shape[0] == n and s.shape[2] == hs and s.shape[3] == ws and s.is_contiguous()
+        cout, cin, kh, kw = weight.shape
+        assert cin == sum(src_channels), (name, cin, src_channels)
+        out_h, out_w = grid
+        packed = self._dev(pack_conv_weight(weight, src_channels))
+        d = ConvDesc()
+        for i, s in enumerate(srcs):
+            d.src[i] = s.data_ptr()
+            d.src_channels[i] = src_channels[i]
+        d.num_src, d.batch, d.src_h, d.src_w = len(srcs), n, hs, ws
+        d.in_mode, d.in_transform = in_mode, tf
+        d.kh, d.kw, d.stride_h, d.stride_w, d.pad_top, d.pad_left = kh, kw, stride[0], stride[1], pad[0], pad[1]
+        d.out_h, d.out_w = out_h, out_w
+        d.dst = out.data_ptr()
+        assert out.shape[0] == n and out.is_contiguous()
+        d.out_channels, d.dst_total_channels, d.dst_channel_offset = cout, out.shape[1], out_ch_offset
+        d.dst_plane_h, d.dst_plane_w = out.shape[2], out.shape[3]
+        d.out_step_h, d.out_step_w, d.out_off_h, d.out_off_w = out_step[0], out_step[1], out_off[0], out_off[1]
+        d.packed_weights = packed.data_ptr()
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        if residual is not None:
+            assert residual.shape == out.shape
+            d.residual = residual.data_ptr()
+        d.activation, d.act_p0, d.act_p1 = act, p0, p1
+        nchunks = sum(math.ceil(((c + 3) // 4 * 4) / 16) for c in src_channels)
+        mb, nb, split_k = self.schedule_override.get(name) or choose_schedule(cout, out_h, out_w, n, nchunks)
+        d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k = mb, nb, split_k
+        if split_k > 1:
+            self._ws_floats = max(self._ws_floats, split_k * n * ((cout + 15) // 16 * 16) * out_h * out_w)
+            self._pending_ws.append(d)
+            d.workspace = 1  # placeholder (non-null) until the shared workspace exists
+        lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name}")
+        macs = n * out_h * out_w * cout * cin * kh * kw
+        twb = 2 if out_w >= 32 else 1
+        wgs = math.ceil(out_w / (16 * twb)) * math.ceil(out_h / (4 * nb // twb)) * math.ceil(((cout + 15) // 16) / mb) * n * split_k
+        self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, wgs=wgs, lds=int(lds),
+                                  cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n))
+        self.keep.append(d)
+        self.stages[stage].append((name, self._launch_conv(d, name)))
+        return out
+
+    def same_conv(self, stage, name, srcs, wkey, bkey, out, *, stride=(1, 1), act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE,
+                  p1=0.0, in_mode=IN_DIRECT):
+        """PadSameConv2d + Conv2d (+ activation): model/layers.py:241-252,329-335."""
+        w = self.sd[wkey]
+        hs, ws = srcs[0].shape[2], srcs[0].shape[3]
+        if in_mode == IN_UPSAMPLE2:
+            hin, win = 2 * hs, 2 * ws
+        elif in_mode == IN_MAXPOOL2:
+            hin, win = hs // 2, ws // 2
+        else:
+            hin, win = hs, ws
+        kh, kw = w.shape[2], w.shape[3]
+        pt, _ = same_pad(hin, kh, stride[0])
+        pl, _ = same_pad(win, kw, stride[1])
+        grid = (math.ceil(hin / stride[0]), math.ceil(win / stride[1]))
+        return self.conv(stage, name, srcs, w, self.sd[bkey] if bkey else None, out, stride=stride, pad=(pt, pl),
+                         grid=grid, act=act, p0=p0, p1=p1, in_mode=in_mode)
+
+    def conv_relu2(self, stage, name, srcs, prefix, mid, out, stride=1):
+        """layers.ConvReLU2 (model/layers.py:308-314): k x 1 stride (s,1), then 1 x k stride (1,s)."""
+        self.same_conv(stage, name + ".conv_y", srcs, prefix + ".conv_y.weight", prefix + ".conv_y.bias", mid,
+                       stride=(stride, 1))
+        return self.same_conv(stage, name + ".conv_x", [mid], prefix + ".conv_x.weight", prefix + ".conv_x.bias", out,
+                              stride=(1, stride))
+
+    def refine(self, stage, name, srcs, prefix, out):
+        """layers.Refine (model/layers.py:389-397): ConvTranspose2d(4, 2) + LeakyReLU + crop, as 4 phase convs."""
+        wt = self.sd[prefix + ".conv2d_t.weight"]
+        bias = self.sd[prefix + ".conv2d_t.bias"]
+        h, w = srcs[0].shape[2], srcs[0].shape[3]
+        for (py, px), (wp, pt, pl) in transposed_phase_weights(wt).items():
+            self.conv(stage, f"{name}.phase{py}{px}", srcs, wp, bias, out, stride=(1, 1), pad=(pt, pl), grid=(h, w),
+                      act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE, out_step=(2, 2), out_off=(py, px))
+        return out
+
+    def add(self, stage, name, fn):
+        self.stages[stage].append((name, fn))
+
+    # ------------------------------------------------------------------ network
+    def _build(self):
+        B, H, W, F, D = self.B, self.H, self.W, self.F, self.D
+        sd, lib = self.sd, self.lib
+        kf = self.alloc("keyframe", B, 3, H, W)
+        frames = self.alloc("frames", F, B, 3, H, W)
+        geom = self.alloc("geom", B * 9 + B * F * 12)      # [kinv | proj], one H2D copy per forward
+        self.buf["kinv"] = geom[: B * 9].view(B, 9)
+        self.buf["proj"] = geom[B * 9:].view(B, F, 12)
+        self.alloc("depths", D)
+
+        # ---------------- ResNet-18 encoder (monorec_model.py:118-129) ----------------
+        enc = "_feature_extractor.encoder"
+        st = "encoder"
+        w, b = fold_batchnorm(sd[enc + ".conv1.weight"], sd, enc + ".bn1")
+        f0 = self.alloc("feat0", B, 64, H // 2, W // 2)
+        self.conv(st, "resnet.conv1", [kf], w, b, f0, stride=(2, 2), pad=(3, 3), grid=(H // 2, W // 2),
+                  act=ACT_RELU, tf=TF_RESNET_NORM)
+        pool = self.alloc("resnet.pool", B, 64, H // 4, W // 4)
+
+        def run_pool(stream, src=f0, dst=pool):
+            _lib.check(lib.mr_maxpool3x3s2_f32(src.data_ptr(), dst.data_ptr(), B * 64, H // 2, W // 2, stream),
+                       "mr_maxpool3x3s2_f32")
+        self.add(st, "resnet.maxpool", run_pool)
+        feats = [f0]
+        x, cin, hh, ww = pool, 64, H // 4, W // 4
+        for li, cout in enumerate((64, 128, 256, 512), start=1):
+            for bi in range(2):
+                pre = f"{enc}.layer{li}.{bi}"
+                stride = 2 if (li > 1 and bi == 0) else 1
+                ho, wo = hh // stride, ww // stride
+                w1, b1 = fold_batchnorm(sd[pre + ".conv1.weight"], sd, pre + ".bn1")
+                w2, b2 = fold_batchnorm(sd[pre + ".conv2.weight"], sd, pre + ".bn2")
+                t = self.alloc(f"resnet.l{li}b{bi}.t", B, cout, ho, wo)
+                self.conv(st, f"resnet.l{li}b{bi}.conv1", [x], w1, b1, t, stride=(stride, stride), pad=(1, 1),
+                          grid=(ho, wo), act=ACT_RELU)
+                idt = x
+                if (pre + ".downsample.0.weight") in sd:
+                    wd, bd = fold_batchnorm(sd[pre + ".downsample.0.weight"], sd, pre + ".downsample.1")
+                    idt = self.alloc(f"resnet.l{li}b{bi}.idt", B, cout, ho, wo)
+                    self.conv(st, f"resnet.l{li}b{bi}.down", [x], wd, bd, idt, stride=(stride, stride), pad=(0, 0),
+                              grid=(ho, wo), act=ACT_NONE)
+                is_feat = bi == 1
+                o = self.alloc(f"feat{li}" if is_feat else f"resnet.l{li}b{bi}.o", B, cout, ho, wo)
+                self.conv(st, f"resnet.l{li}b{bi}.conv2", [t], w2, b2, o, stride=(1, 1), pad=(1, 1), grid=(ho, wo),
+                          act=ACT_RELU, residual=idt)
+                x, cin, hh, ww = o, cout, ho, wo
+            feats.append(x)
+
+        # ---------------- cost volume (monorec_model.py:193-271) ----------------
+        st = "main"
+        sfcv = self.alloc("sfcv", F, B, D, H, W)
+        cv = self.alloc("cost_volume", B, D, H, W)
+        frame_ptrs = (ctypes.c_void_p * F)(*[frames[f].data_ptr() for f in range(F)])
+        sfcv_ptrs = (ctypes.c_void_p * F)(*[sfcv[f].data_ptr() for f in range(F)])
+        self.keep += [frame_ptrs, sfcv_ptrs]
+        kinv, proj, depths = self.buf["kinv"], self.buf["proj"], self.buf["depths"]
+
+        def run_cv(stream):
+            _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                              depths.data_ptr(), B, D, H, W, self.alpha, self.cw,
+                                              cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_f32")
+        self.add(st, "cost_volume", run_cv)
+
+        # ---------------- MaskModule (monorec_model.py:345-385), frames batched as F*B ----------------
+        am = "att_module"
+        enc_ch = (D, 48, 64, 96, 96)
+        x = sfcv.view(F * B, D, H, W)
+        cvf = []
+        for i in range(5):
+            hi, wi = H >> i, W >> i
+            i0, i1 = (0, 1) if i == 0 else (1, 2)       # index 0 of stages 1-4 is the MaxPool
+            a = self.alloc(f"mask.enc{i}.a", F * B, enc_ch[i], hi, wi)
+            xo = self.alloc(f"mask.enc{i}.x", F * B, enc_ch[i], hi, wi)
+            self.same_conv(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a,
+                           in_mode=IN_DIRECT if i == 0 else IN_MAXPOOL2)
+            self.same_conv(st, f"mask.enc{i}.1", [a], f"{am}.enc.{i}.{i1}.conv.weight", f"{am}.enc.{i}.{i1}.conv.bias", xo)
+            m = self.alloc(f"mask.cvf{i}", B, enc_ch[i], hi, wi)
+
+            def run_max(stream, src=xo, dst=m, count=B * enc_ch[i] * hi * wi):
+                _lib.check(lib.mr_max_over_frames_f32(src.data_ptr(), dst.data_ptr(), F, count, stream),
+                           "mr_max_over_frames_f32")
+            self.add(st, f"mask.max{i}", run_max)
+            cvf.append(m)
+            x = xo
+        x_srcs = [cvf[4], feats[3]]                                                  # :372
+        for i in range(4):
+            hi, wi = H >> (3 - i), W >> (3 - i)
+            up_ch = sd[f"{am}.dec.{i}.0.conv.weight"].shape[0]
+            dec_ch = {i: sd[f"{am}.dec.{i}.1.conv.weight"].shape[0]}
+            u = self.alloc(f"mask.dec{i}.up", B, up_ch, hi, wi)
+            self.same_conv(st, f"mask.dec{i}.0", x_srcs, f"{am}.dec.{i}.0.conv.weight", f"{am}.dec.{i}.0.conv.bias", u,
+                           act=ACT_NONE, in_mode=IN_UPSAMPLE2)                        # Upconv, layers.py:353-356
+            cat = [cvf[3 - i], u] if i == 3 else [cvf[3 - i], feats[2 - i], u]       # :374-380
+            a = self.alloc(f"mask.dec{i}.a", B, dec_ch[i], hi, wi)
+            xo = self.alloc(f"mask.dec{i}.x", B, dec_ch[i], hi, wi)
+            self.same_conv(st, f"mask.dec{i}.1", cat, f"{am}.dec.{i}.1.conv.weight", f"{am}.dec.{i}.1.conv.bias", a)
+            self.same_conv(st, f"mask.dec{i}.2", [a], f"{am}.dec.{i}.2.conv.weight", f"{am}.dec.{i}.2.conv.bias", xo)
+            x_srcs = [xo]
+        cv_mask = self.alloc("cv_mask", B, 1, H, W)
+        self.same_conv(st, "mask.classifier", x_srcs, f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
+                       act=ACT_SIGMOID)
+
+        def run_mask(stream):                                                        # :713 (in place)
+            _lib.check(lib.mr_apply_mask_f32(cv.data_ptr(), cv_mask.data_ptr(), cv.data_ptr(), B, D, H * W, stream),
+                       "mr_apply_mask_f32")
+        self.add(st, "apply_mask", run_mask)
+
+        # ---------------- DepthModule (monorec_model.py:526-557) ----------------
+        dm = "depth_module"
+        enc_spec = ((48, 7, 1), (64, 7, 2), (128, 5, 2), (192, 5, 2), (256, 3, 2))   # (channels, kernel, stride)
+        x_srcs = [cv, kf]                                                            # :531
+        dfe = []
+        hh, ww = H, W
+        for i, (ch, _, s) in enumerate(enc_spec):
+            h2, w2 = hh // s, ww // s
+            mid0 = self.alloc(f"depth.enc{i}.0.mid", B, ch, h2, ww)
+            o0 = self.alloc(f"depth.enc{i}.0.out", B, ch, h2, w2)
+            self.conv_relu2(st, f"depth.enc{i}.0", x_srcs, f"{dm}.enc.{i}.0", mid0, o0, stride=s)
+            mid1 = self.alloc(f"depth.enc{i}.1.mid", B, ch, h2, w2)
+            o1 = self.alloc(f"depth.enc{i}.1.out", B, ch, h2, w2)
+            self.conv_relu2(st, f"depth.enc{i}.1", [o0], f"{dm}.enc.{i}.1", mid1, o1)
+            dfe.append(o1)
+            x_srcs, hh, ww = [o1], h2, w2
+        lo, hi_ = self.inv_depth_min_max[1], self.inv_depth_min_max[0]
+        preds = [None] * 4
+
+        def head(idx, src, scale_slot):
+            hh_, ww_ = src.shape[2], src.shape[3]
+            p = self.alloc(f"pred{scale_slot}", B, 1, hh_, ww_)
+            self.same_conv(st, f"depth.head{idx}", [src], f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
+                           p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)                # :556 + :717
+            preds[scale_slot] = p
+
+        r0 = self.alloc("depth.dec0", B, 256, H // 8, W // 8)
+        self.refine(st, "depth.dec0", [dfe[4]], f"{dm}.dec.0", r0)
+        head(0, r0, 3)
+        r1 = self.alloc("depth.dec1.t", B, 128, H // 4, W // 4)
+        self.refine(st, "depth.dec1.0", [dfe[3], feats[2], r0], f"{dm}.dec.1.0", r1)  # :545
+        m1 = self.alloc("depth.dec1.mid", B, 128, H // 4, W // 4)
+        x1 = self.alloc("depth.dec1", B, 128, H // 4, W // 4)
+        self.conv_relu2(st, "depth.dec1.1", [r1], f"{dm}.dec.1.1", m1, x1)
+        head(1, x1, 2)
+        r2 = self.alloc("depth.dec2.t", B, 64, H // 2, W // 2)
+        self.refine(st, "depth.dec2.0", [dfe[2], feats[1], x1], f"{dm}.dec.2.0", r2)
+        m2 = self.alloc("depth.dec2.mid", B, 64, H // 2, W // 2)
+        x2 = self.alloc("depth.dec2", B, 64, H // 2, W // 2)
+        self.conv_relu2(st, "depth.dec2.1", [r2], f"{dm}.dec.2.1", m2, x2)
+        head(2, x2, 1)
+        x3 = self.alloc("depth.dec3", B, 48, H, W)
+        self.refine(st, "depth.dec3", [dfe[1], feats[0], x2], f"{dm}.dec.3", x3)
+        m4 = self.alloc("depth.dec4.mid", B, 32, H, W)
+        x4a = self.alloc("depth.dec4.a", B, 32, H, W)
+        self.conv_relu2(st, "depth.dec4.0", [dfe[0], x3], f"{dm}.dec.4.0", m4, x4a)   # :543
+        x4 = self.alloc("depth.dec4", B, 24, H, W)
+        self.same_conv(st, "depth.dec4.2", [x4a], f"{dm}.dec.4.2.weight", f"{dm}.dec.4.2.bias", x4)
+        head(3, x4, 0)
+        self.feats = feats
+        self.preds = preds
+
+    # ------------------------------------------------------------------ execution
+    def run_stage(self, stage, stream):
+        for _, fn in self.stages[stage]:
+            fn(stream)
+
+    def conv_macs(self):
+        return sum(c["macs"] for c in self.conv_log)

@@ -1,0 +1,385 @@
+"""Drop-in host-side mirror of the reference model API for the cost-volume inference path.
+
+`MonoRecModel` keeps the reference's constructor signature, public attributes, state-dict keys and
+dict-in / dict-out `forward` (reference model/monorec/monorec_model.py:560-729), so
+`evaluate.py`, `create_pointcloud.py` and `example/test_monorec.py` can use it unchanged
+(INTEGRATION.md).  The sub-modules only *hold parameters* under the reference's names
+(SURVEY.md Appendix C); all arithmetic runs in the gfx950 kernels of libmonorec_hip.so through the
+launch plan in `engine.py`.  There is no PyTorch/CPU fallback: calling `forward` without a HIP device
+or without the built library raises.
+"""
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .engine import Plan
+
+
+class _ParamsOnly(nn.Module):
+    """Container whose children exist to own parameters with reference-compatible names."""
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("monorec_amd sub-modules hold parameters only; call MonoRecModel.forward")
+
+
+def _conv(cin, cout, k, stride=1, bias=True):
+    return nn.Conv2d(cin, cout, k, stride=stride, bias=bias)
+
+
+class _Named(_ParamsOnly):
+    def __init__(self, **children):
+        super().__init__()
+        for n, m in children.items():
+            self.add_module(n, m)
+
+
+def _seq(*mods):
+    s = nn.Sequential()
+    for i, m in enumerate(mods):
+        s.add_module(str(i), m)
+    return s
+
+
+class _Placeholder(_ParamsOnly):
+    """Occupies a Sequential index that holds a parameter-free op in the reference (pool/pad/act)."""
+
+
+# --------------------------------------------------------------------------------------------------
+class ResnetEncoder(_ParamsOnly):
+    """Parameters of ResnetEncoder (monorec_model.py:95-129): torchvision ResNet-18 key layout."""
+
+    def __init__(self, num_layers=18, pretrained=True):
+        super().__init__()
+        if num_layers != 18:
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        enc = _ParamsOnly()
+        enc.conv1 = _conv(3, 64, 7, 2, bias=False)
+        enc.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for li, cout in enumerate((64, 128, 256, 512), start=1):
+            blocks = []
+            for bi in range(2):
+                stride = 2 if (li > 1 and bi == 0) else 1
+                blk = _Named(conv1=_conv(cin, cout, 3, stride, bias=False), bn1=nn.BatchNorm2d(cout),
+                             conv2=_conv(cout, cout, 3, 1, bias=False), bn2=nn.BatchNorm2d(cout))
+                if stride != 1 or cin != cout:
+                    blk.downsample = _seq(_conv(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+                blocks.append(blk)
+                cin = cout
+            setattr(enc, f"layer{li}", _seq(*blocks))
+        enc.fc = nn.Linear(512, 1000)   # present in torchvision's state dict; unused by the path
+        self.encoder = enc
+
+
+class CostVolumeModule(_ParamsOnly):
+    """Options of CostVolumeModule (monorec_model.py:132-148); no parameters."""
+
+    def __init__(self, use_mono=True, use_stereo=False, use_ssim=True, patch_size=3,
+                 channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, not_center_cv=False, sfcv_mult_mask=True):
+        super().__init__()
+        self.use_mono, self.use_stereo, self.use_ssim = use_mono, use_stereo, use_ssim
+        self.patch_size = patch_size
+        self.border_radius = patch_size // 2 + 1
+        self.channel_weights = tuple(channel_weights)
+        self.alpha = alpha
+        self.not_center_cv = not_center_cv
+        self.sfcv_mult_mask = sfcv_mult_mask
+
+
+class MaskModule(_ParamsOnly):
+    """Parameters of MaskModule (monorec_model.py:287-343)."""
+
+    def __init__(self, depth_steps=32, feature_channels=(64, 64, 128, 256, 512), use_cv=True, use_features=True):
+        super().__init__()
+        self.depth_steps = depth_steps
+        self.feat_chns = feature_channels
+        self.use_cv, self.use_features = use_cv, use_features
+        ec = (depth_steps, 48, 64, 96, 96)
+        dc = (96, 96, 64, 48)
+        fc = tuple(int(c) for c in feature_channels)
+
+        def cr(cin, cout):
+            return _Named(conv=_conv(cin, cout, 3))
+
+        enc = []
+        for i in range(5):
+            mods = [cr(ec[i - 1] if i else ec[0], ec[i]), cr(ec[i], ec[i])]
+            enc.append(_seq(*mods) if i == 0 else _seq(nn.MaxPool2d(2), *mods))
+        self.enc = nn.ModuleList(enc)
+        up_in = (ec[4] + fc[3], dc[0], dc[1], dc[2])
+        up_out = (dc[0], dc[0], dc[1], dc[2])
+        cat_in = (up_out[0] + ec[3] + fc[2], up_out[1] + ec[2] + fc[1], up_out[2] + ec[1] + fc[0], up_out[3] + ec[0])
+        dec = []
+        for i in range(4):
+            dec.append(_seq(_Named(conv=_conv(up_in[i], up_out[i], 2)), cr(cat_in[i], dc[i]), cr(dc[i], dc[i])))
+        self.dec = nn.ModuleList(dec)
+        self.classifier = _seq(_conv(dc[3], 1, 1), nn.Sigmoid())
+
+
+class DepthModule(_ParamsOnly):
+    """Parameters of DepthModule (monorec_model.py:476-524)."""
+
+    def __init__(self, depth_steps=32, feature_channels=(64, 64, 128, 256, 512), large_model=False):
+        super().__init__()
+        if large_model:
+            raise NotImplementedError("depth_large_model=True is outside the MI355X hot-path scope (SURVEY.md f-4)")
+        self.depth_steps = depth_steps
+        self.feat_chns = feature_channels
+        fc = tuple(int(c) for c in feature_channels)
+        ec = (48, 64, 128, 192, 256)
+        dc = (256, 128, 64, 48, 32, 24)
+        ks = (7, 7, 5, 5, 3)
+
+        def cr2(cin, cout, k, s=1):
+            return _Named(conv_y=nn.Conv2d(cin, cout, (k, 1), stride=(s, 1)),
+                          conv_x=nn.Conv2d(cout, cout, (1, k), stride=(1, s)))
+
+        def refine(cin, cout):
+            return _Named(conv2d_t=nn.ConvTranspose2d(cin, cout, 4, stride=2))
+
+        cin = depth_steps + 3
+        enc = []
+        for i in range(5):
+            enc.append(_seq(cr2(cin, ec[i], ks[i], 1 if i == 0 else 2), cr2(ec[i], ec[i], 3)))
+            cin = ec[i]
+        self.enc = nn.ModuleList(enc)
+        self.dec = nn.ModuleList([
+            refine(ec[4], dc[0]),
+            _seq(refine(ec[3] + fc[2] + dc[0], dc[1]), cr2(dc[1], dc[1], 3)),
+            _seq(refine(ec[2] + fc[1] + dc[1], dc[2]), cr2(dc[2], dc[2], 3)),
+            refine(ec[1] + fc[0] + dc[2], dc[3]),
+            _seq(cr2(ec[0] + dc[3], dc[4], 3), _Placeholder(), _conv(dc[4], dc[5], 3), nn.LeakyReLU(0.1)),
+        ])
+        self.predictors = nn.ModuleList([_seq(_Placeholder(), _conv(c, 1, 3)) for c in dc[:3] + dc[-1:]])
+
+
+# --------------------------------------------------------------------------------------------------
+def host_geometry(keyframe_intrinsics, keyframe_pose, intrinsics, poses):
+    """The 4x4 algebra of CostVolumeModule.forward on CPU fp32 tensors, operation for operation
+    (monorec_model.py:171 inverse(pose); :198 inverse(K_kf); :207 ext @ pose_kf; layers.py:65 K @ T).
+
+    Done on the host with the same ATen CPU operators as the reference so that the matrices handed to
+    the kernel are bit-identical to the reference's (the only ill-conditioned step of the path,
+    SURVEY.md section 0).  Returns kinv (B,9) and proj (B,F,12)."""
+    b = keyframe_pose.shape[0]
+    nf = len(poses)
+    extr = [torch.inverse(p) for p in poses]
+    kinv = torch.empty(b, 9)
+    proj = torch.empty(b, nf, 12)
+    for n in range(b):
+        kinv[n] = torch.inverse(keyframe_intrinsics[n]).unsqueeze(0)[:, :3, :3].reshape(9)
+        for f in range(nf):
+            t = extr[f][n] @ keyframe_pose[n]
+            proj[n, f] = torch.matmul(intrinsics[f][n].unsqueeze(0), t.unsqueeze(0))[:, :3, :].reshape(12)
+    return kinv, proj
+
+
+def depth_hypotheses(inv_depth_min_max, steps):
+    """monorec_model.py:675-677,184: the bounds pass through fp32 tensors and `.item()` before linspace."""
+    lo = torch.tensor([inv_depth_min_max[1]], dtype=torch.float32)[0].item()
+    hi = torch.tensor([inv_depth_min_max[0]], dtype=torch.float32)[0].item()
+    return 1 / torch.linspace(lo, hi, int(steps))
+
+
+class MonoRecModel(nn.Module):
+    """MI355X-native MonoRecModel: same constructor / attributes / state dict / forward contract as the
+    reference class (monorec_model.py:560-729); inference (eval, pretrain_mode=0) only."""
+
+    def __init__(self, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, pretrain_mode=False, pretrain_dropout=0.0,
+                 pretrain_dropout_mode=0, augmentation=None, use_mono=True, use_stereo=False, use_ssim=True,
+                 sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
+                 depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
+                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=True):
+        super().__init__()
+        self.inv_depth_min_max = inv_depth_min_max
+        self.cv_depth_steps = cv_depth_steps
+        self.use_mono = use_mono
+        self.use_stereo = use_stereo
+        self.use_ssim = use_ssim
+        self.sfcv_mult_mask = sfcv_mult_mask
+        self.pretrain_mode = int(pretrain_mode)
+        self.pretrain_dropout = pretrain_dropout
+        self.pretrain_dropout_mode = pretrain_dropout_mode
+        self.augmentation = augmentation
+        self.simple_mask = simple_mask
+        self.mask_use_cv = mask_use_cv
+        self.mask_use_feats = mask_use_feats
+        self.cv_patch_size = cv_patch_size
+        self.no_cv = no_cv
+        self.depth_large_model = depth_large_model
+        self.checkpoint_location = checkpoint_location
+        self.mask_cp_loc = mask_cp_loc
+        self.depth_cp_loc = depth_cp_loc
+        self.freeze_module = freeze_module
+        self.freeze_resnet = freeze_resnet
+        unsupported = dict(pretrain_mode=self.pretrain_mode != 0, use_stereo=bool(use_stereo), use_mono=not use_mono,
+                           use_ssim=use_ssim not in (True, 1), sfcv_mult_mask=not sfcv_mult_mask,
+                           simple_mask=bool(simple_mask), mask_use_cv=not mask_use_cv, mask_use_feats=not mask_use_feats,
+                           cv_patch_size=cv_patch_size != 3, no_cv=bool(no_cv), augmentation=augmentation not in (None, "none"))
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(
+                "monorec_amd implements the default inference configuration of the reference only; "
+                f"unsupported non-default options: {bad} (SURVEY.md section 8 f-4)")
+        self._hip_graph = bool(hip_graph)
+        self._plans = {}
+        self._graphs = {}
+        self._side_stream = None
+
+        self._feature_extractor = ResnetEncoder(num_layers=18, pretrained=True)
+        if self.freeze_resnet:
+            for p in self._feature_extractor.parameters(True):
+                p.requires_grad_(False)
+        self.cv_module = CostVolumeModule(use_mono=use_mono, use_stereo=use_stereo, use_ssim=use_ssim,
+                                          sfcv_mult_mask=self.sfcv_mult_mask, patch_size=cv_patch_size)
+        self.att_module = MaskModule(self.cv_depth_steps, self._feature_extractor.num_ch_enc,
+                                     use_cv=mask_use_cv, use_features=mask_use_feats)
+        self.depth_module = DepthModule(self.cv_depth_steps, feature_channels=self._feature_extractor.num_ch_enc,
+                                        large_model=self.depth_large_model)
+        self.augmenter = None
+
+        def load(cp_list, sub=None, prefix=None):
+            if cp_list is None:
+                return
+            for cp in (cp_list if isinstance(cp_list, (list, tuple)) else [cp_list]):
+                checkpoint = torch.load(cp, map_location=torch.device("cpu"))
+                sd = _filter_state_dict(checkpoint["state_dict"], checkpoint["arch"] == "DataParallel")
+                if sub is None:
+                    self.load_state_dict(sd, strict=False)
+                else:
+                    sub.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix)}, strict=False)
+
+        load(self.checkpoint_location)                                             # monorec_model.py:630-637
+        load(self.mask_cp_loc, self.att_module, "att_module")                      # :639-647
+        load(self.depth_cp_loc, self.depth_module, "depth_module")                 # :649-657
+        for module_name in self.freeze_module:                                     # :659-663
+            module = getattr(self, module_name + "_module")
+            module.eval()
+            for param in module.parameters(True):
+                param.requires_grad_(False)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+
+    # ------------------------------------------------------------------ plan management
+    def _invalidate(self):
+        self._plans = {}
+        self._graphs = {}
+
+    def _apply(self, fn, *a, **k):   # .to() / .cuda(): parameters moved or cast -> repack
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def _plan_for(self, batch, h, w, nf, device):
+        key = (batch, h, w, nf, self.cv_depth_steps, str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            state = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
+            plan = Plan(state, batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
+                        alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights)
+            plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
+            plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
+            plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
+            self._plans[key] = plan
+        return key, plan
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data_dict):
+        if self.training:
+            raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
+        keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
+        kf_intrinsics, kf_pose = data_dict["keyframe_intrinsics"], data_dict["keyframe_pose"]
+        frames = list(data_dict["frames"])
+        poses, intrinsics = list(data_dict["poses"]), list(data_dict["intrinsics"])
+        if not keyframe.is_cuda:
+            raise RuntimeError("monorec_amd.MonoRecModel needs its inputs on a HIP device (cuda:N on ROCm); "
+                               "there is no CPU path")
+        _lib.load()
+        if "cv_depths" in data_dict:
+            raise NotImplementedError("per-pixel cv_depths override is not supported (SURVEY.md f-4)")
+        b, c, h, w = keyframe.shape
+        nf = len(frames)
+        device = keyframe.device
+        data_dict["inv_depth_min"] = keyframe.new_tensor([self.inv_depth_min_max[0]])
+        data_dict["inv_depth_max"] = keyframe.new_tensor([self.inv_depth_min_max[1]])
+        data_dict["cv_depth_steps"] = keyframe.new_tensor([self.cv_depth_steps], dtype=torch.int32)
+
+        key, plan = self._plan_for(b, h, w, nf, device)
+        main = torch.cuda.current_stream(device)
+        if self._side_stream is None or self._side_stream.device != device:
+            self._side_stream = torch.cuda.Stream(device)
+        side = self._side_stream
+        start_time = time.time()
+
+        # 1. pose / intrinsics matrices -> pinned host memory on a side stream (tiny, overlaps the encoder)
+        mats = torch.stack([kf_intrinsics, kf_pose] + intrinsics + poses).float()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            plan.host_mats.copy_(mats, non_blocking=True)
+            mats_done = torch.cuda.Event()
+            mats_done.record(side)
+        mats.record_stream(side)
+
+        # 2. images into the plan's resident buffers + ResNet encoder stage (pose independent)
+        plan.buf["keyframe"].copy_(keyframe)
+        for f in range(nf):
+            plan.buf["frames"][f].copy_(frames[f])
+        self._run_stage(key, plan, "encoder", main)
+
+        # 3. host 4x4 algebra while the encoder runs, then upload
+        mats_done.synchronize()
+        hm = plan.host_mats
+        kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+        plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
+        plan.host_geom[b * 9:].copy_(proj.reshape(-1))
+        plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
+
+        # 4. cost volume -> mask -> depth
+        self._run_stage(key, plan, "main", main)
+        data_dict["cv_module_time"] = keyframe.new_tensor([time.time() - start_time])
+
+        data_dict["cost_volume"] = plan.buf["cost_volume"]
+        data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
+        data_dict["image_features"] = list(plan.feats)
+        data_dict["cv_mask"] = plan.buf["cv_mask"]
+        data_dict["predicted_inverse_depths"] = list(plan.preds)
+        data_dict["result"] = data_dict["predicted_inverse_depths"][0]
+        data_dict["mask"] = data_dict["cv_mask"]
+        return data_dict
+
+    def _run_stage(self, key, plan, stage, stream):
+        if not self._hip_graph:
+            plan.run_stage(stage, stream.cuda_stream)
+            return
+        gkey = (key, stage)
+        entry = self._graphs.get(gkey)
+        if entry is None:
+            # first call: eager (also sets per-kernel attributes); second call: capture; then replay
+            plan.run_stage(stage, stream.cuda_stream)
+            self._graphs[gkey] = "warm"
+            return
+        if entry == "warm":
+            graph = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(stream.device)
+            cap.wait_stream(stream)
+            with torch.cuda.graph(graph, stream=cap):
+                plan.run_stage(stage, torch.cuda.current_stream(stream.device).cuda_stream)
+            stream.wait_stream(cap)
+            self._graphs[gkey] = graph
+            entry = graph
+        entry.replay()
+
+
+def _filter_state_dict(state_dict, data_parallel=False):
+    """Key clean-up applied to reference checkpoints (utils/util.py:244-248): strip the DataParallel
+    'module.' prefix, drop entries of list-style models 1-9 and strip a leading '0.'."""
+    if data_parallel:
+        state_dict = {k[7:]: v for k, v in state_dict.items()}
+    out = {}
+    for k, v in state_dict.items():
+        if k[0] in "123456789":
+            continue
+        out[k[2:] if k.startswith("0") else k] = v
+    return out

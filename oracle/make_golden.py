@@ -1,0 +1,190 @@
+"""TEST INFRASTRUCTURE ONLY.  Generate tests/golden/* from the REAL reference and pin the oracle.
+
+Runs only in the build container (needs /root/reference):   python oracle/make_golden.py
+
+For every case it
+  1. builds seeded synthetic inputs (monorec_amd.synth.make_batch) and key-addressed seeded weights
+     (monorec_amd.synth.seeded_state_dict) - both reproducible anywhere without the reference,
+  2. runs the unmodified reference `MonoRecModel` (imported through oracle/ref_shims.py) on CPU fp32,
+  3. asserts that oracle/monorec_oracle.py reproduces every output of the reference bit for bit,
+  4. stores the reference outputs as a compact fixture: full `result`/`cv_mask` maps, and for the big
+     tensors a deterministic strided sample + float64 sum / abs-sum / shape.
+It also records the low-level arithmetic pins (MKL sgemm FMA order, grid_sample formula, avg_pool
+order) that cost_volume.hip relies on, and the reference's state-dict key/shape table.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from monorec_amd import synth  # noqa: E402
+from oracle import monorec_oracle as orc  # noqa: E402
+from oracle import ref_shims  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MAX_SAMPLES = 8192
+
+# name -> (batch, H, W, frames, depth_steps, input seed, hard_pose, full-model?)
+CASES = {
+    "small": (2, 64, 96, 2, 8, 1, False, True),
+    "small_hard_pose": (2, 64, 96, 2, 8, 2, True, True),
+    "d64_f4": (1, 64, 128, 4, 64, 3, False, True),
+    "c1_256x512": (1, 256, 512, 2, 32, 1, False, True),
+    "cv_only_ragged": (1, 40, 72, 3, 12, 4, False, False),
+}
+
+
+def sample(t):
+    """Deterministic compact summary of a tensor (see tests/golden_util.py for the reader)."""
+    flat = t.detach().reshape(-1).to(torch.float32)
+    stride = max(1, flat.numel() // MAX_SAMPLES)
+    return {
+        "samples": flat[::stride].numpy().copy(),
+        "stride": np.int64(stride),
+        "sum": np.float64(flat.double().sum().item()),
+        "abssum": np.float64(flat.double().abs().sum().item()),
+        "shape": np.array(t.shape, dtype=np.int64),
+    }
+
+
+def flatten_outputs(out):
+    items = {"result": out["result"], "cv_mask": out["cv_mask"], "cost_volume": out["cost_volume"]}
+    for i, t in enumerate(out["single_frame_cvs"]):
+        items[f"sfcv{i}"] = t
+    for i, t in enumerate(out["image_features"]):
+        items[f"feat{i}"] = t
+    for i, t in enumerate(out["predicted_inverse_depths"]):
+        items[f"pred{i}"] = t
+    return items
+
+
+def pin_low_level():
+    """Bitwise facts about the CPU reference arithmetic that cost_volume.hip reproduces."""
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+    h, w, d = 64, 96, 8
+    batch = synth.make_batch(1, h, w, 2, seed=1)
+    stages = {}
+    orc.cost_volume(batch, steps=d, stages=stages)
+    inv_k = torch.inverse(batch["keyframe_intrinsics"][0]).unsqueeze(0)
+    coord = orc.pixel_grid(h, w)
+    rays = (inv_k[:, :3, :3] @ coord)[0].numpy()
+    k = inv_k[0, :3, :3].numpy()
+    x, y, one = coord[0, 0].numpy(), coord[0, 1].numpy(), coord[0, 2].numpy()
+    facts = {}
+    ok = True
+    for i in range(3):
+        v = fma(np.full_like(x, k[i, 2]), one, fma(np.full_like(x, k[i, 1]), y, f32(k[i, 0]) * x))
+        ok &= bool((v == rays[i]).all())
+    facts["rays_fma_k_ascending"] = ok
+    depths = orc.depth_hypotheses(0.33, 0.0025, d)
+    pts = torch.cat([depths.view(d, 1, 1) * torch.from_numpy(rays).unsqueeze(0), torch.ones(d, 1, h * w)], 1)
+    proj = orc.projection_matrix(batch["intrinsics"][0][0], batch["poses"][0][0], batch["keyframe_pose"][0])
+    pc = torch.matmul(proj, pts).numpy()
+    p, xx = proj[0].numpy(), pts.numpy()
+    ok = True
+    for i in range(3):
+        bb = [np.full_like(xx[:, 0], p[i, j]) for j in range(4)]
+        v = fma(bb[3], xx[:, 3], fma(bb[2], xx[:, 2], fma(bb[1], xx[:, 1], bb[0] * xx[:, 0])))
+        ok &= bool((v == pc[:, i]).all())
+    facts["projection_fma_k_ascending"] = ok
+    grid = orc.sample_grid(pts, proj, h, w)
+    gx, gy = grid[..., 0].numpy().reshape(d, -1), grid[..., 1].numpy().reshape(d, -1)
+    z = pc[:, 2] + f32(1e-7)
+    u = np.clip((pc[:, 0] / z / f32(w - 1) - f32(0.5)) * f32(2), -2, 2)
+    facts["grid_true_division"] = bool((u == gx).all())
+    img = batch["frames"][0][0].numpy()
+    warped = torch.nn.functional.grid_sample(batch["frames"][0][0:1].expand(d, -1, -1, -1), grid, mode="bilinear",
+                                             padding_mode="zeros", align_corners=False).numpy()
+    sx = fma(gx + f32(1), np.full_like(gx, w / 2), np.full_like(gx, -0.5))
+    sy = fma(gy + f32(1), np.full_like(gy, h / 2), np.full_like(gy, -0.5))
+    x0, y0 = np.floor(sx), np.floor(sy)
+    ww, nn_ = sx - x0, sy - y0
+    e, s = f32(1) - ww, f32(1) - nn_
+    nw, ne, sw, se = s * e, s * ww, nn_ * e, nn_ * ww
+    x0i, y0i = x0.astype(np.int64), y0.astype(np.int64)
+
+    def tap(c, yi, xi):
+        inb = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)
+        return np.where(inb, img[c][np.clip(yi, 0, h - 1), np.clip(xi, 0, w - 1)], f32(0))
+
+    ok = True
+    for c in range(3):
+        v = fma(tap(c, y0i + 1, x0i + 1), se, fma(tap(c, y0i + 1, x0i), sw, fma(tap(c, y0i, x0i + 1), ne, tap(c, y0i, x0i) * nw)))
+        ok &= bool((v.reshape(d, h, w) == warped[:, c]).all())
+    facts["grid_sample_fma_unnormalize_and_bilinear_chain"] = ok
+    a = torch.rand(2, 3, 12, 14)
+    ap = torch.nn.functional.pad(a, (1, 1, 1, 1), mode="reflect").numpy()
+    acc = None
+    for ky in range(3):
+        for kx in range(3):
+            t = ap[:, :, ky:ky + 12, kx:kx + 14]
+            acc = t.copy() if acc is None else acc + t
+    facts["avg_pool_sequential_sum_div9"] = bool((acc / f32(9) == torch.nn.functional.avg_pool2d(torch.from_numpy(ap), 3, 1).numpy()).all())
+    return facts
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.manual_seed(0)
+    Ref = ref_shims.reference_model_class()
+    report = {"torch": torch.__version__, "cases": {}, "low_level": pin_low_level()}
+    assert all(report["low_level"].values()), report["low_level"]
+
+    ref32 = Ref(cv_depth_steps=32)
+    keys = {k: list(v.shape) for k, v in ref32.state_dict().items()}
+    with open(os.path.join(GOLDEN, "state_dict_keys_d32.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+    for name, (b, h, w, nf, d, seed, hard, full) in CASES.items():
+        batch = synth.make_batch(b, h, w, nf, seed=seed, hard_pose=hard)
+        store = {}
+        if full:
+            ref = Ref(cv_depth_steps=d).eval()
+            sd = synth.seeded_state_dict(ref.state_dict(), seed=0)
+            ref.load_state_dict(sd, strict=True)
+            with torch.no_grad():
+                out_ref = ref(synth.clone_batch(batch))
+            out_orc = orc.forward(sd, batch, cv_depth_steps=d)
+            items_ref, items_orc = flatten_outputs(out_ref), flatten_outputs(out_orc)
+        else:
+            ref = Ref(cv_depth_steps=d).eval()
+            dd = synth.clone_batch(batch)
+            dd["inv_depth_min"], dd["inv_depth_max"] = torch.tensor([0.33]), torch.tensor([0.0025])
+            dd["cv_depth_steps"] = torch.tensor([d], dtype=torch.int32)
+            with torch.no_grad():
+                dd = ref.cv_module(dd)
+            cv, sf = orc.cost_volume(batch, steps=d)
+            items_ref = {"cost_volume": dd["cost_volume"], **{f"sfcv{i}": t for i, t in enumerate(dd["single_frame_cvs"])}}
+            items_orc = {"cost_volume": cv, **{f"sfcv{i}": t for i, t in enumerate(sf)}}
+        diffs = {}
+        for k in items_ref:
+            diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+            assert diffs[k] == 0.0, f"oracle deviates from the reference on {name}/{k}: {diffs[k]}"
+            sm = sample(items_ref[k])
+            for kk, vv in sm.items():
+                store[f"{k}.{kk}"] = vv
+        for k in ("result", "cv_mask"):
+            if k in items_ref:
+                store[f"{k}.full"] = items_ref[k].numpy()
+        if not full:
+            store["cost_volume.full"] = items_ref["cost_volume"].numpy()
+        store["meta"] = np.array([b, h, w, nf, d, seed, int(hard), int(full)], dtype=np.int64)
+        np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **store)
+        report["cases"][name] = {"config": [b, h, w, nf, d, seed, hard, full], "oracle_vs_reference_maxabs": diffs}
+        print(name, "ok; oracle == reference on", len(diffs), "tensors")
+    with open(os.path.join(GOLDEN, "PINNING.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+    print("wrote", GOLDEN)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+"""Reader for the fixtures written by oracle/make_golden.py (outputs of the real reference)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        b, h, w, nf, d, seed, hard, full = [int(v) for v in self.z["meta"]]
+        self.batch, self.h, self.w, self.frames, self.depths = b, h, w, nf, d
+        self.seed, self.hard_pose, self.full_model = seed, bool(hard), bool(full)
+
+    def names(self):
+        return sorted({k.rsplit(".", 1)[0] for k in self.z.files if k != "meta"})
+
+    def make_inputs(self):
+        from monorec_amd import synth
+        return synth.make_batch(self.batch, self.h, self.w, self.frames, seed=self.seed, hard_pose=self.hard_pose)
+
+    def compare(self, name, tensor, atol, rtol=0.0, max_outlier_frac=0.0):
+        """Compare `tensor` with the stored reference output `name`.
+
+        Returns a dict with max abs error over the stored samples (and the full map when stored).
+        `max_outlier_frac` tolerates a tiny fraction of entries beyond the tolerance (validity-mask
+        flips of the cost volume) - 0 means none."""
+        t = tensor.detach().to("cpu", torch.float32)
+        assert list(t.shape) == [int(v) for v in self.z[name + ".shape"]], (name, t.shape)
+        flat = t.reshape(-1)
+        stride = int(self.z[name + ".stride"])
+        got = flat[::stride].numpy()
+        want = self.z[name + ".samples"]
+        if (name + ".full") in self.z.files:
+            got, want = t.numpy().reshape(-1), self.z[name + ".full"].reshape(-1)
+        err = np.abs(got - want)
+        tol = atol + rtol * np.abs(want)
+        bad = err > tol
+        frac = float(bad.mean())
+        info = {"max_abs": float(err.max()), "outlier_frac": frac, "n": int(err.size)}
+        assert frac <= max_outlier_frac, f"{name}: {info} (atol={atol}, rtol={rtol})"
+        return info

@@ -1,0 +1,211 @@
+"""CPU: the C-ABI library loads and exports what include/monorec_hip.h declares (no GPU compute),
+and the host logic around it (padding, ConvTranspose phases, BN folding, weight packing, pose algebra,
+model surface) is right."""
+import ctypes
+import json
+import math
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import GOLDEN
+from monorec_amd import _lib, engine, synth
+from monorec_amd.model import MonoRecModel, depth_hypotheses, host_geometry
+from oracle import monorec_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "monorec_hip.h")
+
+
+# ------------------------------------------------------------------------------------------ ABI
+def test_library_exports_every_declared_symbol(hip_lib):
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(mr_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
+    for name in declared:
+        assert getattr(hip_lib, name) is not None
+    assert hip_lib.mr_abi_version() == 1
+    assert b"LDS" in hip_lib.mr_error_string(-3)
+
+
+def test_conv_desc_layout_matches_the_c_struct():
+    fields = ", ".join(f'offsetof(mr_conv_desc, {n})' for n, _ in _lib.ConvDesc._fields_)
+    src = f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(){{ size_t o[] = {{{fields}}};' \
+          'printf("%zu", sizeof(mr_conv_desc)); for (unsigned i = 0; i < sizeof(o)/sizeof(o[0]); ++i) printf(" %zu", o[i]); return 0; }'
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", c, "-o", exe], check=True)
+        vals = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_lib.ConvDesc)
+    assert vals[1:] == [getattr(_lib.ConvDesc, n).offset for n, _ in _lib.ConvDesc._fields_]
+
+
+def test_bad_arguments_are_reported_not_crashed(hip_lib):
+    d = _lib.ConvDesc()
+    assert hip_lib.mr_conv2d_lds_bytes(ctypes.byref(d)) == -1
+    assert hip_lib.mr_conv2d_f32(ctypes.byref(d), None) == -1
+    assert hip_lib.mr_max_over_frames_f32(None, None, 2, 16, None) == -1
+    assert hip_lib.mr_cost_volume_f32(None, None, 2, None, None, None, 1, 32, 64, 64, 10.0, None, None, None, None) == -1
+
+
+# ------------------------------------------------------------------------------------------ host logic
+@pytest.mark.parametrize("n,k,s", [(256, 7, 2), (256, 5, 2), (256, 3, 2), (512, 2, 1), (64, 3, 1), (9, 7, 2), (8, 1, 2)])
+def test_same_pad_matches_reference_rule(n, k, s):
+    lo, hi = engine.same_pad(n, k, s)
+    total = s * (math.ceil(n / s) - 1) + k - n
+    assert lo + hi == total and lo == total // 2 and hi - lo in (0, 1)
+    assert (n + lo + hi - k) // s + 1 == math.ceil(n / s)
+
+
+def test_transposed_conv_phase_decomposition():
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 6, 7)
+    wt = torch.randn(5, 4, 4, 4)
+    bias = torch.randn(4)
+    want = F.conv_transpose2d(x, wt, bias, stride=2)[:, :, 1:-1, 1:-1]      # layers.Refine crop
+    got = torch.zeros_like(want)
+    for (py, px), (w, pt, pl) in engine.transposed_phase_weights(wt).items():
+        xp = F.pad(x, [pl, 1 - pl, pt, 1 - pt])
+        got[:, :, py::2, px::2] = F.conv2d(xp, w, bias)
+    assert torch.allclose(got, want, atol=1e-5)
+
+
+def test_batchnorm_folding():
+    torch.manual_seed(0)
+    w = torch.randn(8, 3, 3, 3)
+    sd = {"bn.weight": torch.rand(8) + .5, "bn.bias": torch.randn(8), "bn.running_mean": torch.randn(8),
+          "bn.running_var": torch.rand(8) + .5}
+    x = torch.randn(2, 3, 9, 9)
+    want = F.batch_norm(F.conv2d(x, w), sd["bn.running_mean"], sd["bn.running_var"], sd["bn.weight"], sd["bn.bias"],
+                        False, 0.0, 1e-5)
+    wf, bf = engine.fold_batchnorm(w, sd, "bn")
+    assert torch.allclose(F.conv2d(x, wf, bf), want, atol=1e-5)
+
+
+def _emulate_kernel_k_loop(packed, srcs, cout, kh, kw, stride, pad, grid):
+    """Python model of conv_mfma_kernel's K walk over the packed weight stream (conv_layout.h):
+    D[cout][pixel] += A[cout][k] * B[k][pixel] with A fragments read in stream order."""
+    n = srcs[0].shape[0]
+    ho, wo = grid
+    cb_n = (cout + 15) // 16
+    out = np.zeros((n, cb_n * 16, ho, wo), np.float64)
+    off = 0
+    for s in srcs:
+        c_real = s.shape[1]
+        cpad = (c_real + 3) // 4 * 4
+        xp = np.zeros((n, cpad, s.shape[2] + 2 * 8, s.shape[3] + 2 * 8), np.float64)
+        xp[:, :c_real, 8:-8, 8:-8] = s.numpy()
+        for c0 in range(0, cpad, 16):
+            ck = min(16, cpad - c0)
+            for tap in range(kh * kw):
+                ky, kx = divmod(tap, kw)
+                for c4 in range(ck // 4):
+                    for cb in range(cb_n):
+                        frag = packed[off:off + 64].numpy().astype(np.float64)
+                        off += 64
+                        a = frag.reshape(4, 16)        # lane = k*16 + cout_in_block
+                        for k in range(4):
+                            ch = c0 + c4 * 4 + k
+                            ys = 8 - pad[0] + ky + stride[0] * np.arange(ho)
+                            xs = 8 - pad[1] + kx + stride[1] * np.arange(wo)
+                            b = xp[:, ch][:, ys][:, :, xs]                      # (n, ho, wo)
+                            out[:, cb * 16:(cb + 1) * 16] += a[k][None, :, None, None] * b[:, None]
+    assert off == packed.numel()
+    return torch.from_numpy(out[:, :cout]).float()
+
+
+@pytest.mark.parametrize("srcs_c,cout,k,stride,pad", [
+    ((32, 3), 48, (7, 1), (1, 1), (3, 0)),      # DepthModule enc0 conv_y: concat of cv + keyframe (3 -> pad 4)
+    ((3,), 64, (7, 7), (2, 2), (3, 3)),         # ResNet stem
+    ((24,), 1, (3, 3), (1, 1), (1, 1)),         # head on 24 channels (16 + 8 chunk), single output channel
+    ((16, 20, 8), 40, (2, 2), (1, 1), (1, 0)),  # three sources, partial last cout block
+])
+def test_packed_weight_stream_matches_conv2d(hip_lib, srcs_c, cout, k, stride, pad):
+    torch.manual_seed(1)
+    n, h, w = 1, 10, 12
+    srcs = [torch.randn(n, c, h, w) for c in srcs_c]
+    weight = torch.randn(cout, sum(srcs_c), *k)
+    ho = (h + 2 * pad[0] - k[0]) // stride[0] + 1
+    wo = (w + 2 * pad[1] - k[1]) // stride[1] + 1
+    want = F.conv2d(F.pad(torch.cat(srcs, 1), [pad[1], pad[1], pad[0], pad[0]]), weight, stride=stride)
+    packed = engine.pack_conv_weight(weight, list(srcs_c))
+    got = _emulate_kernel_k_loop(packed, srcs, cout, k[0], k[1], stride, pad, (ho, wo))
+    assert torch.allclose(got, want, atol=1e-4), float((got - want).abs().max())
+
+
+def test_host_geometry_is_bit_identical_to_the_oracle_algebra():
+    for hard in (False, True):
+        b = synth.make_batch(2, 64, 96, 3, seed=5, hard_pose=hard)
+        kinv, proj = host_geometry(b["keyframe_intrinsics"], b["keyframe_pose"], b["intrinsics"], b["poses"])
+        for n in range(2):
+            assert torch.equal(kinv[n].view(3, 3), torch.inverse(b["keyframe_intrinsics"][n])[:3, :3])
+            for f in range(3):
+                want = orc.projection_matrix(b["intrinsics"][f][n], b["poses"][f][n], b["keyframe_pose"][n])
+                assert torch.equal(proj[n, f].view(3, 4), want[0])
+
+
+def test_depth_hypotheses_equal_reference_formula():
+    for d in (8, 32, 48, 64):
+        assert torch.equal(depth_hypotheses((0.33, 0.0025), d), orc.depth_hypotheses(0.33, 0.0025, d))
+
+
+# ------------------------------------------------------------------------------------------ model surface
+def test_state_dict_keys_equal_reference_fixture():
+    want = json.load(open(os.path.join(GOLDEN, "state_dict_keys_d32.json")))
+    got = {k: list(v.shape) for k, v in MonoRecModel(cv_depth_steps=32).state_dict().items()}
+    assert got == want
+
+
+def test_public_attributes_are_json_serialisable():
+    m = MonoRecModel(inv_depth_min_max=[0.33, 0.0025], checkpoint_location=None, pretrain_mode=0, pretrain_dropout=0,
+                     use_stereo=False, use_mono=True, use_ssim=1)
+    public = {k: v for k, v in m.__dict__.items() if not k.startswith("_")}     # evaluate.py:36-43
+    json.dumps({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in public.items()})
+    assert public["cv_depth_steps"] == 32 and public["training"] is True
+
+
+@pytest.mark.parametrize("kw", [dict(use_stereo=True), dict(pretrain_mode=1), dict(simple_mask=True), dict(use_ssim=2),
+                                dict(depth_large_model=True), dict(no_cv=True), dict(cv_patch_size=5)])
+def test_unsupported_options_raise(kw):
+    with pytest.raises(NotImplementedError):
+        MonoRecModel(**kw)
+
+
+def test_forward_refuses_cpu_inputs_and_training_mode():
+    m = MonoRecModel(cv_depth_steps=8)
+    batch = synth.make_batch(1, 64, 96, 2)
+    with pytest.raises(NotImplementedError):
+        m(batch)                       # still in training mode
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(batch)
+    with pytest.raises(KeyError):
+        m({"keyframe": batch["keyframe"]})
+
+
+def test_checkpoint_loading_strips_dataparallel_prefix(tmp_path):
+    m = MonoRecModel(cv_depth_steps=8)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=3)
+    cp = tmp_path / "cp.pth"
+    torch.save({"arch": "DataParallel", "state_dict": {"module." + k: v for k, v in sd.items()}}, cp)
+    m2 = MonoRecModel(cv_depth_steps=8, checkpoint_location=[str(cp)])
+    assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+
+
+def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
+    """Builds the whole launch plan with CPU buffers (no launches): every descriptor validates, LDS stays
+    inside a CU, and the conv MACs equal the reference's hook count (61.07 GMAC @ c1)."""
+    m = MonoRecModel(cv_depth_steps=32)
+    sd = synth.seeded_state_dict(m.state_dict())
+    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    assert abs(plan.conv_macs() / 1e9 - 61.07) < 0.01
+    assert max(c["lds"] for c in plan.conv_log) <= 64 * 1024
+    assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 for c in plan.conv_log)
+    assert len(plan.stages["encoder"]) == 21 and plan.stages["main"][0][0] == "cost_volume"

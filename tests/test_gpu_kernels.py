@@ -1,0 +1,219 @@
+"""GPU (MI355X): kernel-level parity of libmonorec_hip.so against the CPU oracle / plain torch fp32
+references, every call going through the C ABI (monorec_amd.engine.Plan -> ctypes -> mr_*)."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import Golden
+from monorec_amd import _lib, engine, synth
+from monorec_amd._lib import (ACT_ABS_TANH_AFFINE, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, IN_DIRECT,
+                              IN_MAXPOOL2, IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM)
+from monorec_amd.model import depth_hypotheses, host_geometry
+from oracle import monorec_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _run(plan):
+    plan.finalize()
+    plan.run_stage("main", _stream())
+    torch.cuda.synchronize()
+
+
+def _act_ref(x, act, p0, p1):
+    if act == ACT_RELU:
+        return F.relu(x)
+    if act == ACT_LEAKY_RELU:
+        return F.leaky_relu(x, p0)
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(x)
+    if act == ACT_ABS_TANH_AFFINE:
+        t = torch.abs(torch.tanh(x))
+        return (1 - t) * p0 + t * p1
+    return x
+
+
+CONV_CASES = [
+    # (srcs_c, cout, k, stride, pad, hw, batch, act, in_mode, tf, residual, (mb, nb, split_k))
+    ((32,), 32, (3, 3), (1, 1), (1, 1), (40, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1)),
+    ((32,), 48, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_LEAKY_RELU, IN_MAXPOOL2, TF_NONE, False, (3, 2, 1)),
+    ((3,), 64, (7, 7), (2, 2), (3, 3), (64, 96), 2, ACT_RELU, IN_DIRECT, TF_RESNET_NORM, False, (2, 2, 1)),
+    ((64,), 64, (3, 3), (1, 1), (1, 1), (16, 24), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 1)),
+    ((64,), 128, (3, 3), (2, 2), (1, 1), (16, 32), 1, ACT_RELU, IN_DIRECT, TF_NONE, False, (4, 1, 2)),
+    ((64,), 128, (1, 1), (2, 2), (0, 0), (16, 32), 2, ACT_NONE, IN_DIRECT, TF_NONE, False, (1, 2, 1)),
+    ((96, 256), 96, (2, 2), (1, 1), (0, 0), (4, 6), 1, ACT_NONE, IN_UPSAMPLE2, TF_NONE, False, (6, 1, 1)),
+    ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (6, 2, 4)),
+    ((32, 3), 48, (7, 1), (1, 1), (3, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 4, 1)),
+    ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (4, 2, 1)),
+    ((64,), 64, (1, 7), (1, 2), (0, 2), (32, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 2, 1)),
+    ((128,), 128, (1, 5), (1, 2), (0, 1), (16, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 1, 2)),
+    ((48,), 1, (1, 1), (1, 1), (0, 0), (32, 64), 2, ACT_SIGMOID, IN_DIRECT, TF_NONE, False, (1, 4, 1)),
+    ((24,), 1, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 4, 1)),
+    ((256,), 1, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 1, 8)),
+    ((512,), 512, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 4)),
+    ((32,), 24, (3, 3), (1, 1), (1, 1), (24, 40), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"conv{i}" for i in range(len(CONV_CASES))])
+def test_conv_matches_torch_fp32(hip_lib, case):
+    srcs_c, cout, k, stride, pad, (hs, ws), n, act, in_mode, tf, use_res, sched = case
+    g = torch.Generator().manual_seed(7)
+    srcs = [torch.randn(n, c, hs, ws, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    weight = torch.randn(cout, cin, *k, generator=g) / math.sqrt(cin * k[0] * k[1])
+    bias = torch.randn(cout, generator=g)
+    x = torch.cat(srcs, 1)
+    if tf == TF_RESNET_NORM:
+        x = ((x + 0.5) - 0.45) / 0.225
+    if in_mode == IN_UPSAMPLE2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    elif in_mode == IN_MAXPOOL2:
+        x = F.max_pool2d(x, 2)
+    hin, win = x.shape[2], x.shape[3]
+    ho = (hin + 2 * pad[0] - k[0]) // stride[0] + 1
+    wo = (win + 2 * pad[1] - k[1]) // stride[1] + 1
+    if in_mode == IN_UPSAMPLE2:          # Upconv pads (0,1,0,1): model/layers.py:355
+        ho, wo = hin, win
+        xr = F.pad(x, [0, 1, 0, 1])
+    else:
+        xr = F.pad(x, [pad[1], pad[1], pad[0], pad[0]])
+    ref = F.conv2d(xr.double(), weight.double(), bias.double(), stride=stride).float()[:, :, :ho, :wo]
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    p0, p1 = (0.1, 0.0) if act == ACT_LEAKY_RELU else (0.0025, 0.33)
+    ref = _act_ref(ref, act, p0, p1)
+
+    plan = engine.Plan.bare(DEV, schedule_override={"t": sched})
+    out = plan.alloc("out", n, cout, ho, wo)
+    out.fill_(float("nan"))
+    plan.conv("main", "t", [s.to(DEV) for s in srcs], weight, bias, out, stride=stride, pad=pad, grid=(ho, wo),
+              act=act, p0=p0, p1=p1, in_mode=in_mode, tf=tf, residual=res.to(DEV) if use_res else None)
+    _run(plan)
+    got = out.cpu()
+    assert not torch.isnan(got).any()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("mb", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_conv_every_register_tile(hip_lib, mb, nb):
+    g = torch.Generator().manual_seed(mb * 10 + nb)
+    x = torch.randn(2, 20, 24, 40, generator=g)
+    w = torch.randn(96, 20, 3, 3, generator=g) / 13.0
+    b = torch.randn(96, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    plan = engine.Plan.bare(DEV, schedule_override={"t": (mb, nb, 1)})
+    out = plan.alloc("out", 2, 96, 24, 40)
+    plan.conv("main", "t", [x.to(DEV)], w, b, out, pad=(1, 1), grid=(24, 40))
+    _run(plan)
+    assert (out.cpu() - ref).abs().max().item() < 2e-4
+
+
+def test_refine_transposed_conv(hip_lib):
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randn(2, 48, 8, 12, generator=g), torch.randn(2, 16, 8, 12, generator=g)]
+    wt = torch.randn(64, 40, 4, 4, generator=g) / 16.0
+    bias = torch.randn(40, generator=g)
+    sd = {"r.conv2d_t.weight": wt, "r.conv2d_t.bias": bias}
+    ref = orc.refine(sd, "r", torch.cat(srcs, 1))
+    plan = engine.Plan.bare(DEV, state=sd)
+    out = plan.alloc("out", 2, 40, 16, 24)
+    out.fill_(float("nan"))
+    plan.refine("main", "r", [s.to(DEV) for s in srcs], "r", out)
+    _run(plan)
+    assert (out.cpu() - ref).abs().max().item() < 2e-4
+
+
+def test_small_kernels(hip_lib):
+    lib = hip_lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 5, 18, 22, generator=g)
+    xd = x.to(DEV)
+    out = torch.empty(3, 5, 9, 11, device=DEV)
+    _lib.check(lib.mr_maxpool3x3s2_f32(xd.data_ptr(), out.data_ptr(), 15, 18, 22, _stream()))
+    assert torch.equal(out.cpu(), F.max_pool2d(x, 3, 2, 1))
+    fr = torch.randn(4, 2 * 6 * 8 * 10, generator=g)
+    frd = fr.to(DEV)
+    mx = torch.empty(2 * 6 * 8 * 10, device=DEV)
+    _lib.check(lib.mr_max_over_frames_f32(frd.data_ptr(), mx.data_ptr(), 4, fr.shape[1], _stream()))
+    assert torch.equal(mx.cpu(), fr.max(0)[0])
+    cv = torch.randn(2, 8, 16, 24, generator=g)
+    mask = torch.rand(2, 1, 16, 24, generator=g)
+    cvd, md = cv.to(DEV), mask.to(DEV)
+    _lib.check(lib.mr_apply_mask_f32(cvd.data_ptr(), md.data_ptr(), cvd.data_ptr(), 2, 8, 16 * 24, _stream()))
+    assert torch.equal(cvd.cpu(), (1 - mask) * cv)
+
+
+def _hip_cost_volume(batch, d):
+    lib = _lib.load()
+    kf = batch["keyframe"].to(DEV)
+    b, _, h, w = kf.shape
+    nf = len(batch["frames"])
+    frames = [f.to(DEV).contiguous() for f in batch["frames"]]
+    kinv, proj = host_geometry(batch["keyframe_intrinsics"], batch["keyframe_pose"], batch["intrinsics"], batch["poses"])
+    kinv, proj = kinv.to(DEV), proj.to(DEV)
+    depths = depth_hypotheses((0.33, 0.0025), d).to(DEV)
+    cv = torch.full((b, d, h, w), float("nan"), device=DEV)
+    sf = [torch.full((b, d, h, w), float("nan"), device=DEV) for _ in range(nf)]
+    fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
+    sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
+    cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
+    _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
+                                      b, d, h, w, 10.0, cw, cv.data_ptr(), sp, _stream()), "mr_cost_volume_f32")
+    torch.cuda.synchronize()
+    return cv.cpu(), [s.cpu() for s in sf]
+
+
+@pytest.mark.parametrize("case", ["cv_only_ragged", "small", "small_hard_pose", "d64_f4"])
+def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
+    g = Golden(case)
+    batch = g.make_inputs()
+    cv, sf = _hip_cost_volume(batch, g.depths)
+    assert not torch.isnan(cv).any() and not any(torch.isnan(s).any() for s in sf)
+    stages = {}
+    ocv, osf = orc.cost_volume(batch, steps=g.depths, stages=stages)
+    # validity mask: sfcv == 0 for all depths <=> invalid; must agree with the oracle except for rare
+    # 1-ulp projection flips (none expected: the projection chain reproduces the CPU bits)
+    for f in range(len(sf)):
+        flips = ((sf[f] == 0).all(1) != (osf[f] == 0).all(1)).float().mean().item()
+        assert flips <= 1e-4, (f, flips)
+        bad = ((sf[f] - osf[f]).abs() > 2e-5).float().mean().item()
+        assert bad <= 2e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
+    bad = ((cv - ocv).abs() > 5e-5).float().mean().item()
+    assert bad <= 2e-4, (bad, (cv - ocv).abs().max().item())
+    # and against the committed outputs of the real reference
+    name = "cost_volume"
+    if g.full_model:   # the fixture stores the masked volume for full-model cases; compare sfcv only
+        for f in range(len(sf)):
+            g.compare(f"sfcv{f}", sf[f], atol=2e-5, max_outlier_frac=2e-4)
+    else:
+        g.compare(name, cv, atol=5e-5, max_outlier_frac=2e-4)
+
+
+def test_cost_volume_properties_at_full_size(hip_lib):
+    """Size-independent properties at BASELINE's c2 size (256x512, F=2, D=32)."""
+    batch = synth.make_batch(1, 256, 512, 2, seed=11)
+    cv, sf = _hip_cost_volume(batch, 32)
+    assert cv.min() >= -1 and cv.max() <= 1
+    for s in sf:
+        assert s.min() >= -1 and s.max() <= 1
+        assert float(s[:, :, :2].abs().max()) == 0 and float(s[:, :, :, -2:].abs().max()) == 0
+    # identical source frames with identical poses -> both frames give identical single-frame volumes
+    batch["frames"][1] = batch["frames"][0].clone()
+    batch["poses"][1] = batch["poses"][0].clone()
+    cv2, sf2 = _hip_cost_volume(batch, 32)
+    assert torch.equal(sf2[0], sf2[1])
+    # fused volume of two identical frames equals the single-frame volume wherever it is valid
+    valid = (sf2[0] != 0).any(1, keepdim=True).expand_as(cv2)
+    assert (cv2[valid] - sf2[0][valid]).abs().max().item() < 1e-5

@@ -1,0 +1,67 @@
+"""CPU: the oracle restatement against the committed fixtures (= outputs of the real reference,
+written by oracle/make_golden.py in the build container)."""
+import json
+import os
+
+import pytest
+import torch
+
+from golden_util import GOLDEN, Golden
+from monorec_amd import synth
+from monorec_amd.model import MonoRecModel
+from oracle import monorec_oracle as orc
+
+# The fixtures were produced on the build container's CPU; on another host MKL/oneDNN may order sums
+# differently, so allow fp32 noise (reference's own 1-vs-8-thread noise: 6e-8) and the
+# rare validity-mask flip that a 1-ulp projection difference can cause.
+ATOL = 2e-5
+FLIPS = 2e-4
+
+
+def test_pinning_report_says_oracle_equals_reference():
+    rep = json.load(open(os.path.join(GOLDEN, "PINNING.json")))
+    assert all(rep["low_level"].values())
+    for case, info in rep["cases"].items():
+        assert max(info["oracle_vs_reference_maxabs"].values()) == 0.0, case
+
+
+@pytest.mark.parametrize("case", ["small", "small_hard_pose", "d64_f4"])
+def test_oracle_full_model_matches_reference_fixture(case):
+    g = Golden(case)
+    model = MonoRecModel(cv_depth_steps=g.depths)
+    sd = synth.seeded_state_dict(model.state_dict(), seed=0)
+    out = orc.forward(sd, g.make_inputs(), cv_depth_steps=g.depths)
+    g.compare("result", out["result"], atol=ATOL)
+    g.compare("cv_mask", out["cv_mask"], atol=ATOL)
+    g.compare("cost_volume", out["cost_volume"], atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(out["single_frame_cvs"]):
+        g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(out["image_features"]):
+        g.compare(f"feat{i}", t, atol=1e-4, rtol=1e-5)
+    for i, t in enumerate(out["predicted_inverse_depths"]):
+        g.compare(f"pred{i}", t, atol=ATOL)
+
+
+def test_oracle_cost_volume_ragged_size():
+    g = Golden("cv_only_ragged")
+    cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths)
+    g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(sf):
+        g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
+
+
+def test_cost_volume_range_and_invalid_pixels():
+    g = Golden("small")
+    cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths)
+    assert cv.min() >= -1 and cv.max() <= 1
+    # the 2 px border is always invalid (border mask, monorec_model.py:282-284)
+    assert float(cv[:, :, :2].abs().max()) == 0 and float(cv[:, :, :, -2:].abs().max()) == 0
+    for t in sf:
+        assert float(t[:, :, :, :2].abs().max()) == 0
+
+
+def test_seeded_weights_are_order_independent():
+    m = MonoRecModel(cv_depth_steps=8)
+    a = synth.seeded_state_dict(m.state_dict(), seed=0)
+    b = synth.seeded_state_dict(dict(reversed(list(m.state_dict().items()))), seed=0)
+    assert all(torch.equal(a[k], b[k]) for k in a)

@@ -33,10 +33,13 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
+    if not force and os.path.exists(LIB_PATH) and not _stale(
+            LIB_PATH, [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "conv_layout.h")]):
+        return LIB_PATH                     # prebuilt library travels with the snapshot; nothing to do
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "conv_layout.h"), os.path.join(HERE, "..", "include", "monorec_hip.h"), __file__]
     objdir = os.path.join(HERE, "build")

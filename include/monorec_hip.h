@@ -96,13 +96,21 @@ typedef struct mr_conv_desc {
     /* schedule */
     int32_t cout_blocks_per_wg;      /* MB: 16-channel output blocks per workgroup, one of 1,2,3,4,6 */
     int32_t pixel_blocks_per_wave;   /* NB: 16-pixel row segments per wave, one of 1,2,4            */
+    int32_t chunk_channels;          /* CK: input channels staged per LDS chunk, one of 16,32,64    */
     int32_t split_k;                 /* >= 1; > 1 needs `workspace`                               */
-    float* workspace;                /* split_k * batch * ceil16(out_channels) * out_h * out_w floats */
+    float* workspace;                /* split_k * phases * batch * ceil16(out_channels) * out_h * out_w floats */
+    /* optional output phases (the 4 parities of ConvTranspose2d(k=4,s=2), model/layers.py:389):
+     * num_phases == 4 runs four filter sets in ONE launch; phase p uses phase_weights[p], its own
+     * pad_top/pad_left and output offset, and the common kh/kw/stride/out_step.  num_phases <= 1: ignored. */
+    int32_t num_phases;
+    const float* phase_weights[4];
+    int32_t phase_pad_top[4], phase_pad_left[4], phase_out_off_h[4], phase_out_off_w[4];
 } mr_conv_desc;
 
-/* number of floats of the packed weight image for a conv with the given source split */
+/* number of floats of the packed weight image for a conv with the given source split and schedule
+ * (cout_blocks_per_wg, chunk_channels must equal the values later put into mr_conv_desc) */
 size_t mr_conv_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
-                                    int32_t kh, int32_t kw);
+                                    int32_t kh, int32_t kw, int32_t cout_blocks_per_wg, int32_t chunk_channels);
 
 /*
  * Host-side repack of an (out_channels, sum(src_channels), kh, kw) fp32 weight (nn.Conv2d layout,
@@ -110,7 +118,8 @@ size_t mr_conv_packed_weight_floats(int32_t out_channels, const int32_t* src_cha
  * mr_conv_packed_weight_floats() floats; upload it once per layer.
  */
 int mr_conv_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels,
-                             int32_t num_src, int32_t kh, int32_t kw, float* dst);
+                             int32_t num_src, int32_t kh, int32_t kw, int32_t cout_blocks_per_wg,
+                             int32_t chunk_channels, float* dst);
 
 /* bytes of dynamic LDS the launch will request (for planning / tests); negative MR_ERR_* if invalid */
 int64_t mr_conv2d_lds_bytes(const mr_conv_desc* desc);

@@ -43,17 +43,23 @@ class ConvDesc(ctypes.Structure):
         ("act_p0", ctypes.c_float), ("act_p1", ctypes.c_float),
         ("cout_blocks_per_wg", ctypes.c_int32),
         ("pixel_blocks_per_wave", ctypes.c_int32),
+        ("chunk_channels", ctypes.c_int32),
         ("split_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p),
+        ("num_phases", ctypes.c_int32),
+        ("phase_weights", ctypes.c_void_p * 4),
+        ("phase_pad_top", ctypes.c_int32 * 4), ("phase_pad_left", ctypes.c_int32 * 4),
+        ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4),
     ]
 
 
 # every symbol include/monorec_hip.h declares: (restype, argtypes)
 ABI = {
     "mr_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
-                                                       ctypes.c_int32, ctypes.c_int32]),
+                                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mr_conv_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
-                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv2d_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(ConvDesc)]),
     "mr_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "mr_cost_volume_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,

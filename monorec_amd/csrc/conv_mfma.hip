@@ -1,22 +1,28 @@
 // Direct convolution on the fp32 matrix cores of gfx950 (MI355X).
 //
-// Stands in for every nn.Conv2d / ConvTranspose2d phase on the MonoRec inference path
+// Stands in for every nn.Conv2d / ConvTranspose2d on the MonoRec inference path
 // (reference: model/layers.py:241-252,289-356,380-400; model/monorec/monorec_model.py:118-129,
 // 345-385,526-557).  See conv_layout.h for the GEMM view and the packed weight stream.
 //
 // Workgroup = 256 threads = 4 waves.  It owns a TH x (TWB*16) tile of one output plane and MB
-// consecutive 16-channel output blocks.  Per K chunk (<=16 input channels) the haloed input tile is
-// staged once into LDS (zero padding, nearest-upsample, 2x2 max-pool and the ResNet input
-// normalisation are applied while staging, so those ops never touch HBM); every wave then walks
-// taps x channel-quads, reading its B fragments from LDS (conflict-free: plane stride = 16 mod 32)
-// and its A fragments straight from the L2-resident packed weight stream (register double buffer),
-// and issues MB*NB v_mfma_f32_16x16x4_f32 per k-step.  fp32 MFMA is an exact fmaf chain, so results
-// differ from the oneDNN CPU reference only by summation order.
+// consecutive 16-channel output blocks.  Per K chunk (<= CK input channels of one concat source):
+//   * the haloed input tile is staged into LDS - each thread owns fixed tile positions and issues the
+//     loads of 16 channels back to back (one memory latency per batch, not per element); zero padding,
+//     nearest-upsample, 2x2 max-pool and the ResNet input normalisation are applied here, so those ops
+//     never touch HBM;
+//   * the chunk's A fragments (one contiguous block of the packed stream) are DMA'd global->LDS with
+//     global_load_lds_dwordx4 (no VGPR round trip);
+//   * after one barrier every wave sweeps taps x channel-quads reading A (lane-linear) and B
+//     (plane stride = 16 mod 32, conflict free) from LDS and issues MB*NB v_mfma_f32_16x16x4_f32 per
+//     k-step - the sweep contains no global memory access at all.
+// Latency of the staging phase is hidden by co-resident workgroups (LDS footprint is kept small enough
+// for >= 3 per CU).  fp32 MFMA is an exact fmaf chain, so results differ from the oneDNN CPU reference
+// only by summation order.
 //
 // Epilogue: bias (eval-BatchNorm folded by the host), residual add, activation, scatter with an
-// output step/offset (ConvTranspose2d phases) into a channel slice of the destination.
-// split_k > 1 writes raw partial sums to a workspace; splitk_epilogue_kernel finishes them in a fixed
-// order (deterministic, no atomics).
+// output step/offset into a channel slice of the destination.  The four output parities of
+// ConvTranspose2d(k4,s2) run as four "phases" of ONE launch.  split_k > 1 writes raw partial sums to a
+// workspace; splitk_epilogue_kernel finishes them in a fixed order (deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -26,30 +32,34 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define MR_MAX_PPT 6   // tile positions staged per thread (ceil(IH*IW / 256))
+
 struct ConvKArgs {
     const float* src[MR_MAX_SOURCES];
-    long long src_bstride[MR_MAX_SOURCES];
+    int src_bytes[MR_MAX_SOURCES];   // whole source tensor, < 2 GiB (buffer descriptor range)
     int src_c[MR_MAX_SOURCES];
     int src_cpad[MR_MAX_SOURCES];
     int nsrc;
     int Hs, Ws, Hin, Win;
     int in_mode, in_tf;
-    int KH, KW, SH, SW, PT, PL;
+    int KH, KW, SH, SW;
     int Ho, Wo;
     float* dst;
     long long dst_bstride;
     int dst_H, dst_W, ch_off;
-    int ostep_h, ostep_w, ooff_h, ooff_w;
+    int ostep_h, ostep_w;
     int Cout, CB;
-    const float* w;
     const float* bias;
     const float* res;
     int act;
     float p0, p1;
     int tiles_x, TH, TWB;
-    int IH, IW, PLANE;
-    int ksplit, nchunks, batch;
+    int IH, IW, PLANE, CK, ppt;
+    int ksplit, nchunks, batch, nphase;
+    long long wgroup_stride;   // packed floats per cout group
     float* ws;
+    const float* w[4];         // per phase
+    int PT[4], PL[4], ooff_h[4], ooff_w[4];
 };
 
 __device__ __forceinline__ float mr_activate(float v, int act, float p0, float p1) {
@@ -65,34 +75,101 @@ __device__ __forceinline__ float mr_activate(float v, int act, float p0, float p
     }
 }
 
-__device__ __forceinline__ void mr_store_out(const ConvKArgs& a, int b, int cout, int oy, int ox, float v) {
+__device__ __forceinline__ void mr_store_out(const ConvKArgs& a, int ph, int b, int cout, int oy, int ox, float v) {
     if (a.bias) v += a.bias[cout];
     const long long idx = (long long)b * a.dst_bstride +
-                          ((long long)(a.ch_off + cout) * a.dst_H + (oy * a.ostep_h + a.ooff_h)) * a.dst_W +
-                          (ox * a.ostep_w + a.ooff_w);
+                          ((long long)(a.ch_off + cout) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
+                          (ox * a.ostep_w + a.ooff_w[ph]);
     if (a.res) v += a.res[idx];
     a.dst[idx] = mr_activate(v, a.act, a.p0, a.p1);
 }
 
-__device__ __forceinline__ float mr_fetch(const float* plane, int gy, int gx, int Ws, int mode) {
-    if (mode == MR_IN_DIRECT) return plane[gy * Ws + gx];
-    if (mode == MR_IN_UPSAMPLE2) return plane[(gy >> 1) * Ws + (gx >> 1)];
-    const float* p = plane + (2 * gy) * Ws + 2 * gx;   // MR_IN_MAXPOOL2
-    return fmaxf(fmaxf(p[0], p[1]), fmaxf(p[Ws], p[Ws + 1]));
+// Stage 16 channel planes of one tile position through a buffer descriptor: an offset of -1 is out of
+// range for the SRD, so the hardware returns 0 - zero padding, padded channels and inactive lanes need
+// no branch, and the 16 buffer_load_dword are issued back to back (one memory latency per batch).
+template <bool POOL, bool NORM>
+__device__ __forceinline__ void stage_position(float* __restrict__ ldsI, __amdgpu_buffer_rsrc_t rsrc, int voff, int sbase_bytes,
+                                               int cs, int ck, int creal, int HsWs, int Ws, int PLANE, int lo) {
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const bool cok = cs + c < creal;                          // wave-uniform
+        const int vo = cok ? voff : -1;
+        const int so = sbase_bytes + (cs + c) * HsWs * 4;         // wave-uniform -> SGPR soffset
+        float x;
+        if (POOL) {
+            const int v1 = vo < 0 ? -1 : vo + 4, v2 = vo < 0 ? -1 : vo + Ws * 4, v3 = vo < 0 ? -1 : vo + Ws * 4 + 4;
+            const float x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, so, 0));
+            const float x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, v1, so, 0));
+            const float x2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, v2, so, 0));
+            const float x3 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, v3, so, 0));
+            x = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+        } else {
+            x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, so, 0));
+        }
+        // out-of-range samples loaded as 0 must stay 0 after the normalisation: multiply by a 0/1 lane mask
+        // (arithmetic, so the compiler cannot sink the load under a branch; the operand is always finite)
+        if (NORM) x = (((x + 0.5f) - 0.45f) / 0.225f) * (vo < 0 ? 0.f : 1.f);
+        v[c] = x;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c += 4)
+        if (cs + c < ck) {                                        // ck is a multiple of 4
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ldsI[(cs + c + u) * PLANE + lo] = v[c + u];
+        }
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void kstep(f32x4 (&acc)[MB][NB], const float* __restrict__ wt, const float* __restrict__ ldsI,
+                                      const int (&lbase)[NB], int c4, int off) {
+    float av[MB], bv[NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) av[m] = wt[(c4 * MB + m) * 64];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bv[i] = ldsI[lbase[i] + off];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[i], acc[m][i], 0, 0, 0);
 }
 
 template <int MB, int NB>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsI = lds;                       // [CK][PLANE]
+    float* ldsW = lds + a.CK * a.PLANE;      // [taps][ck4][MB][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int cb0 = blockIdx.y * MB;
-    const int b = blockIdx.z / a.ksplit, ks = blockIdx.z % a.ksplit;
+    const int grp = blockIdx.y;
+    const int cb0 = grp * MB;
+    int z = blockIdx.z;
+    const int ph = z % a.nphase; z /= a.nphase;
+    const int ks = z % a.ksplit;
+    const int b = z / a.ksplit;
     const int oy0 = ty * a.TH, ox0 = tx * a.TWB * 16;
-    const int iy_base = oy0 * a.SH - a.PT, ix_base = ox0 * a.SW - a.PL;
+    const int iy_base = oy0 * a.SH - a.PT[ph], ix_base = ox0 * a.SW - a.PL[ph];
+    const int HsWs = a.Hs * a.Ws;
+
+    // ---- fixed staging positions of this thread: p = tid + 256*j  ->  (iy, ix) of the haloed tile ----
+    int goff[MR_MAX_PPT], loff[MR_MAX_PPT];
+    const int P = a.IH * a.IW;
+#pragma unroll
+    for (int j = 0; j < MR_MAX_PPT; ++j) {
+        const int p = tid + 256 * j;
+        const int iy = p / a.IW, ix = p - iy * a.IW;
+        const int gy = iy_base + iy, gx = ix_base + ix;
+        loff[j] = p < P ? p : -1;
+        bool inb = p < P && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        int g = 0;
+        if (a.in_mode == MR_IN_DIRECT) g = gy * a.Ws + gx;
+        else if (a.in_mode == MR_IN_UPSAMPLE2) g = (gy >> 1) * a.Ws + (gx >> 1);
+        else g = (2 * gy) * a.Ws + 2 * gx;
+        goff[j] = inb ? g : -1;
+    }
 
     int prow[NB], pcol[NB], lbase[NB];
 #pragma unroll
@@ -102,10 +179,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         pcol[i] = (pb % a.TWB) * 16 + (lane & 15);
         lbase[i] = (lane >> 4) * a.PLANE + prow[i] * a.SH * a.IW + pcol[i] * a.SW;
     }
-    // clamp cout blocks of a partially filled last group onto valid weights (results are discarded)
-    int wcb[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) wcb[m] = min(cb0 + m, a.CB - 1) * 64 + lane;
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -115,66 +188,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 
     const int q_lo = (ks * a.nchunks) / a.ksplit, q_hi = ((ks + 1) * a.nchunks) / a.ksplit;
     const int T = a.KH * a.KW;
-    const int step_stride = a.CB * 64;
+    const float* wgrp = a.w[ph] + (long long)grp * a.wgroup_stride;
     long long woff = 0;
     int q = 0;
     for (int s = 0; s < a.nsrc; ++s) {
-        const float* sbase = a.src[s] + (long long)b * a.src_bstride[s];
-        for (int c0 = 0; c0 < a.src_cpad[s]; c0 += MR_CHUNK_CHANNELS, ++q) {
-            const int ck = min(MR_CHUNK_CHANNELS, a.src_cpad[s] - c0);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[s], 0, a.src_bytes[s], 0x00020000);
+        for (int c0 = 0; c0 < a.src_cpad[s]; c0 += a.CK, ++q) {
+            const int ck = min(a.CK, a.src_cpad[s] - c0);
             const int ck4 = ck >> 2;
-            const int nsteps = T * ck4;
+            const int wfloats = T * ck4 * MB * 64;
             if (q >= q_lo && q < q_hi) {
                 __syncthreads();  // all waves finished reading the previous chunk
-                // ---- stage the haloed input tile of channels [c0, c0+ck) -------------------------
-                for (int c = 0; c < ck; ++c) {
-                    const bool cok = (c0 + c) < a.src_c[s];
-                    const float* plane = sbase + (long long)(c0 + c) * a.Hs * a.Ws;
-                    for (int iy = wave; iy < a.IH; iy += 4) {
-                        const int gy = iy_base + iy;
-                        const bool yok = cok && gy >= 0 && gy < a.Hin;
-                        float* lrow = lds + c * a.PLANE + iy * a.IW;
-                        for (int ix = lane; ix < a.IW; ix += 64) {
-                            const int gx = ix_base + ix;
-                            float v = 0.f;
-                            if (yok && gx >= 0 && gx < a.Win) {
-                                v = mr_fetch(plane, gy, gx, a.Ws, a.in_mode);
-                                if (a.in_tf == MR_TF_RESNET_NORM) v = ((v + 0.5f) - 0.45f) / 0.225f;
-                            }
-                            lrow[ix] = v;
+                // ---- A fragments of this (group, chunk): contiguous block, DMA global -> LDS --------
+                {
+                    const float* wsrc = wgrp + woff;
+                    const int n1k = wfloats >> 8;                     // 1 KiB pieces (64 lanes x 16 B)
+                    for (int kb = wave; kb < n1k; kb += 4)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 256 + lane * 4),
+                                                         (__attribute__((address_space(3))) void*)(ldsW + kb * 256), 16, 0, 0);
+                    const int nfrag = wfloats >> 6;                   // tail: 256 B pieces (64 lanes x 4 B)
+                    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += 4)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + fr * 64 + lane),
+                                                         (__attribute__((address_space(3))) void*)(ldsW + fr * 64), 4, 0, 0);
+                }
+                // ---- input tile: per position, 16 channel planes per batch of loads --------------------
+                const int creal = a.src_c[s] - c0;                    // real (unpadded) channels left
+                const int sbase_bytes = (b * a.src_c[s] + c0) * HsWs * 4;   // byte offset of channel c0 of sample b
+                for (int cs = 0; cs < ck; cs += 16) {
+#pragma unroll
+                    for (int j = 0; j < MR_MAX_PPT; ++j) {
+                        if (j < a.ppt && loff[j] >= 0) {
+                            const int voff = goff[j] >= 0 ? goff[j] * 4 : -1;
+                            if (a.in_mode == MR_IN_MAXPOOL2)
+                                stage_position<true, false>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
+                            else if (a.in_tf == MR_TF_RESNET_NORM)
+                                stage_position<false, true>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
+                            else
+                                stage_position<false, false>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
                         }
                     }
                 }
                 __syncthreads();
-                // ---- MFMA sweep ------------------------------------------------------------------
-                const float* wq = a.w + woff;
-                float a_cur[MB], a_nxt[MB];
-#pragma unroll
-                for (int m = 0; m < MB; ++m) a_cur[m] = wq[wcb[m]];
-                int st = 0;
+                // ---- MFMA sweep: LDS only ------------------------------------------------------------
+                const float* wl = ldsW + lane;
                 for (int kh = 0; kh < a.KH; ++kh) {
                     for (int kw = 0; kw < a.KW; ++kw) {
                         const int tapoff = kh * a.IW + kw;
-                        for (int c4 = 0; c4 < ck4; ++c4, ++st) {
-                            const int nst = min(st + 1, nsteps - 1);
-#pragma unroll
-                            for (int m = 0; m < MB; ++m) a_nxt[m] = wq[nst * step_stride + wcb[m]];
-                            const int off = c4 * 4 * a.PLANE + tapoff;
-                            float bv[NB];
-#pragma unroll
-                            for (int i = 0; i < NB; ++i) bv[i] = lds[lbase[i] + off];
-#pragma unroll
-                            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                                for (int i = 0; i < NB; ++i)
-                                    acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m], bv[i], acc[m][i], 0, 0, 0);
-#pragma unroll
-                            for (int m = 0; m < MB; ++m) a_cur[m] = a_nxt[m];
+                        const float* wt = wl + (kh * a.KW + kw) * ck4 * (MB * 64);
+                        int c4 = 0;
+                        for (; c4 + 4 <= ck4; c4 += 4) {          // manual 4x unroll: LDS reads of 4 k-steps overlap
+                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
+                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 1, (c4 + 1) * 4 * a.PLANE + tapoff);
+                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 2, (c4 + 2) * 4 * a.PLANE + tapoff);
+                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 3, (c4 + 3) * 4 * a.PLANE + tapoff);
                         }
+                        for (; c4 < ck4; ++c4) kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
                     }
                 }
             }
-            woff += mr_chunk_weight_floats(ck, T, a.CB);
+            woff += wfloats;
         }
     }
 
@@ -191,9 +263,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
                 const int cout = (cb0 + m) * 16 + (lane >> 4) * 4 + r;
                 if (a.ksplit > 1) {
                     if (cout < CB16)
-                        a.ws[((((long long)ks * a.batch + b) * CB16 + cout) * a.Ho + oy) * a.Wo + ox] = acc[m][i][r];
+                        a.ws[(((((long long)ks * a.nphase + ph) * a.batch + b) * CB16 + cout) * a.Ho + oy) * a.Wo + ox] = acc[m][i][r];
                 } else if (cout < a.Cout) {
-                    mr_store_out(a, b, cout, oy, ox, acc[m][i][r]);
+                    mr_store_out(a, ph, b, cout, oy, ox, acc[m][i][r]);
                 }
             }
         }
@@ -202,17 +274,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvKArgs a) {
     const long long plane = (long long)a.Ho * a.Wo;
-    const long long total = (long long)a.batch * a.Cout * plane;
+    const long long total = (long long)a.nphase * a.batch * a.Cout * plane;
     const int CB16 = a.CB * 16;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ox = (int)(i % a.Wo);
         const int oy = (int)((i / a.Wo) % a.Ho);
         const int cout = (int)((i / plane) % a.Cout);
-        const int b = (int)(i / (plane * a.Cout));
+        const int b = (int)((i / (plane * a.Cout)) % a.batch);
+        const int ph = (int)(i / (plane * a.Cout * a.batch));
         float v = 0.f;
         for (int ks = 0; ks < a.ksplit; ++ks)
-            v += a.ws[((((long long)ks * a.batch + b) * CB16 + cout) * a.Ho + oy) * a.Wo + ox];
-        mr_store_out(a, b, cout, oy, ox, v);
+            v += a.ws[(((((long long)ks * a.nphase + ph) * a.batch + b) * CB16 + cout) * a.Ho + oy) * a.Wo + ox];
+        mr_store_out(a, ph, b, cout, oy, ox, v);
     }
 }
 
@@ -223,21 +296,24 @@ namespace {
 
 struct Derived {
     ConvKArgs k;
-    int max_ck;
     size_t lds_bytes;
     int mb, nb;
     dim3 grid;
 };
 
+bool valid_mb(int mb) { return mb == 1 || mb == 2 || mb == 3 || mb == 4 || mb == 6; }
+bool valid_ck(int ck) { return ck == 16 || ck == 32 || ck == 64; }
+
 int derive(const mr_conv_desc* d, Derived* out) {
     if (!d || d->num_src < 1 || d->num_src > MR_MAX_SOURCES) return MR_ERR_BAD_ARGUMENT;
     if (d->batch < 1 || d->kh < 1 || d->kw < 1 || d->stride_h < 1 || d->stride_w < 1) return MR_ERR_BAD_ARGUMENT;
     if (d->stride_w > 2) return MR_ERR_UNSUPPORTED;
-    if (d->out_h < 1 || d->out_w < 1 || d->out_channels < 1 || !d->dst || !d->packed_weights) return MR_ERR_BAD_ARGUMENT;
+    if (d->out_h < 1 || d->out_w < 1 || d->out_channels < 1 || !d->dst) return MR_ERR_BAD_ARGUMENT;
     const int mb = d->cout_blocks_per_wg, nb = d->pixel_blocks_per_wave;
-    if (!(mb == 1 || mb == 2 || mb == 3 || mb == 4 || mb == 6)) return MR_ERR_BAD_ARGUMENT;
-    if (!(nb == 1 || nb == 2 || nb == 4)) return MR_ERR_BAD_ARGUMENT;
+    if (!valid_mb(mb) || !(nb == 1 || nb == 2 || nb == 4) || !valid_ck(d->chunk_channels)) return MR_ERR_BAD_ARGUMENT;
     if (d->split_k < 1 || (d->split_k > 1 && !d->workspace)) return MR_ERR_BAD_ARGUMENT;
+    const int nphase = d->num_phases <= 1 ? 1 : d->num_phases;
+    if (nphase != 1 && nphase != 4) return MR_ERR_BAD_ARGUMENT;
     ConvKArgs& k = out->k;
     memset(&k, 0, sizeof(k));
     k.nsrc = d->num_src;
@@ -251,31 +327,45 @@ int derive(const mr_conv_desc* d, Derived* out) {
     }
     k.in_mode = d->in_mode;
     k.in_tf = d->in_transform;
-    int nchunks = 0, max_ck = 0;
+    k.CK = d->chunk_channels;
+    int nchunks = 0, cpad_total = 0;
     for (int s = 0; s < d->num_src; ++s) {
         if (!d->src[s] || d->src_channels[s] < 1) return MR_ERR_BAD_ARGUMENT;
         k.src[s] = d->src[s];
         k.src_c[s] = d->src_channels[s];
         k.src_cpad[s] = mr_pad4(d->src_channels[s]);
-        k.src_bstride[s] = (long long)d->src_channels[s] * d->src_h * d->src_w;
-        nchunks += mr_chunks_of(d->src_channels[s]);
-        const int ck_s = k.src_cpad[s] < MR_CHUNK_CHANNELS ? k.src_cpad[s] : MR_CHUNK_CHANNELS;
-        if (ck_s > max_ck) max_ck = ck_s;
+        const long long sbytes = (long long)d->batch * d->src_channels[s] * d->src_h * d->src_w * 4;
+        if (sbytes >= (1ll << 31)) return MR_ERR_UNSUPPORTED;   // 32-bit byte offsets in the SRD path
+        k.src_bytes[s] = (int)sbytes;
+        nchunks += mr_chunks_of(d->src_channels[s], k.CK);
+        cpad_total += k.src_cpad[s];
     }
     if (d->split_k > nchunks) return MR_ERR_BAD_ARGUMENT;
-    k.KH = d->kh; k.KW = d->kw; k.SH = d->stride_h; k.SW = d->stride_w; k.PT = d->pad_top; k.PL = d->pad_left;
+    k.KH = d->kh; k.KW = d->kw; k.SH = d->stride_h; k.SW = d->stride_w;
     k.Ho = d->out_h; k.Wo = d->out_w;
     k.dst = d->dst;
     k.dst_H = d->dst_plane_h; k.dst_W = d->dst_plane_w;
     k.dst_bstride = (long long)d->dst_total_channels * d->dst_plane_h * d->dst_plane_w;
     k.ch_off = d->dst_channel_offset;
-    k.ostep_h = d->out_step_h; k.ostep_w = d->out_step_w; k.ooff_h = d->out_off_h; k.ooff_w = d->out_off_w;
+    k.ostep_h = d->out_step_h; k.ostep_w = d->out_step_w;
     if (k.ostep_h < 1 || k.ostep_w < 1) return MR_ERR_BAD_ARGUMENT;
-    if ((k.Ho - 1) * k.ostep_h + k.ooff_h >= k.dst_H || (k.Wo - 1) * k.ostep_w + k.ooff_w >= k.dst_W) return MR_ERR_BAD_ARGUMENT;
+    k.nphase = nphase;
+    for (int p = 0; p < nphase; ++p) {
+        if (nphase == 1) {
+            k.w[0] = d->packed_weights; k.PT[0] = d->pad_top; k.PL[0] = d->pad_left;
+            k.ooff_h[0] = d->out_off_h; k.ooff_w[0] = d->out_off_w;
+        } else {
+            k.w[p] = d->phase_weights[p]; k.PT[p] = d->phase_pad_top[p]; k.PL[p] = d->phase_pad_left[p];
+            k.ooff_h[p] = d->phase_out_off_h[p]; k.ooff_w[p] = d->phase_out_off_w[p];
+        }
+        if (!k.w[p] || k.ooff_h[p] < 0 || k.ooff_w[p] < 0) return MR_ERR_BAD_ARGUMENT;
+        if ((k.Ho - 1) * k.ostep_h + k.ooff_h[p] >= k.dst_H || (k.Wo - 1) * k.ostep_w + k.ooff_w[p] >= k.dst_W)
+            return MR_ERR_BAD_ARGUMENT;
+    }
     if (d->dst_channel_offset < 0 || d->dst_channel_offset + d->out_channels > d->dst_total_channels) return MR_ERR_BAD_ARGUMENT;
     k.Cout = d->out_channels;
     k.CB = mr_ceil_div(d->out_channels, 16);
-    k.w = d->packed_weights; k.bias = d->bias; k.res = d->residual;
+    k.bias = d->bias; k.res = d->residual;
     k.act = d->activation; k.p0 = d->act_p0; k.p1 = d->act_p1;
     k.TWB = d->out_w >= 32 ? 2 : 1;
     k.TH = 4 * nb / k.TWB;
@@ -286,12 +376,18 @@ int derive(const mr_conv_desc* d, Derived* out) {
     int plane = k.IH * k.IW;
     if (k.SW == 1) { while ((plane & 31) != 16) ++plane; } else { plane |= 1; }
     k.PLANE = plane;
+    k.ppt = mr_ceil_div(k.IH * k.IW, 256);
+    if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED;
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
-    out->max_ck = max_ck;
-    out->lds_bytes = (size_t)max_ck * plane * sizeof(float);
+    const int taps = k.KH * k.KW;
+    k.wgroup_stride = (long long)taps * (cpad_total / 4) * mb * 64;
+    const int ck_max = cpad_total < k.CK ? cpad_total : k.CK;   // upper bound of any chunk
+    const size_t w_floats = (size_t)taps * (ck_max / 4) * mb * 64;
+    out->lds_bytes = ((size_t)k.CK * plane + w_floats) * sizeof(float);
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
     out->mb = mb; out->nb = nb;
-    out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)mr_ceil_div(k.CB, mb), (unsigned)(d->batch * d->split_k));
+    out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)mr_ceil_div(k.CB, mb),
+                     (unsigned)(d->batch * d->split_k * nphase));
     return 0;
 }
 
@@ -320,45 +416,43 @@ int launch_nb(const Derived& dv, hipStream_t stream) {
 }  // namespace
 
 extern "C" size_t mr_conv_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
-                                               int32_t kh, int32_t kw) {
-    const int cb = mr_ceil_div(out_channels, 16);
-    size_t n = 0;
-    for (int s = 0; s < num_src; ++s) {
-        const int cpad = mr_pad4(src_channels[s]);
-        for (int c0 = 0; c0 < cpad; c0 += MR_CHUNK_CHANNELS) {
-            const int ck = cpad - c0 < MR_CHUNK_CHANNELS ? cpad - c0 : MR_CHUNK_CHANNELS;
-            n += (size_t)mr_chunk_weight_floats(ck, kh * kw, cb);
-        }
-    }
-    return n;
+                                               int32_t kh, int32_t kw, int32_t mb, int32_t ck) {
+    if (!src_channels || num_src < 1 || !valid_mb(mb) || !valid_ck(ck)) return 0;
+    const int groups = mr_ceil_div(mr_ceil_div(out_channels, 16), mb);
+    int cpad_total = 0;
+    for (int s = 0; s < num_src; ++s) cpad_total += mr_pad4(src_channels[s]);
+    return (size_t)groups * kh * kw * (cpad_total / 4) * mb * 64;
 }
 
 extern "C" int mr_conv_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels,
-                                        int32_t num_src, int32_t kh, int32_t kw, float* dst) {
+                                        int32_t num_src, int32_t kh, int32_t kw, int32_t mb, int32_t ck, float* dst) {
     if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES) return MR_ERR_BAD_ARGUMENT;
-    const int cb_n = mr_ceil_div(out_channels, 16);
+    if (!valid_mb(mb) || !valid_ck(ck)) return MR_ERR_BAD_ARGUMENT;
+    const int groups = mr_ceil_div(mr_ceil_div(out_channels, 16), mb);
     const int taps = kh * kw;
     int cin_total = 0;
     for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
     size_t o = 0;
-    int cin_off = 0;
-    for (int s = 0; s < num_src; ++s) {
-        const int cpad = mr_pad4(src_channels[s]);
-        for (int c0 = 0; c0 < cpad; c0 += MR_CHUNK_CHANNELS) {
-            const int ck = cpad - c0 < MR_CHUNK_CHANNELS ? cpad - c0 : MR_CHUNK_CHANNELS;
-            for (int tap = 0; tap < taps; ++tap)
-                for (int c4 = 0; c4 < ck / 4; ++c4)
-                    for (int cb = 0; cb < cb_n; ++cb)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int cout = cb * 16 + (lane & 15);
-                            const int cl = c0 + c4 * 4 + (lane >> 4);
-                            float v = 0.f;
-                            if (cout < out_channels && cl < src_channels[s])
-                                v = weight[((size_t)cout * cin_total + (cin_off + cl)) * taps + tap];
-                            dst[o++] = v;
-                        }
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = mr_pad4(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += ck) {
+                const int ckq = cpad - c0 < ck ? cpad - c0 : ck;
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int c4 = 0; c4 < ckq / 4; ++c4)
+                        for (int m = 0; m < mb; ++m)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int cout = (g * mb + m) * 16 + (lane & 15);
+                                const int cl = c0 + c4 * 4 + (lane >> 4);
+                                float v = 0.f;
+                                if (cout < out_channels && cl < src_channels[s])
+                                    v = weight[((size_t)cout * cin_total + (cin_off + cl)) * taps + tap];
+                                dst[o++] = v;
+                            }
+            }
+            cin_off += src_channels[s];
         }
-        cin_off += src_channels[s];
     }
     return 0;
 }
@@ -384,7 +478,7 @@ extern "C" int mr_conv2d_f32(const mr_conv_desc* desc, void* stream_) {
     }
     if (rc != 0) return rc;
     if (dv.k.ksplit > 1) {
-        const long long total = (long long)dv.k.batch * dv.k.Cout * dv.k.Ho * dv.k.Wo;
+        const long long total = (long long)dv.k.nphase * dv.k.batch * dv.k.Cout * dv.k.Ho * dv.k.Wo;
         const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, dv.k);
         rc = (int)hipGetLastError();

@@ -33,16 +33,18 @@ def same_pad(n, k, s):
     return math.floor(total / 2), math.ceil(total / 2)
 
 
-def pack_conv_weight(weight, src_channels):
-    """(Cout, sum(src_channels), kh, kw) fp32 CPU tensor -> packed A-fragment stream (CPU tensor)."""
+def pack_conv_weight(weight, src_channels, mb, ck):
+    """(Cout, sum(src_channels), kh, kw) fp32 CPU tensor -> packed A-fragment stream (CPU tensor) for a
+    launch with `mb` cout blocks per workgroup and `ck` channels per LDS chunk (csrc/conv_layout.h)."""
     lib = _lib.load()
     w = weight.detach().to(torch.float32).contiguous().cpu()
     cout, cin, kh, kw = w.shape
     assert cin == sum(src_channels), (cin, src_channels)
     sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
-    n = lib.mr_conv_packed_weight_floats(cout, sc, len(src_channels), kh, kw)
+    n = lib.mr_conv_packed_weight_floats(cout, sc, len(src_channels), kh, kw, mb, ck)
+    assert n > 0, (mb, ck)
     out = torch.empty(n, dtype=torch.float32)
-    _lib.check(lib.mr_conv_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), kh, kw, out.data_ptr()),
+    _lib.check(lib.mr_conv_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), kh, kw, mb, ck, out.data_ptr()),
                "mr_conv_pack_weights_f32")
     return out
 
@@ -77,34 +79,98 @@ def transposed_phase_weights(wt):
     return out
 
 
-def choose_schedule(cout, out_h, out_w, batch, nchunks, target_wgs=448):
-    """(MB, NB, split_k) for mr_conv2d_f32: biggest register tile that still fills the 256 CUs."""
+def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb):
+    """Tile geometry used by mr_conv2d_f32 for a given NB (mirrors derive() in csrc/conv_mfma.hip)."""
+    twb = 2 if out_w >= 32 else 1
+    th = 4 * nb // twb
+    ih, iw = (th - 1) * sh + kh, (twb * 16 - 1) * sw + kw
+    plane = ih * iw
+    if sw == 1:
+        while plane % 32 != 16:
+            plane += 1
+    else:
+        plane |= 1
+    tiles = math.ceil(out_w / (twb * 16)) * math.ceil(out_h / th)
+    return dict(twb=twb, th=th, ih=ih, iw=iw, plane=plane, tiles=tiles,
+                tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
+
+
+def lds_bytes(geo, taps, cpad_total, mb, ck):
+    return 4 * (ck * geo["plane"] + taps * (min(ck, cpad_total) // 4) * mb * 64)
+
+
+TUNED = {}          # signature -> (mb, nb, split_k, ck); filled from tuned_schedules.json when present
+
+
+def _load_tuned():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_schedules.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            TUNED.update({k: tuple(v) for k, v in json.load(f).items()})
+
+
+_load_tuned()
+
+
+def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases):
+    return f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
+
+
+def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=64 * 1024):
+    """All launchable (mb, nb, split_k, ck) for a conv, with the workgroup count of each."""
     cb = (cout + 15) // 16
-    best = None
+    cpads = [(c + 3) // 4 * 4 for c in src_channels]
+    taps = kh * kw
+    out = []
     for nb in (4, 2, 1):
-        twb = 2 if out_w >= 32 else 1
-        th = 4 * nb // twb
-        tiles = math.ceil(out_w / (twb * 16)) * math.ceil(out_h / th)
-        tile_eff = (out_h * out_w) / (tiles * th * twb * 16)
+        geo = conv_geometry(out_h, out_w, kh, kw, sh, sw, nb)
+        if geo["ppt"] > 6:
+            continue
         for mb in (6, 4, 3, 2, 1):
-            if mb > cb:
+            if mb > cb and mb != 1:
                 continue
             groups = math.ceil(cb / mb)
-            cout_eff = cb / (groups * mb)
-            wgs = tiles * groups * batch
-            eff = tile_eff * cout_eff
-            # reuse/efficiency score: MFMAs per operand load grow with mb*nb/(mb+nb)
-            reuse = (mb * nb) / (mb + nb)
-            fill = min(1.0, wgs / target_wgs)
-            score = eff * fill * (0.55 + 0.45 * min(reuse, 2.4) / 2.4)
-            cand = (score, mb, nb, wgs)
-            if best is None or cand > best:
-                best = cand
-    _, mb, nb, wgs = best
-    split_k = 1
-    if wgs < 192 and nchunks >= 4:
-        split_k = int(min(8, nchunks // 2, max(1, 256 // wgs)))
-    return mb, nb, max(1, split_k)
+            for ck in (16, 32, 64):
+                if ck > 16 and ck // 2 >= max(cpads):
+                    continue
+                if lds_bytes(geo, taps, sum(cpads), mb, ck) > lds_cap:
+                    continue
+                nchunks = sum(math.ceil(c / ck) for c in cpads)
+                wgs = geo["tiles"] * groups * batch * phases
+                for sk in (1, 2, 4, 8, 16):
+                    if sk > nchunks:
+                        break
+                    out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, wgs=wgs * sk, nchunks=nchunks,
+                                    eff=geo["tile_eff"] * cb / (groups * mb),
+                                    lds=lds_bytes(geo, taps, sum(cpads), mb, ck)))
+    return out
+
+
+def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1):
+    """(MB, NB, split_k, CK) for mr_conv2d_f32.  A tuned table (tools/tune_conv.py, measured on MI355X)
+    wins; otherwise a model: biggest register tile that still puts >= 3 workgroups on each of the 256 CUs,
+    deepest chunk that keeps >= 3 workgroups' LDS on a CU, split-K only to fill the machine."""
+    sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases)
+    if sig in TUNED:
+        return TUNED[sig]
+    best = None
+    for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=52 * 1024):
+        reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
+        fill = min(1.0, c["wgs"] / 768.0)
+        per_wg_steps = c["nchunks"] / c["split_k"]
+        score = c["eff"] * fill * (0.5 + 0.5 * min(reuse, 1.5) / 1.5)
+        score *= 1.0 - 0.04 * math.log2(c["split_k"])              # workspace round trip + extra launch
+        score *= 1.0 + 0.03 * math.log2(c["ck"] / 16)              # fewer barriers
+        if per_wg_steps < 2:
+            score *= 0.8
+        cand = (score, c["mb"], c["nb"], c["split_k"], c["ck"])
+        if best is None or cand > best:
+            best = cand
+    if best is None:
+        raise ValueError("no launchable schedule")
+    return best[1:]
 
 
 class Plan:
@@ -168,16 +234,21 @@ class Plan:
 
     def conv(self, stage, name, srcs, weight, bias, out, *, stride=(1, 1), pad=(0, 0), grid=None,
              act=ACT_NONE, p0=0.0, p1=0.0, in_mode=IN_DIRECT, tf=TF_NONE, residual=None,
-             out_step=(1, 1), out_off=(0, 0), out_ch_offset=0):
-        """Append one mr_conv2d_f32 launch. srcs: list of (N,C,Hs,Ws) tensors concatenated on channels."""
+             out_step=(1, 1), out_off=(0, 0), out_ch_offset=0, phases=None):
+        """Append one mr_conv2d_f32 launch. srcs: list of (N,C,Hs,Ws) tensors concatenated on channels.
+        phases: optional list of 4 (weight, pad_top, pad_left, out_off_h, out_off_w) run in one launch."""
         n, _, hs, ws = srcs[0].shape
         src_channels = [int(s.shape[1]) for s in srcs]
         for s in srcs:
             assert s.shape[0] == n and s.shape[2] == hs and s.shape[3] == ws and s.is_contiguous()
-        cout, cin, kh, kw = weight.shape
+        w0 = weight if phases is None else phases[0][0]
+        cout, cin, kh, kw = w0.shape
         assert cin == sum(src_channels), (name, cin, src_channels)
         out_h, out_w = grid
-        packed = self._dev(pack_conv_weight(weight, src_channels))
+        nph = 1 if phases is None else len(phases)
+        sched = self.schedule_override.get(name) or choose_schedule(cout, src_channels, kh, kw, stride[0], stride[1],
+                                                                    out_h, out_w, n, nph)
+        mb, nb, split_k, ck = sched
         d = ConvDesc()
         for i, s in enumerate(srcs):
             d.src[i] = s.data_ptr()
@@ -191,27 +262,38 @@ class Plan:
         d.out_channels, d.dst_total_channels, d.dst_channel_offset = cout, out.shape[1], out_ch_offset
         d.dst_plane_h, d.dst_plane_w = out.shape[2], out.shape[3]
         d.out_step_h, d.out_step_w, d.out_off_h, d.out_off_w = out_step[0], out_step[1], out_off[0], out_off[1]
-        d.packed_weights = packed.data_ptr()
+        if phases is None:
+            d.packed_weights = self._dev(pack_conv_weight(weight, src_channels, mb, ck)).data_ptr()
+            d.num_phases = 1
+        else:
+            d.num_phases = nph
+            for i, (wp, pt, pl, oh, ow) in enumerate(phases):
+                d.phase_weights[i] = self._dev(pack_conv_weight(wp, src_channels, mb, ck)).data_ptr()
+                d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh, ow
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         if residual is not None:
             assert residual.shape == out.shape
             d.residual = residual.data_ptr()
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
-        nchunks = sum(math.ceil(((c + 3) // 4 * 4) / 16) for c in src_channels)
-        mb, nb, split_k = self.schedule_override.get(name) or choose_schedule(cout, out_h, out_w, n, nchunks)
-        d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k = mb, nb, split_k
+        d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
         if split_k > 1:
-            self._ws_floats = max(self._ws_floats, split_k * n * ((cout + 15) // 16 * 16) * out_h * out_w)
+            self._ws_floats = max(self._ws_floats, split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
             self._pending_ws.append(d)
             d.workspace = 1  # placeholder (non-null) until the shared workspace exists
         lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
         if lds < 0:
-            _lib.check(int(lds), f"plan {name}")
-        macs = n * out_h * out_w * cout * cin * kh * kw
-        twb = 2 if out_w >= 32 else 1
-        wgs = math.ceil(out_w / (16 * twb)) * math.ceil(out_h / (4 * nb // twb)) * math.ceil(((cout + 15) // 16) / mb) * n * split_k
-        self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, wgs=wgs, lds=int(lds),
-                                  cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n))
+            _lib.check(int(lds), f"plan {name} sched={sched}")
+        macs = nph * n * out_h * out_w * cout * cin * kh * kw
+        geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb)
+        wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
+        self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, ck=ck, wgs=wgs, lds=int(lds),
+                                  cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
+                                  sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph),
+                                  spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),
+                                            stride=tuple(stride), pad=tuple(pad), grid=(out_h, out_w), in_mode=in_mode,
+                                            tf=tf, act=act, p0=p0, p1=p1, residual=residual is not None,
+                                            out_shape=tuple(out.shape), out_step=tuple(out_step), out_off=tuple(out_off),
+                                            phases=None if phases is None else [(pt, pl, oh, ow) for _, pt, pl, oh, ow in phases])))
         self.keep.append(d)
         self.stages[stage].append((name, self._launch_conv(d, name)))
         return out
@@ -242,14 +324,14 @@ class Plan:
                               stride=(1, stride))
 
     def refine(self, stage, name, srcs, prefix, out):
-        """layers.Refine (model/layers.py:389-397): ConvTranspose2d(4, 2) + LeakyReLU + crop, as 4 phase convs."""
+        """layers.Refine (model/layers.py:389-397): ConvTranspose2d(4, 2) + LeakyReLU + crop = 4 output-parity
+        2x2 convolutions, run as the 4 phases of ONE launch."""
         wt = self.sd[prefix + ".conv2d_t.weight"]
         bias = self.sd[prefix + ".conv2d_t.bias"]
         h, w = srcs[0].shape[2], srcs[0].shape[3]
-        for (py, px), (wp, pt, pl) in transposed_phase_weights(wt).items():
-            self.conv(stage, f"{name}.phase{py}{px}", srcs, wp, bias, out, stride=(1, 1), pad=(pt, pl), grid=(h, w),
-                      act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE, out_step=(2, 2), out_off=(py, px))
-        return out
+        phases = [(wp, pt, pl, py, px) for (py, px), (wp, pt, pl) in transposed_phase_weights(wt).items()]
+        return self.conv(stage, name, srcs, None, bias, out, stride=(1, 1), grid=(h, w), act=ACT_LEAKY_RELU,
+                         p0=LEAKY_SLOPE, out_step=(2, 2), phases=phases)
 
     def add(self, stage, name, fn):
         self.stages[stage].append((name, fn))

@@ -89,45 +89,51 @@ def test_batchnorm_folding():
     assert torch.allclose(F.conv2d(x, wf, bf), want, atol=1e-5)
 
 
-def _emulate_kernel_k_loop(packed, srcs, cout, kh, kw, stride, pad, grid):
+def _emulate_kernel_k_loop(packed, srcs, cout, kh, kw, stride, pad, grid, mb, ck):
     """Python model of conv_mfma_kernel's K walk over the packed weight stream (conv_layout.h):
-    D[cout][pixel] += A[cout][k] * B[k][pixel] with A fragments read in stream order."""
+    per cout group g: for chunk, tap, c4, m: D[(g*mb+m)*16 + i][pixel] += A[i][k] * B[k][pixel]."""
     n = srcs[0].shape[0]
     ho, wo = grid
     cb_n = (cout + 15) // 16
-    out = np.zeros((n, cb_n * 16, ho, wo), np.float64)
+    groups = (cb_n + mb - 1) // mb
+    out = np.zeros((n, groups * mb * 16, ho, wo), np.float64)
     off = 0
+    padded = []
     for s in srcs:
         c_real = s.shape[1]
         cpad = (c_real + 3) // 4 * 4
-        xp = np.zeros((n, cpad, s.shape[2] + 2 * 8, s.shape[3] + 2 * 8), np.float64)
+        xp = np.zeros((n, cpad, s.shape[2] + 16, s.shape[3] + 16), np.float64)
         xp[:, :c_real, 8:-8, 8:-8] = s.numpy()
-        for c0 in range(0, cpad, 16):
-            ck = min(16, cpad - c0)
-            for tap in range(kh * kw):
-                ky, kx = divmod(tap, kw)
-                for c4 in range(ck // 4):
-                    for cb in range(cb_n):
-                        frag = packed[off:off + 64].numpy().astype(np.float64)
-                        off += 64
-                        a = frag.reshape(4, 16)        # lane = k*16 + cout_in_block
-                        for k in range(4):
-                            ch = c0 + c4 * 4 + k
-                            ys = 8 - pad[0] + ky + stride[0] * np.arange(ho)
-                            xs = 8 - pad[1] + kx + stride[1] * np.arange(wo)
-                            b = xp[:, ch][:, ys][:, :, xs]                      # (n, ho, wo)
-                            out[:, cb * 16:(cb + 1) * 16] += a[k][None, :, None, None] * b[:, None]
+        padded.append((xp, cpad))
+    for g in range(groups):
+        for xp, cpad in padded:
+            for c0 in range(0, cpad, ck):
+                ckq = min(ck, cpad - c0)
+                for tap in range(kh * kw):
+                    ky, kx = divmod(tap, kw)
+                    ys = 8 - pad[0] + ky + stride[0] * np.arange(ho)
+                    xs = 8 - pad[1] + kx + stride[1] * np.arange(wo)
+                    for c4 in range(ckq // 4):
+                        for m in range(mb):
+                            a = packed[off:off + 64].numpy().astype(np.float64).reshape(4, 16)   # lane = k*16 + i
+                            off += 64
+                            cb = g * mb + m
+                            for k in range(4):
+                                b = xp[:, c0 + c4 * 4 + k][:, ys][:, :, xs]                      # (n, ho, wo)
+                                out[:, cb * 16:(cb + 1) * 16] += a[k][None, :, None, None] * b[:, None]
     assert off == packed.numel()
     return torch.from_numpy(out[:, :cout]).float()
 
 
-@pytest.mark.parametrize("srcs_c,cout,k,stride,pad", [
-    ((32, 3), 48, (7, 1), (1, 1), (3, 0)),      # DepthModule enc0 conv_y: concat of cv + keyframe (3 -> pad 4)
-    ((3,), 64, (7, 7), (2, 2), (3, 3)),         # ResNet stem
-    ((24,), 1, (3, 3), (1, 1), (1, 1)),         # head on 24 channels (16 + 8 chunk), single output channel
-    ((16, 20, 8), 40, (2, 2), (1, 1), (1, 0)),  # three sources, partial last cout block
+@pytest.mark.parametrize("srcs_c,cout,k,stride,pad,mb,ck", [
+    ((32, 3), 48, (7, 1), (1, 1), (3, 0), 3, 16),      # DepthModule enc0 conv_y: concat of cv + keyframe (3 -> pad 4)
+    ((3,), 64, (7, 7), (2, 2), (3, 3), 2, 16),         # ResNet stem
+    ((24,), 1, (3, 3), (1, 1), (1, 1), 1, 16),         # head on 24 channels (16 + 8 chunk), single output channel
+    ((16, 20, 8), 40, (2, 2), (1, 1), (1, 0), 2, 16),  # three sources, partial last cout group
+    ((72, 40), 96, (3, 3), (1, 1), (1, 1), 4, 32),     # deeper chunks, group count not dividing the cout blocks
+    ((128,), 32, (1, 3), (1, 2), (0, 1), 1, 64),
 ])
-def test_packed_weight_stream_matches_conv2d(hip_lib, srcs_c, cout, k, stride, pad):
+def test_packed_weight_stream_matches_conv2d(hip_lib, srcs_c, cout, k, stride, pad, mb, ck):
     torch.manual_seed(1)
     n, h, w = 1, 10, 12
     srcs = [torch.randn(n, c, h, w) for c in srcs_c]
@@ -135,8 +141,8 @@ def test_packed_weight_stream_matches_conv2d(hip_lib, srcs_c, cout, k, stride, p
     ho = (h + 2 * pad[0] - k[0]) // stride[0] + 1
     wo = (w + 2 * pad[1] - k[1]) // stride[1] + 1
     want = F.conv2d(F.pad(torch.cat(srcs, 1), [pad[1], pad[1], pad[0], pad[0]]), weight, stride=stride)
-    packed = engine.pack_conv_weight(weight, list(srcs_c))
-    got = _emulate_kernel_k_loop(packed, srcs, cout, k[0], k[1], stride, pad, (ho, wo))
+    packed = engine.pack_conv_weight(weight, list(srcs_c), mb, ck)
+    got = _emulate_kernel_k_loop(packed, srcs, cout, k[0], k[1], stride, pad, (ho, wo), mb, ck)
     assert torch.allclose(got, want, atol=1e-4), float((got - want).abs().max())
 
 
@@ -207,5 +213,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
     assert abs(plan.conv_macs() / 1e9 - 61.07) < 0.01
     assert max(c["lds"] for c in plan.conv_log) <= 64 * 1024
-    assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 for c in plan.conv_log)
+    assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (16, 32, 64)
+               for c in plan.conv_log)
+    assert sum(c["phases"] == 4 for c in plan.conv_log) == 4        # the four Refine transposed convolutions
     assert len(plan.stages["encoder"]) == 21 and plan.stages["main"][0][0] == "cost_volume"

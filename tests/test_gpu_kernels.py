@@ -42,24 +42,24 @@ def _act_ref(x, act, p0, p1):
 
 
 CONV_CASES = [
-    # (srcs_c, cout, k, stride, pad, hw, batch, act, in_mode, tf, residual, (mb, nb, split_k))
-    ((32,), 32, (3, 3), (1, 1), (1, 1), (40, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1)),
-    ((32,), 48, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_LEAKY_RELU, IN_MAXPOOL2, TF_NONE, False, (3, 2, 1)),
-    ((3,), 64, (7, 7), (2, 2), (3, 3), (64, 96), 2, ACT_RELU, IN_DIRECT, TF_RESNET_NORM, False, (2, 2, 1)),
-    ((64,), 64, (3, 3), (1, 1), (1, 1), (16, 24), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 1)),
-    ((64,), 128, (3, 3), (2, 2), (1, 1), (16, 32), 1, ACT_RELU, IN_DIRECT, TF_NONE, False, (4, 1, 2)),
-    ((64,), 128, (1, 1), (2, 2), (0, 0), (16, 32), 2, ACT_NONE, IN_DIRECT, TF_NONE, False, (1, 2, 1)),
-    ((96, 256), 96, (2, 2), (1, 1), (0, 0), (4, 6), 1, ACT_NONE, IN_UPSAMPLE2, TF_NONE, False, (6, 1, 1)),
-    ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (6, 2, 4)),
-    ((32, 3), 48, (7, 1), (1, 1), (3, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 4, 1)),
-    ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (4, 2, 1)),
-    ((64,), 64, (1, 7), (1, 2), (0, 2), (32, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 2, 1)),
-    ((128,), 128, (1, 5), (1, 2), (0, 1), (16, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 1, 2)),
-    ((48,), 1, (1, 1), (1, 1), (0, 0), (32, 64), 2, ACT_SIGMOID, IN_DIRECT, TF_NONE, False, (1, 4, 1)),
-    ((24,), 1, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 4, 1)),
-    ((256,), 1, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 1, 8)),
-    ((512,), 512, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 4)),
-    ((32,), 24, (3, 3), (1, 1), (1, 1), (24, 40), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1)),
+    # (srcs_c, cout, k, stride, pad, hw, batch, act, in_mode, tf, residual, (mb, nb, split_k, ck))
+    ((32,), 32, (3, 3), (1, 1), (1, 1), (40, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1, 16)),
+    ((32,), 48, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_LEAKY_RELU, IN_MAXPOOL2, TF_NONE, False, (3, 2, 1, 16)),
+    ((3,), 64, (7, 7), (2, 2), (3, 3), (64, 96), 2, ACT_RELU, IN_DIRECT, TF_RESNET_NORM, False, (2, 2, 1, 16)),
+    ((64,), 64, (3, 3), (1, 1), (1, 1), (16, 24), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 1, 16)),
+    ((64,), 128, (3, 3), (2, 2), (1, 1), (16, 32), 1, ACT_RELU, IN_DIRECT, TF_NONE, False, (4, 1, 2, 16)),
+    ((64,), 128, (1, 1), (2, 2), (0, 0), (16, 32), 2, ACT_NONE, IN_DIRECT, TF_NONE, False, (1, 2, 1, 16)),
+    ((96, 256), 96, (2, 2), (1, 1), (0, 0), (4, 6), 1, ACT_NONE, IN_UPSAMPLE2, TF_NONE, False, (6, 1, 1, 16)),
+    ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (6, 2, 4, 32)),
+    ((32, 3), 48, (7, 1), (1, 1), (3, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 4, 1, 16)),
+    ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (4, 2, 1, 16)),
+    ((64,), 64, (1, 7), (1, 2), (0, 2), (32, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 2, 1, 16)),
+    ((128,), 128, (1, 5), (1, 2), (0, 1), (16, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 1, 2, 16)),
+    ((48,), 1, (1, 1), (1, 1), (0, 0), (32, 64), 2, ACT_SIGMOID, IN_DIRECT, TF_NONE, False, (1, 4, 1, 16)),
+    ((24,), 1, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 4, 1, 16)),
+    ((256,), 1, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 1, 8, 32)),
+    ((512,), 512, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 4, 32)),
+    ((32,), 24, (3, 3), (1, 1), (1, 1), (24, 40), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1, 16)),
 ]
 
 
@@ -106,28 +106,29 @@ def test_conv_matches_torch_fp32(hip_lib, case):
 
 
 @pytest.mark.parametrize("mb", [1, 2, 3, 4, 6])
-@pytest.mark.parametrize("nb", [1, 2, 4])
-def test_conv_every_register_tile(hip_lib, mb, nb):
+@pytest.mark.parametrize("nb,ck", [(1, 16), (2, 32), (4, 64)])
+def test_conv_every_register_tile(hip_lib, mb, nb, ck):
     g = torch.Generator().manual_seed(mb * 10 + nb)
-    x = torch.randn(2, 20, 24, 40, generator=g)
-    w = torch.randn(96, 20, 3, 3, generator=g) / 13.0
+    x = torch.randn(2, 84, 24, 40, generator=g)
+    w = torch.randn(96, 84, 3, 3, generator=g) / 27.0
     b = torch.randn(96, generator=g)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
-    plan = engine.Plan.bare(DEV, schedule_override={"t": (mb, nb, 1)})
+    plan = engine.Plan.bare(DEV, schedule_override={"t": (mb, nb, 1, ck)})
     out = plan.alloc("out", 2, 96, 24, 40)
     plan.conv("main", "t", [x.to(DEV)], w, b, out, pad=(1, 1), grid=(24, 40))
     _run(plan)
     assert (out.cpu() - ref).abs().max().item() < 2e-4
 
 
-def test_refine_transposed_conv(hip_lib):
+@pytest.mark.parametrize("sched", [(1, 1, 1, 16), (3, 2, 2, 16), (2, 4, 1, 32)])
+def test_refine_transposed_conv(hip_lib, sched):
     g = torch.Generator().manual_seed(3)
     srcs = [torch.randn(2, 48, 8, 12, generator=g), torch.randn(2, 16, 8, 12, generator=g)]
     wt = torch.randn(64, 40, 4, 4, generator=g) / 16.0
     bias = torch.randn(40, generator=g)
     sd = {"r.conv2d_t.weight": wt, "r.conv2d_t.bias": bias}
     ref = orc.refine(sd, "r", torch.cat(srcs, 1))
-    plan = engine.Plan.bare(DEV, state=sd)
+    plan = engine.Plan.bare(DEV, state=sd, schedule_override={"r": sched})
     out = plan.alloc("out", 2, 40, 16, 24)
     out.fill_(float("nan"))
     plan.refine("main", "r", [s.to(DEV) for s in srcs], "r", out)

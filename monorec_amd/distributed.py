@@ -1,0 +1,79 @@
+"""Multi-GPU evaluation: one process per GPU, keyframe batches sharded across ranks, ONE tiny
+all-gather of per-rank metric sums at the end (RCCL over xGMI on MI355X; gloo on CPU for tests).
+
+This replaces the reference's single-process `torch.nn.DataParallel` wrapping
+(base/base_trainer.py:26-29, evaluater/evaluater.py:27-30), which scatters every batch across GPUs,
+re-broadcasts the 70 MB of weights on every forward and gathers outputs to GPU 0.  Keyframes are
+independent in eval mode, so there is no data-path collective at all: every rank owns a
+replica of the weights and a contiguous/round-robin shard of the *batch list* (batch granularity keeps
+the reference's per-batch metric semantics, evaluater.py:94-103,116), and the only exchange is
+`world x (num_metrics + 1)` float64 values.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+    kwargs = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world, **kwargs)
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_batches(num_batches, rank=None, world=None, contiguous=False):
+    """Indices of the batches this rank evaluates. Round-robin by default (balances a sequence whose
+    cost drifts); contiguous keeps neighbouring keyframes (source-frame reuse) on one rank."""
+    if rank is None or world is None:
+        rank, world = world_info()
+    if contiguous:
+        per = (num_batches + world - 1) // world
+        return list(range(rank * per, min(num_batches, (rank + 1) * per)))
+    return list(range(rank, num_batches, world))
+
+
+def gather_sums(local_sums, device=None):
+    """all_gather of a small float64 vector; returns a (world, n) tensor on every rank."""
+    rank, world = world_info()
+    t = torch.as_tensor(local_sums, dtype=torch.float64)
+    if world == 1:
+        return t.reshape(1, -1)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = t.to(device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu()
+
+
+def reduce_batch_metrics(per_batch_metrics):
+    """Combine per-batch metric vectors evaluated on this rank's shard into the global per-batch mean -
+    exactly what Evaluater.eval computes in one process (sum over batches / number of batches,
+    evaluater.py:94-103,116).  per_batch_metrics: list of equal-length sequences (one per local batch)."""
+    n_metrics = len(per_batch_metrics[0]) if per_batch_metrics else 0
+    _, world = world_info()
+    if world > 1:   # ranks with an empty shard still need the vector length
+        lens = gather_sums([float(n_metrics)])
+        n_metrics = int(lens.max().item())
+    local = torch.zeros(n_metrics + 1, dtype=torch.float64)
+    for m in per_batch_metrics:
+        local[:n_metrics] += torch.as_tensor(m, dtype=torch.float64)
+        local[n_metrics] += 1
+    total = gather_sums(local).sum(0)
+    return (total[:n_metrics] / total[n_metrics].clamp_min(1)).tolist(), int(total[n_metrics].item())

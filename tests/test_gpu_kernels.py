@@ -106,7 +106,7 @@ def test_conv_matches_torch_fp32(hip_lib, case):
 
 
 @pytest.mark.parametrize("mb", [1, 2, 3, 4, 6])
-@pytest.mark.parametrize("nb,ck", [(1, 16), (2, 32), (4, 64)])
+@pytest.mark.parametrize("nb,ck", [(1, 64), (2, 32), (4, 16)])
 def test_conv_every_register_tile(hip_lib, mb, nb, ck):
     g = torch.Generator().manual_seed(mb * 10 + nb)
     x = torch.randn(2, 84, 24, 40, generator=g)
@@ -182,24 +182,28 @@ def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
     batch = g.make_inputs()
     cv, sf = _hip_cost_volume(batch, g.depths)
     assert not torch.isnan(cv).any() and not any(torch.isnan(s).any() for s in sf)
-    stages = {}
-    ocv, osf = orc.cost_volume(batch, steps=g.depths, stages=stages)
-    # validity mask: sfcv == 0 for all depths <=> invalid; must agree with the oracle except for rare
-    # 1-ulp projection flips (none expected: the projection chain reproduces the CPU bits)
+    # 1. the committed outputs of the REAL reference (generated in the build container): tight.
+    #    Measured on MI355X: max |diff| 2-5e-7, no outliers - the kernel reproduces the reference's
+    #    projection / bilinear / SSIM arithmetic bit for bit, only the 27-tap sum order differs.
+    if g.full_model:   # the fixture stores the masked fused volume for full-model cases; compare sfcv only
+        for f in range(len(sf)):
+            info = g.compare(f"sfcv{f}", sf[f], atol=2e-6, max_outlier_frac=1e-4)
+            print(case, f"sfcv{f} vs reference fixture", info)
+    else:
+        print(case, "cv vs reference fixture", g.compare("cost_volume", cv, atol=5e-6, max_outlier_frac=1e-4))
+        for f in range(len(sf)):
+            g.compare(f"sfcv{f}", sf[f], atol=2e-6, max_outlier_frac=1e-4)
+    # 2. the CPU oracle run on THIS host.  A different CPU (MKL/oneDNN code path) moves the oracle itself by
+    #    up to ~4e-5 on ~0.1 % of the entries (SSIM ratios of tiny variances amplify 1-ulp differences of
+    #    the warped samples), so this leg is looser and flip tolerant.
+    ocv, osf = orc.cost_volume(batch, steps=g.depths)
     for f in range(len(sf)):
         flips = ((sf[f] == 0).all(1) != (osf[f] == 0).all(1)).float().mean().item()
         assert flips <= 1e-4, (f, flips)
-        bad = ((sf[f] - osf[f]).abs() > 2e-5).float().mean().item()
-        assert bad <= 2e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
-    bad = ((cv - ocv).abs() > 5e-5).float().mean().item()
-    assert bad <= 2e-4, (bad, (cv - ocv).abs().max().item())
-    # and against the committed outputs of the real reference
-    name = "cost_volume"
-    if g.full_model:   # the fixture stores the masked volume for full-model cases; compare sfcv only
-        for f in range(len(sf)):
-            g.compare(f"sfcv{f}", sf[f], atol=2e-5, max_outlier_frac=2e-4)
-    else:
-        g.compare(name, cv, atol=5e-5, max_outlier_frac=2e-4)
+        bad = ((sf[f] - osf[f]).abs() > 1e-4).float().mean().item()
+        assert bad <= 1e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
+    bad = ((cv - ocv).abs() > 2e-4).float().mean().item()
+    assert bad <= 1e-4, (bad, (cv - ocv).abs().max().item())
 
 
 def test_cost_volume_properties_at_full_size(hip_lib):

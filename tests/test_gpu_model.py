@@ -34,16 +34,17 @@ def _check_against(out, ref_out, tag):
         a, b = out["image_features"][i].cpu(), ref_out["image_features"][i]
         errs[f"feat{i}"] = ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
     cvd = (out["cost_volume"].cpu() - ref_out["cost_volume"]).abs()
-    errs["cv_outliers"] = (cvd > 1e-4).float().mean().item()
+    errs["cv_outliers"] = (cvd > 2e-4).float().mean().item()
     for f, s in enumerate(out["single_frame_cvs"]):
-        errs[f"sfcv{f}_outliers"] = ((s.cpu() - ref_out["single_frame_cvs"][f]).abs() > 2e-5).float().mean().item()
+        # local-CPU oracle noise on another host CPU is ~4e-5 on 0.1 % of entries (see test_gpu_kernels.py)
+        errs[f"sfcv{f}_outliers"] = ((s.cpu() - ref_out["single_frame_cvs"][f]).abs() > 1e-4).float().mean().item()
     print(tag, {k: f"{v:.2e}" for k, v in errs.items()})
     assert errs["result"] <= RESULT_ATOL, errs
     assert errs["cv_mask"] <= 1e-4, errs
     assert all(errs[f"pred{i}"] <= RESULT_ATOL for i in range(4)), errs
     assert all(errs[f"feat{i}"] <= 1e-4 for i in range(5)), errs
     assert errs["cv_outliers"] <= 5e-4, errs
-    assert all(errs[f"sfcv{f}_outliers"] <= 2e-4 for f in range(len(out["single_frame_cvs"]))), errs
+    assert all(errs[f"sfcv{f}_outliers"] <= 1e-4 for f in range(len(out["single_frame_cvs"]))), errs
     return errs
 
 
@@ -64,7 +65,9 @@ def test_forward_matches_oracle_and_fixture(hip_lib, case):
         g.compare(f"pred{i}", out["predicted_inverse_depths"][i], atol=RESULT_ATOL)
     for i in range(5):
         g.compare(f"feat{i}", out["image_features"][i], atol=2e-4, rtol=1e-4)
-    g.compare("cost_volume", out["cost_volume"], atol=1e-4, max_outlier_frac=5e-4)
+    g.compare("cost_volume", out["cost_volume"], atol=1e-5, max_outlier_frac=1e-4)
+    for f in range(g.frames):
+        g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=2e-6, max_outlier_frac=1e-4)
     # dict contract (monorec_model.py:675-677,726-727)
     assert out["result"] is out["predicted_inverse_depths"][0] and out["mask"] is out["cv_mask"]
     assert out["cv_depth_steps"].dtype == torch.int32 and int(out["cv_depth_steps"][0]) == g.depths

@@ -294,7 +294,7 @@ class Plan:
                                             tf=tf, act=act, p0=p0, p1=p1, residual=residual is not None,
                                             out_shape=tuple(out.shape), out_step=tuple(out_step), out_off=tuple(out_off),
                                             phases=None if phases is None else [(pt, pl, oh, ow) for _, pt, pl, oh, ow in phases])))
-        self.keep.append(d)
+        self.keep += [d, out, residual] + list(srcs)      # the descriptor only holds raw pointers
         self.stages[stage].append((name, self._launch_conv(d, name)))
         return out
 

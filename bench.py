@@ -74,6 +74,21 @@ def time_layers(model, batch_dev, plan_key, reps=5):
     return rows
 
 
+def committed_pmc_traffic():
+    """HBM bytes per conv launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under
+    profiles/ (collected with `rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --no-graph`,
+    summarised by tools/summarize_prof.py).  PMC counters cannot be read from inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))["derived"]["conv_mfma_kernel_all_instances"]
+        return d.get("hbm_bytes_per_dispatch"), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(sd, batch_cpu, depths, budget_s=25.0):
     """The CPU oracle (restatement of the reference's torch-CPU path, oracle/monorec_oracle.py) on this
     box's host cores: 1 warm-up + best of up to 5 forwards of the same keyframe batch."""
@@ -155,6 +170,7 @@ def main():
         conv_flops = 2.0 * sum(r["macs"] for r in conv_rows)
         achieved = conv_flops / conv_s / 1e12
         cv_row = next(r for r in rows if r["name"] == "cost_volume")
+        traffic, traffic_src = committed_pmc_traffic() if (args.batch, args.height, args.width, args.frames, args.depths) == (1, 256, 512, 2, 32) else (None, None)
         cv_bytes = 4.0 * args.batch * args.height * args.width * (3 + args.depths) * (1 + args.frames)
         result = {
             "metric": "frames/sec (keyframes/s), KITTI 256x512 2-src/32-bin cost-volume inference",
@@ -175,7 +191,7 @@ def main():
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4_f32)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
                          "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
                          "algorithmic_gflop_per_step": conv_flops / 1e9, "conv_ms_per_step": conv_s * 1e3},
             "cost_volume_kernel": {"bound": "hbm", "us": cv_row["seconds"] * 1e6, "algorithmic_MB": cv_bytes / 1e6,

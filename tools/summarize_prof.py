@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 result databases (gpurun_out/...) into the small tracked summaries under profiles/.
+
+    python tools/summarize_prof.py --tag r01 --stats gpurun_out/prof/r01_results.db \
+        --pmc gpurun_out/pmc_FETCH_SIZE/p_results.db gpurun_out/pmc_WRITE_SIZE/p_results.db ...
+"""
+import argparse
+import collections
+import csv
+import json
+import os
+import sqlite3
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--stats", default=None)
+    ap.add_argument("--pmc", nargs="*", default=[])
+    ap.add_argument("--launches-per-step", type=int, default=None, help="dispatches of each kernel instance per profiled run / steps")
+    args = ap.parse_args()
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    if args.stats:
+        c = sqlite3.connect(args.stats)
+        cols = [r[1] for r in c.execute("pragma table_info(top_kernels)")]
+        rows = list(c.execute("select * from top_kernels"))
+        with open(os.path.join(out_dir, f"{args.tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(cols + ["note: durations in us; rocprofv3 --kernel-trace --stats"])
+            w.writerows(rows)
+    agg = collections.defaultdict(dict)
+    for path in args.pmc:
+        c = sqlite3.connect(path)
+        q = "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"
+        for k, cn, n, s in c.execute(q):
+            agg[k][cn] = {"dispatches": n, "sum": s, "per_dispatch": s / n}
+    if agg:
+        summary = {}
+        conv = collections.defaultdict(float)
+        conv_n = 0
+        for k, v in agg.items():
+            short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            summary[short] = v
+            if "conv_mfma_kernel" in k:
+                for cn, d in v.items():
+                    conv[cn] += d["sum"]
+                conv_n += next(iter(v.values()))["dispatches"]
+        derived = {"conv_mfma_kernel_all_instances": {"dispatches": conv_n}}
+        d = derived["conv_mfma_kernel_all_instances"]
+        if "FETCH_SIZE" in conv:
+            d["FETCH_SIZE_KiB_per_dispatch"] = conv["FETCH_SIZE"] / conv_n
+        if "WRITE_SIZE" in conv:
+            d["WRITE_SIZE_KiB_per_dispatch"] = conv["WRITE_SIZE"] / conv_n
+        if "FETCH_SIZE" in conv and "WRITE_SIZE" in conv:
+            d["hbm_bytes_per_dispatch"] = (conv["FETCH_SIZE"] + conv["WRITE_SIZE"]) * 1024 / conv_n
+            d["note"] = ("dword (4 B/lane) buffer loads: the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to "
+                         "16 B/lane streams and is NOT applied here (uncalibrated width); WRITE_SIZE as reported")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in conv and "GRBM_GUI_ACTIVE" in conv:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+            d["mfma_util"] = (conv["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (conv["GRBM_GUI_ACTIVE"] / 8)
+        if "SQ_WAIT_ANY" in conv and "SQ_WAVE_CYCLES" in conv:
+            d["wait_any_frac_of_wave_cycles"] = conv["SQ_WAIT_ANY"] / conv["SQ_WAVE_CYCLES"]
+        if "SQ_LDS_BANK_CONFLICT" in conv:
+            d["lds_bank_conflict_cycles"] = conv["SQ_LDS_BANK_CONFLICT"]
+        with open(os.path.join(out_dir, f"{args.tag}_pmc_summary.json"), "w") as f:
+            json.dump({"derived": derived, "per_kernel": summary}, f, indent=1, sort_keys=True)
+        print(json.dumps(derived, indent=1))
+
+
+if __name__ == "__main__":
+    main()

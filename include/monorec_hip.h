@@ -96,7 +96,7 @@ typedef struct mr_conv_desc {
     /* schedule */
     int32_t cout_blocks_per_wg;      /* MB: 16-channel output blocks per workgroup, one of 1,2,3,4,6 */
     int32_t pixel_blocks_per_wave;   /* NB: 16-pixel row segments per wave, one of 1,2,4            */
-    int32_t chunk_channels;          /* CK: input channels staged per LDS chunk, one of 16,32,64    */
+    int32_t chunk_channels;          /* CK: input channels staged per LDS chunk, one of 8,16,32,64  */
     int32_t split_k;                 /* >= 1; > 1 needs `workspace`                               */
     float* workspace;                /* split_k * phases * batch * ceil16(out_channels) * out_h * out_w floats */
     /* optional output phases (the 4 parities of ConvTranspose2d(k=4,s=2), model/layers.py:389):

@@ -55,6 +55,8 @@ struct ConvKArgs {
     float p0, p1;
     int tiles_x, TH, TWB;
     int IH, IW, PLANE, CK, ppt;
+    int wmax_floats;           // A-fragment floats of the largest chunk (per pipeline buffer)
+    int dma_in;                // input tile staged by buffer_load ... lds (direct / upsample reads)
     int ksplit, nchunks, batch, nphase;
     long long wgroup_stride;   // packed floats per cout group
     float* ws;
@@ -134,11 +136,139 @@ __device__ __forceinline__ void kstep(f32x4 (&acc)[MB][NB], const float* __restr
         for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[i], acc[m][i], 0, 0, 0);
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ---- LDS-DMA, issued through inline asm ------------------------------------------------------------------
+// hipcc treats an LDS-DMA builtin as a store that may alias every later ds_read and drains it (vmcnt(0))
+// before the MFMA sweep of the *other* pipeline buffer, which serialises load and compute.  Inline asm is
+// invisible to that pass; the kernel waits itself (dma_wait_all) right before the barrier that publishes the
+// buffer.  M0 (LDS base of the DMA) is saved/restored inside the statement; `s_nop 4` covers the
+// SALU/VALU-write -> VMEM-SGPR-read hazard the compiler does not pad for asm operands.
+__device__ __forceinline__ void dma_buffer_dword(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const float* g) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma_global_x1(unsigned lds_byte_addr, const float* g) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// K-chunk cursor over the concatenated sources (chunks never straddle two sources).
+struct ChunkCursor {
+    int s, c0;
+    long long woff;
+};
+
+template <int MB>
+__device__ __forceinline__ void cursor_advance(const ConvKArgs& a, ChunkCursor& c, int T) {
+    const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
+    c.woff += (long long)T * (ck >> 2) * MB * 64;
+    c.c0 += a.CK;
+    if (c.c0 >= a.src_cpad[c.s]) { c.c0 = 0; ++c.s; }
+}
+
+// Issue everything chunk `c` needs into LDS buffer (ldsI, ldsW):
+//   * A fragments: one contiguous block, global_load_lds_dwordx4 (1 KiB per wave instruction);
+//   * input tile: DMA path (direct / upsample reads): buffer_load_dword ... lds, one 256 B row of the tile per
+//     wave instruction, hardware zero fill for out-of-range offsets; no VGPRs, nothing to wait for here;
+//     register path (2x2 max-pool or input normalisation): SRD loads -> VALU -> ds_write.
+template <int MB, bool DMA_IN>
+__device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCursor& c, float* ldsI, float* ldsW,
+                                            unsigned ldsI_addr, unsigned ldsW_addr,
+                                            const float* wgrp, int b, int T, int lane, int wave, int HsWs,
+                                            const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT]) {
+    const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
+    const int wfloats = T * (ck >> 2) * MB * 64;
+    const float* wsrc = wgrp + c.woff;
+    const int n1k = wfloats >> 8;                     // 1 KiB pieces (64 lanes x 16 B)
+    for (int kb = wave; kb < n1k; kb += 4) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
+    const int nfrag = wfloats >> 6;                   // tail: 256 B pieces (64 lanes x 4 B)
+    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += 4) dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane);
+
+    const int creal = a.src_c[c.s] - c.c0;                            // real (unpadded) channels left
+    const int sbase_bytes = (b * a.src_c[c.s] + c.c0) * HsWs * 4;     // byte offset of channel c0 of sample b
+    if (DMA_IN) {
+        const i32x4 srd = make_srd(a.src[c.s], a.src_bytes[c.s]);
+#pragma unroll
+        for (int j = 0; j < MR_MAX_PPT; ++j) {
+            if (j < a.ppt && loff[j] >= 0) {                          // EXEC masks lanes beyond the tile
+                const int voff = goff[j] >= 0 ? goff[j] * 4 : -1;     // -1: out of range -> hardware writes 0
+                const unsigned lrow = ldsI_addr + (wave * 64 + 256 * j) * 4;   // wave-uniform; lane l lands at +4l
+                for (int cc = 0; cc < ck; ++cc) {
+                    const int vo = cc < creal ? voff : -1;            // padded channels read as zero
+                    dma_buffer_dword(lrow + cc * a.PLANE * 4, vo, srd, sbase_bytes + cc * HsWs * 4);
+                }
+            }
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[c.s], 0, a.src_bytes[c.s], 0x00020000);
+        for (int cs = 0; cs < ck; cs += 16) {
+#pragma unroll
+            for (int j = 0; j < MR_MAX_PPT; ++j) {
+                if (j < a.ppt && loff[j] >= 0) {
+                    const int voff = goff[j] >= 0 ? goff[j] * 4 : -1;
+                    if (a.in_mode == MR_IN_MAXPOOL2)
+                        stage_position<true, false>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
+                    else if (a.in_tf == MR_TF_RESNET_NORM)
+                        stage_position<false, true>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
+                    else
+                        stage_position<false, false>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
+                }
+            }
+        }
+    }
+}
+
 template <int MB, int NB>
+__device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
+                                            const int (&lbase)[NB], int ck4, int lane) {
+    const float* wl = ldsW + lane;
+    for (int kh = 0; kh < a.KH; ++kh) {
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int tapoff = kh * a.IW + kw;
+            const float* wt = wl + (kh * a.KW + kw) * ck4 * (MB * 64);
+            int c4 = 0;
+            for (; c4 + 4 <= ck4; c4 += 4) {          // manual 4x unroll: LDS reads of 4 k-steps overlap
+                kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
+                kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 1, (c4 + 1) * 4 * a.PLANE + tapoff);
+                kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 2, (c4 + 2) * 4 * a.PLANE + tapoff);
+                kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 3, (c4 + 3) * 4 * a.PLANE + tapoff);
+            }
+            for (; c4 < ck4; ++c4) kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
+        }
+    }
+}
+
+// DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
+// max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
+// make hipcc drain vmcnt before every sweep and spill SGPRs).
+template <int MB, int NB, bool DMA_IN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ldsI = lds;                       // [CK][PLANE]
-    float* ldsW = lds + a.CK * a.PLANE;      // [taps][ck4][MB][64]
+    // two pipeline buffers, each [CK][PLANE] input tile + [taps][ck4][MB][64] A fragments
+    const int ioff = a.CK * a.PLANE;
+    const int bufsz = ioff + a.wmax_floats;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,65 +319,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     const int q_lo = (ks * a.nchunks) / a.ksplit, q_hi = ((ks + 1) * a.nchunks) / a.ksplit;
     const int T = a.KH * a.KW;
     const float* wgrp = a.w[ph] + (long long)grp * a.wgroup_stride;
-    long long woff = 0;
-    int q = 0;
-    for (int s = 0; s < a.nsrc; ++s) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[s], 0, a.src_bytes[s], 0x00020000);
-        for (int c0 = 0; c0 < a.src_cpad[s]; c0 += a.CK, ++q) {
-            const int ck = min(a.CK, a.src_cpad[s] - c0);
-            const int ck4 = ck >> 2;
-            const int wfloats = T * ck4 * MB * 64;
-            if (q >= q_lo && q < q_hi) {
-                __syncthreads();  // all waves finished reading the previous chunk
-                // ---- A fragments of this (group, chunk): contiguous block, DMA global -> LDS --------
-                {
-                    const float* wsrc = wgrp + woff;
-                    const int n1k = wfloats >> 8;                     // 1 KiB pieces (64 lanes x 16 B)
-                    for (int kb = wave; kb < n1k; kb += 4)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 256 + lane * 4),
-                                                         (__attribute__((address_space(3))) void*)(ldsW + kb * 256), 16, 0, 0);
-                    const int nfrag = wfloats >> 6;                   // tail: 256 B pieces (64 lanes x 4 B)
-                    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += 4)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + fr * 64 + lane),
-                                                         (__attribute__((address_space(3))) void*)(ldsW + fr * 64), 4, 0, 0);
-                }
-                // ---- input tile: per position, 16 channel planes per batch of loads --------------------
-                const int creal = a.src_c[s] - c0;                    // real (unpadded) channels left
-                const int sbase_bytes = (b * a.src_c[s] + c0) * HsWs * 4;   // byte offset of channel c0 of sample b
-                for (int cs = 0; cs < ck; cs += 16) {
-#pragma unroll
-                    for (int j = 0; j < MR_MAX_PPT; ++j) {
-                        if (j < a.ppt && loff[j] >= 0) {
-                            const int voff = goff[j] >= 0 ? goff[j] * 4 : -1;
-                            if (a.in_mode == MR_IN_MAXPOOL2)
-                                stage_position<true, false>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
-                            else if (a.in_tf == MR_TF_RESNET_NORM)
-                                stage_position<false, true>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
-                            else
-                                stage_position<false, false>(ldsI, rsrc, voff, sbase_bytes, cs, ck, creal, HsWs, a.Ws, a.PLANE, loff[j]);
-                        }
-                    }
-                }
-                __syncthreads();
-                // ---- MFMA sweep: LDS only ------------------------------------------------------------
-                const float* wl = ldsW + lane;
-                for (int kh = 0; kh < a.KH; ++kh) {
-                    for (int kw = 0; kw < a.KW; ++kw) {
-                        const int tapoff = kh * a.IW + kw;
-                        const float* wt = wl + (kh * a.KW + kw) * ck4 * (MB * 64);
-                        int c4 = 0;
-                        for (; c4 + 4 <= ck4; c4 += 4) {          // manual 4x unroll: LDS reads of 4 k-steps overlap
-                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
-                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 1, (c4 + 1) * 4 * a.PLANE + tapoff);
-                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 2, (c4 + 2) * 4 * a.PLANE + tapoff);
-                            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 3, (c4 + 3) * 4 * a.PLANE + tapoff);
-                        }
-                        for (; c4 < ck4; ++c4) kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
-                    }
-                }
-            }
-            woff += wfloats;
+
+    // ---- software pipeline over K chunks: chunk q+1 streams into the other buffer while q is swept ----------
+    ChunkCursor cur = {0, 0, 0};
+    for (int q = 0; q < q_lo; ++q) cursor_advance<MB>(a, cur, T);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff);
+    dma_wait_all();
+    __syncthreads();
+    int pb = 0;
+    for (int q = q_lo; q < q_hi; ++q) {
+        const int ck4 = min(a.CK, a.src_cpad[cur.s] - cur.c0) >> 2;
+        float* bcur = lds + pb * bufsz;
+        float* bnxt = lds + (pb ^ 1) * bufsz;
+        cursor_advance<MB>(a, cur, T);
+        if (q + 1 < q_hi) {
+            const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
+            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff);
         }
+        sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
+        dma_wait_all();                                // this wave's share of the next chunk has landed
+        __syncthreads();                               // ... everyone's has, and everyone is done with this buffer
+        pb ^= 1;
     }
 
     // ---- epilogue: D fragment lane l holds pixel (l&15), couts (l>>4)*4 + r ---------------------
@@ -302,7 +395,7 @@ struct Derived {
 };
 
 bool valid_mb(int mb) { return mb == 1 || mb == 2 || mb == 3 || mb == 4 || mb == 6; }
-bool valid_ck(int ck) { return ck == 16 || ck == 32 || ck == 64; }
+bool valid_ck(int ck) { return ck == 8 || ck == 16 || ck == 32 || ck == 64; }
 
 int derive(const mr_conv_desc* d, Derived* out) {
     if (!d || d->num_src < 1 || d->num_src > MR_MAX_SOURCES) return MR_ERR_BAD_ARGUMENT;
@@ -381,9 +474,14 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
     const int taps = k.KH * k.KW;
     k.wgroup_stride = (long long)taps * (cpad_total / 4) * mb * 64;
-    const int ck_max = cpad_total < k.CK ? cpad_total : k.CK;   // upper bound of any chunk
-    const size_t w_floats = (size_t)taps * (ck_max / 4) * mb * 64;
-    out->lds_bytes = ((size_t)k.CK * plane + w_floats) * sizeof(float);
+    int ck_max = 0;                                              // largest chunk of any source
+    for (int s = 0; s < d->num_src; ++s) {
+        const int c = k.src_cpad[s] < k.CK ? k.src_cpad[s] : k.CK;
+        if (c > ck_max) ck_max = c;
+    }
+    k.wmax_floats = taps * (ck_max / 4) * mb * 64;
+    k.dma_in = (d->in_mode != MR_IN_MAXPOOL2 && d->in_transform == MR_TF_NONE) ? 1 : 0;
+    out->lds_bytes = 2 * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);   // double buffered
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
     out->mb = mb; out->nb = nb;
     out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)mr_ceil_div(k.CB, mb),
@@ -391,25 +489,32 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB>
+template <int MB, int NB, bool DMA_IN>
 int launch(const Derived& dv, hipStream_t stream) {
     static bool attr_set = false;  // raise the dynamic-LDS ceiling once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB>), dv.grid, dim3(256), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN>), dv.grid, dim3(256), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
 template <int MB>
 int launch_nb(const Derived& dv, hipStream_t stream) {
+    if (dv.k.dma_in) {
+        switch (dv.nb) {
+            case 1: return launch<MB, 1, true>(dv, stream);
+            case 2: return launch<MB, 2, true>(dv, stream);
+            default: return launch<MB, 4, true>(dv, stream);
+        }
+    }
     switch (dv.nb) {
-        case 1: return launch<MB, 1>(dv, stream);
-        case 2: return launch<MB, 2>(dv, stream);
-        default: return launch<MB, 4>(dv, stream);
+        case 1: return launch<MB, 1, false>(dv, stream);
+        case 2: return launch<MB, 2, false>(dv, stream);
+        default: return launch<MB, 4, false>(dv, stream);
     }
 }
 

@@ -95,8 +95,10 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb):
                 tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
 
 
-def lds_bytes(geo, taps, cpad_total, mb, ck):
-    return 4 * (ck * geo["plane"] + taps * (min(ck, cpad_total) // 4) * mb * 64)
+def lds_bytes(geo, taps, cpads, mb, ck):
+    """Dynamic LDS of one workgroup: two pipeline buffers of (input tile + A fragments of the largest chunk)."""
+    ck_max = max(min(c, ck) for c in cpads)
+    return 2 * 4 * (ck * geo["plane"] + taps * (ck_max // 4) * mb * 64)
 
 
 TUNED = {}          # signature -> (mb, nb, split_k, ck); filled from tuned_schedules.json when present
@@ -118,7 +120,7 @@ def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, 
     return f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
 
 
-def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=64 * 1024):
+def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024):
     """All launchable (mb, nb, split_k, ck) for a conv, with the workgroup count of each."""
     cb = (cout + 15) // 16
     cpads = [(c + 3) // 4 * 4 for c in src_channels]
@@ -132,10 +134,10 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
             if mb > cb and mb != 1:
                 continue
             groups = math.ceil(cb / mb)
-            for ck in (16, 32, 64):
+            for ck in (8, 16, 32, 64):
                 if ck > 16 and ck // 2 >= max(cpads):
                     continue
-                if lds_bytes(geo, taps, sum(cpads), mb, ck) > lds_cap:
+                if lds_bytes(geo, taps, cpads, mb, ck) > lds_cap:
                     continue
                 nchunks = sum(math.ceil(c / ck) for c in cpads)
                 wgs = geo["tiles"] * groups * batch * phases
@@ -144,7 +146,7 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                         break
                     out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, wgs=wgs * sk, nchunks=nchunks,
                                     eff=geo["tile_eff"] * cb / (groups * mb),
-                                    lds=lds_bytes(geo, taps, sum(cpads), mb, ck)))
+                                    lds=lds_bytes(geo, taps, cpads, mb, ck)))
     return out
 
 
@@ -156,7 +158,7 @@ def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, pha
     if sig in TUNED:
         return TUNED[sig]
     best = None
-    for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=52 * 1024):
+    for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=80 * 1024):
         reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
         fill = min(1.0, c["wgs"] / 768.0)
         per_wg_steps = c["nchunks"] / c["split_k"]

@@ -33,6 +33,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MR_MAX_PPT 6   // tile positions staged per thread (ceil(IH*IW / 256))
+#define MR_MAX_G4 4    // 16-byte groups per lane per channel plane in the dwordx4 DMA path
 
 struct ConvKArgs {
     const float* src[MR_MAX_SOURCES];
@@ -57,6 +58,10 @@ struct ConvKArgs {
     int IH, IW, PLANE, CK, ppt;
     int wmax_floats;           // A-fragment floats of the largest chunk (per pipeline buffer)
     int dma_in;                // input tile staged by buffer_load ... lds (direct / upsample reads)
+    int dma_x4;                // ... as aligned 16-byte groups (direct reads, source width % 4 == 0)
+    int IWa;                   // LDS row pitch of the tile (IW, or the 4-aligned superset for dma_x4)
+    int g4pt;                  // 16-byte groups per lane per channel plane (dma_x4)
+    int xsh[4];                // per phase: columns between the aligned tile origin and the first tap column
     int ksplit, nchunks, batch, nphase;
     long long wgroup_stride;   // packed floats per cout group
     float* ws;
@@ -150,6 +155,12 @@ __device__ __forceinline__ void dma_buffer_dword(unsigned lds_byte_addr, int vof
                  "buffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
+__device__ __forceinline__ void dma_buffer_x4(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const float* g) {
     unsigned keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
@@ -197,7 +208,8 @@ template <int MB, bool DMA_IN>
 __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCursor& c, float* ldsI, float* ldsW,
                                             unsigned ldsI_addr, unsigned ldsW_addr,
                                             const float* wgrp, int b, int T, int lane, int wave, int HsWs,
-                                            const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT]) {
+                                            const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT],
+                                            const int (&voff4)[MR_MAX_G4]) {
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
     const int wfloats = T * (ck >> 2) * MB * 64;
     const float* wsrc = wgrp + c.woff;
@@ -208,7 +220,21 @@ __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCurso
 
     const int creal = a.src_c[c.s] - c.c0;                            // real (unpadded) channels left
     const int sbase_bytes = (b * a.src_c[c.s] + c.c0) * HsWs * 4;     // byte offset of channel c0 of sample b
-    if (DMA_IN) {
+    if (DMA_IN && a.dma_x4) {
+        // one buffer_load_dwordx4 ... lds = 64 lanes x 16 B = up to 256 consecutive floats of one channel plane;
+        // wave w streams channels w, w+4, ... of the chunk
+        const i32x4 srd = make_srd(a.src[c.s], a.src_bytes[c.s]);
+        for (int cc = wave; cc < ck; cc += 4) {
+            const unsigned lplane = ldsI_addr + cc * a.PLANE * 4;
+            const int so = sbase_bytes + cc * HsWs * 4;
+            const bool cok = cc < creal;
+#pragma unroll
+            for (int i = 0; i < MR_MAX_G4; ++i) {
+                if (i < a.g4pt && voff4[i] != -2)                      // -2: lane beyond the tile rows (EXEC off)
+                    dma_buffer_x4(lplane + i * 1024, cok ? voff4[i] : -1, srd, so);
+            }
+        }
+    } else if (DMA_IN) {
         const i32x4 srd = make_srd(a.src[c.s], a.src_bytes[c.s]);
 #pragma unroll
         for (int j = 0; j < MR_MAX_PPT; ++j) {
@@ -246,7 +272,7 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
     const float* wl = ldsW + lane;
     for (int kh = 0; kh < a.KH; ++kh) {
         for (int kw = 0; kw < a.KW; ++kw) {
-            const int tapoff = kh * a.IW + kw;
+            const int tapoff = kh * a.IWa + kw;
             const float* wt = wl + (kh * a.KW + kw) * ck4 * (MB * 64);
             int c4 = 0;
             for (; c4 + 4 <= ck4; c4 += 4) {          // manual 4x unroll: LDS reads of 4 k-steps overlap
@@ -286,12 +312,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 
     // ---- fixed staging positions of this thread: p = tid + 256*j  ->  (iy, ix) of the haloed tile ----
     int goff[MR_MAX_PPT], loff[MR_MAX_PPT];
-    const int P = a.IH * a.IW;
+    const int P = a.IH * a.IWa;
+    const int xsh = a.xsh[ph];
 #pragma unroll
     for (int j = 0; j < MR_MAX_PPT; ++j) {
         const int p = tid + 256 * j;
-        const int iy = p / a.IW, ix = p - iy * a.IW;
-        const int gy = iy_base + iy, gx = ix_base + ix;
+        const int iy = p / a.IWa, ix = p - iy * a.IWa;
+        const int gy = iy_base + iy, gx = ix_base - xsh + ix;
         loff[j] = p < P ? p : -1;
         bool inb = p < P && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
         int g = 0;
@@ -301,13 +328,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         goff[j] = inb ? g : -1;
     }
 
+    // dwordx4 DMA path: lane l owns the 16-byte groups r = l + 64*i of every channel plane
+    int voff4[MR_MAX_G4];
+    {
+        const int gpr = a.IWa >> 2;                       // groups per tile row
+#pragma unroll
+        for (int i = 0; i < MR_MAX_G4; ++i) {
+            const int r = lane + 64 * i;
+            const int iy = r / gpr, ix4 = r - iy * gpr;
+            const int gy = iy_base + iy, gx = ix_base - xsh + 4 * ix4;
+            const bool inb = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            voff4[i] = iy < a.IH ? (inb ? (gy * a.Ws + gx) * 4 : -1) : -2;
+        }
+    }
+
     int prow[NB], pcol[NB], lbase[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int pb = wave * NB + i;
         prow[i] = pb / a.TWB;
         pcol[i] = (pb % a.TWB) * 16 + (lane & 15);
-        lbase[i] = (lane >> 4) * a.PLANE + prow[i] * a.SH * a.IW + pcol[i] * a.SW;
+        lbase[i] = (lane >> 4) * a.PLANE + prow[i] * a.SH * a.IWa + pcol[i] * a.SW + xsh;
     }
 
     f32x4 acc[MB][NB];
@@ -324,7 +365,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     ChunkCursor cur = {0, 0, 0};
     for (int q = 0; q < q_lo; ++q) cursor_advance<MB>(a, cur, T);
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
-    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff);
+    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff, voff4);
     dma_wait_all();
     __syncthreads();
     int pb = 0;
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         cursor_advance<MB>(a, cur, T);
         if (q + 1 < q_hi) {
             const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
-            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff);
+            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff, voff4);
         }
         sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
         dma_wait_all();                                // this wave's share of the next chunk has landed
@@ -466,11 +507,27 @@ int derive(const mr_conv_desc* d, Derived* out) {
     const int tiles_y = mr_ceil_div(d->out_h, k.TH);
     k.IH = (k.TH - 1) * k.SH + k.KH;
     k.IW = (k.TWB * 16 - 1) * k.SW + k.KW;
-    int plane = k.IH * k.IW;
-    if (k.SW == 1) { while ((plane & 31) != 16) ++plane; } else { plane |= 1; }
+    k.dma_in = (d->in_mode != MR_IN_MAXPOOL2 && d->in_transform == MR_TF_NONE) ? 1 : 0;
+    // dwordx4 DMA needs 16-byte groups that are entirely inside or outside the image: tile origin rounded
+    // down to a multiple of 4 columns (tile x0 * stride is a multiple of 16), source width % 4 == 0
+    k.dma_x4 = (k.dma_in && d->in_mode == MR_IN_DIRECT && (k.Ws & 3) == 0) ? 1 : 0;
+    int xsh_max = 0;
+    for (int p = 0; p < nphase; ++p) {
+        k.xsh[p] = k.dma_x4 ? ((4 - (k.PL[p] & 3)) & 3) : 0;
+        if (k.xsh[p] > xsh_max) xsh_max = k.xsh[p];
+    }
+    k.IWa = k.dma_x4 ? ((xsh_max + k.IW + 3) & ~3) : k.IW;
+    int plane = k.IH * k.IWa;
+    if (k.SW == 1) { while ((plane & 31) != 16) ++plane; }
+    else if (k.dma_x4) { plane = (plane + 3) & ~3; }          // 16-byte rows win over the odd-stride bank trick
+    else { plane |= 1; }
     k.PLANE = plane;
-    k.ppt = mr_ceil_div(k.IH * k.IW, 256);
+    k.ppt = mr_ceil_div(k.IH * k.IWa, 256);
     if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED;
+    k.g4pt = mr_ceil_div(k.IH * (k.IWa >> 2), 64);
+    if (k.dma_x4 && k.g4pt > MR_MAX_G4) { k.dma_x4 = 0; k.IWa = k.IW; for (int p = 0; p < 4; ++p) k.xsh[p] = 0;
+        plane = k.IH * k.IW; if (k.SW == 1) { while ((plane & 31) != 16) ++plane; } else { plane |= 1; }
+        k.PLANE = plane; k.ppt = mr_ceil_div(k.IH * k.IW, 256); if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED; }
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
     const int taps = k.KH * k.KW;
     k.wgroup_stride = (long long)taps * (cpad_total / 4) * mb * 64;
@@ -480,7 +537,6 @@ int derive(const mr_conv_desc* d, Derived* out) {
         if (c > ck_max) ck_max = c;
     }
     k.wmax_floats = taps * (ck_max / 4) * mb * 64;
-    k.dma_in = (d->in_mode != MR_IN_MAXPOOL2 && d->in_transform == MR_TF_NONE) ? 1 : 0;
     out->lds_bytes = 2 * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);   // double buffered
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
     out->mb = mb; out->nb = nb;

@@ -84,6 +84,7 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb):
     twb = 2 if out_w >= 32 else 1
     th = 4 * nb // twb
     ih, iw = (th - 1) * sh + kh, (twb * 16 - 1) * sw + kw
+    iw = (iw + 3 + 3) // 4 * 4          # upper bound: 4-aligned superset used by the dwordx4 DMA path
     plane = ih * iw
     if sw == 1:
         while plane % 32 != 16:

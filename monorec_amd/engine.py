@@ -4,9 +4,11 @@ The plan owns every activation buffer (allocated once, HBM resident), the repack
 ordered list of C-ABI launches (include/monorec_hip.h).  It is the host-side replacement of the ATen
 call sequence inside `MonoRecModel.forward` (reference model/monorec/monorec_model.py:672-729):
 
-    stage "encoder" : ResnetEncoder.forward            (:118-129)   - independent of the poses
-    stage "main"    : CostVolumeModule (:193-271) -> MaskModule (:345-385) -> (1-mask)*cv (:713)
-                      -> DepthModule (:526-557) -> inverse-depth affine (:717)
+    stage "encoder" : ResnetEncoder.forward (:118-129)                 - independent of the poses
+    stage "cv"      : CostVolumeModule (:193-271) -> MaskModule encoder (:357-365)  - independent of the image features
+    stage "main"    : MaskModule decoder (:370-383) -> (1-mask)*cv (:713) -> DepthModule (:526-557) -> affine (:717)
+"encoder" and "cv" have no data dependence on each other, so MonoRecModel runs them on two HIP streams at the
+same time (at batch 1 neither fills the 256 CUs alone); "main" joins them.
 
 Because nothing in a stage allocates or synchronises, each stage can be recorded into a hipGraph
 (torch.cuda.CUDAGraph is the HIP graph API on ROCm) and replayed with ~10 us of host cost instead of
@@ -195,7 +197,7 @@ class Plan:
         self.sd = state
         self.buf = {}
         self.keep = []          # packed weights / biases (device tensors kept alive)
-        self.stages = {"encoder": [], "main": []}
+        self.stages = {"encoder": [], "cv": [], "main": []}
         self.conv_log = []      # (name, macs, mb, nb, split_k, wgs) for bench / tuning
         self._ws_floats = 0
         self._pending_ws = []
@@ -389,7 +391,7 @@ class Plan:
             feats.append(x)
 
         # ---------------- cost volume (monorec_model.py:193-271) ----------------
-        st = "main"
+        st = "cv"
         sfcv = self.alloc("sfcv", F, B, D, H, W)
         cv = self.alloc("cost_volume", B, D, H, W)
         frame_ptrs = (ctypes.c_void_p * F)(*[frames[f].data_ptr() for f in range(F)])
@@ -424,6 +426,7 @@ class Plan:
             self.add(st, f"mask.max{i}", run_max)
             cvf.append(m)
             x = xo
+        st = "main"
         x_srcs = [cvf[4], feats[3]]                                                  # :372
         for i in range(4):
             hi, wi = H >> (3 - i), W >> (3 - i)

@@ -229,6 +229,7 @@ class MonoRecModel(nn.Module):
         self._plans = {}
         self._graphs = {}
         self._side_stream = None
+        self._enc_stream = None
 
         self._feature_extractor = ResnetEncoder(num_layers=18, pretrained=True)
         if self.freeze_resnet:
@@ -310,7 +311,8 @@ class MonoRecModel(nn.Module):
         main = torch.cuda.current_stream(device)
         if self._side_stream is None or self._side_stream.device != device:
             self._side_stream = torch.cuda.Stream(device)
-        side = self._side_stream
+            self._enc_stream = torch.cuda.Stream(device)
+        side, enc = self._side_stream, self._enc_stream
         start_time = time.time()
 
         # 1. pose / intrinsics matrices -> pinned host memory on a side stream (tiny, overlaps the encoder)
@@ -322,11 +324,14 @@ class MonoRecModel(nn.Module):
             mats_done.record(side)
         mats.record_stream(side)
 
-        # 2. images into the plan's resident buffers + ResNet encoder stage (pose independent)
+        # 2. images into the plan's resident buffers; ResNet encoder stage (pose independent) on its own stream
         plan.buf["keyframe"].copy_(keyframe)
         for f in range(nf):
             plan.buf["frames"][f].copy_(frames[f])
-        self._run_stage(key, plan, "encoder", main)
+        enc.wait_stream(main)
+        self._run_stage(key, plan, "encoder", enc)
+        enc_done = torch.cuda.Event()
+        enc_done.record(enc)
 
         # 3. host 4x4 algebra while the encoder runs, then upload
         mats_done.synchronize()
@@ -336,7 +341,9 @@ class MonoRecModel(nn.Module):
         plan.host_geom[b * 9:].copy_(proj.reshape(-1))
         plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
 
-        # 4. cost volume -> mask -> depth
+        # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
+        self._run_stage(key, plan, "cv", main)
+        main.wait_event(enc_done)
         self._run_stage(key, plan, "main", main)
         data_dict["cv_module_time"] = keyframe.new_tensor([time.time() - start_time])
 
@@ -350,6 +357,7 @@ class MonoRecModel(nn.Module):
         return data_dict
 
     def _run_stage(self, key, plan, stage, stream):
+        """Run one stage of the plan on `stream`: eagerly, or (hip_graph) as a captured hipGraph replay."""
         if not self._hip_graph:
             plan.run_stage(stage, stream.cuda_stream)
             return
@@ -369,7 +377,8 @@ class MonoRecModel(nn.Module):
             stream.wait_stream(cap)
             self._graphs[gkey] = graph
             entry = graph
-        entry.replay()
+        with torch.cuda.stream(stream):
+            entry.replay()
 
 
 def _filter_state_dict(state_dict, data_parallel=False):

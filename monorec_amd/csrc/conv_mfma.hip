@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/monorec_hip.h"
 #include "conv_layout.h"
@@ -62,6 +63,7 @@ struct ConvKArgs {
     int IWa;                   // LDS row pitch of the tile (IW, or the 4-aligned superset for dma_x4)
     int g4pt;                  // 16-byte groups per lane per channel plane (dma_x4)
     int xsh[4];                // per phase: columns between the aligned tile origin and the first tap column
+    int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores
     int ksplit, nchunks, batch, nphase;
     long long wgroup_stride;   // packed floats per cout group
     float* ws;
@@ -213,13 +215,14 @@ __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCurso
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
     const int wfloats = T * (ck >> 2) * MB * 64;
     const float* wsrc = wgrp + c.woff;
-    const int n1k = wfloats >> 8;                     // 1 KiB pieces (64 lanes x 16 B)
+    const int n1k = (a.dbg & 4) ? 0 : wfloats >> 8;   // 1 KiB pieces (64 lanes x 16 B)
     for (int kb = wave; kb < n1k; kb += 4) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
-    const int nfrag = wfloats >> 6;                   // tail: 256 B pieces (64 lanes x 4 B)
+    const int nfrag = (a.dbg & 4) ? 0 : wfloats >> 6; // tail: 256 B pieces (64 lanes x 4 B)
     for (int fr = (n1k << 2) + wave; fr < nfrag; fr += 4) dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane);
 
     const int creal = a.src_c[c.s] - c.c0;                            // real (unpadded) channels left
     const int sbase_bytes = (b * a.src_c[c.s] + c.c0) * HsWs * 4;     // byte offset of channel c0 of sample b
+    if (a.dbg & 2) return;
     if (DMA_IN && a.dma_x4) {
         // one buffer_load_dwordx4 ... lds = 64 lanes x 16 B = up to 256 consecutive floats of one channel plane;
         // wave w streams channels w, w+4, ... of the chunk
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
             const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
             issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff, voff4);
         }
-        sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
+        if (!(a.dbg & 1)) sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
         dma_wait_all();                                // this wave's share of the next chunk has landed
         __syncthreads();                               // ... everyone's has, and everyone is done with this buffer
         pb ^= 1;
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 
     // ---- epilogue: D fragment lane l holds pixel (l&15), couts (l>>4)*4 + r ---------------------
     const int CB16 = a.CB * 16;
+    if (a.dbg & 8) { if (acc[0][0][0] != 123.456f) return; }
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -539,6 +543,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.wmax_floats = taps * (ck_max / 4) * mb * 64;
     out->lds_bytes = 2 * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);   // double buffered
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
+    { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb;
     out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)mr_ceil_div(k.CB, mb),
                      (unsigned)(d->batch * d->split_k * nphase));

@@ -321,6 +321,26 @@ class Plan:
         return self.conv(stage, name, srcs, w, self.sd[bkey] if bkey else None, out, stride=stride, pad=(pt, pl),
                          grid=grid, act=act, p0=p0, p1=p1, in_mode=in_mode)
 
+    def one_out_conv(self, stage, name, src, wkey, bkey, out, *, act, p0=0.0, p1=0.0):
+        """PadSameConv2d + Conv2d(c, 1, k) (+ activation) on the VALU kernel mr_conv2d_one_out_f32 (heads, classifier)."""
+        w = self._dev(self.sd[wkey])
+        b = self._dev(self.sd[bkey]) if bkey else None
+        n, cin, h, wd = src.shape
+        assert w.shape[0] == 1 and w.shape[1] == cin and out.shape == (n, 1, h, wd)
+        kh, kw = w.shape[2], w.shape[3]
+        pt, _ = same_pad(h, kh, 1)
+        pl, _ = same_pad(wd, kw, 1)
+        lib = self.lib
+        self.keep += [src, out]
+
+        def run(stream):
+            _lib.check(lib.mr_conv2d_one_out_f32(src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                                 out.data_ptr(), n, cin, h, wd, kh, kw, pt, pl, act, p0, p1, stream), name)
+        self.conv_log.append(dict(name=name, macs=n * h * wd * cin * kh * kw, mb=0, nb=0, split_k=1, ck=0, wgs=0, lds=0,
+                                  cout=1, cin=cin, k=(kh, kw), out=(h, wd), batch=n, phases=1, sig=None, spec=None))
+        self.add(stage, name, run)
+        return out
+
     def conv_relu2(self, stage, name, srcs, prefix, mid, out, stride=1):
         """layers.ConvReLU2 (model/layers.py:308-314): k x 1 stride (s,1), then 1 x k stride (1,s)."""
         self.same_conv(stage, name + ".conv_y", srcs, prefix + ".conv_y.weight", prefix + ".conv_y.bias", mid,
@@ -357,8 +377,14 @@ class Plan:
         st = "encoder"
         w, b = fold_batchnorm(sd[enc + ".conv1.weight"], sd, enc + ".bn1")
         f0 = self.alloc("feat0", B, 64, H // 2, W // 2)
-        self.conv(st, "resnet.conv1", [kf], w, b, f0, stride=(2, 2), pad=(3, 3), grid=(H // 2, W // 2),
-                  act=ACT_RELU, tf=TF_RESNET_NORM)
+        # input normalisation as its own 3 us pass so that the stem runs on the DMA-staged conv path
+        kfn = self.alloc("keyframe_norm", B, 3, H, W)
+
+        def run_norm(stream, src=kf, dst=kfn):
+            _lib.check(lib.mr_resnet_normalize_f32(src.data_ptr(), dst.data_ptr(), B * 3 * H * W, stream),
+                       "mr_resnet_normalize_f32")
+        self.add(st, "resnet.normalize", run_norm)
+        self.conv(st, "resnet.conv1", [kfn], w, b, f0, stride=(2, 2), pad=(3, 3), grid=(H // 2, W // 2), act=ACT_RELU)
         pool = self.alloc("resnet.pool", B, 64, H // 4, W // 4)
 
         def run_pool(stream, src=f0, dst=pool):
@@ -415,8 +441,15 @@ class Plan:
             i0, i1 = (0, 1) if i == 0 else (1, 2)       # index 0 of stages 1-4 is the MaxPool
             a = self.alloc(f"mask.enc{i}.a", F * B, enc_ch[i], hi, wi)
             xo = self.alloc(f"mask.enc{i}.x", F * B, enc_ch[i], hi, wi)
-            self.same_conv(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a,
-                           in_mode=IN_DIRECT if i == 0 else IN_MAXPOOL2)
+            if i > 0:      # nn.MaxPool2d(2) as its own HBM-bound pass; the conv then stages by LDS-DMA
+                xp = self.alloc(f"mask.enc{i}.pool", F * B, enc_ch[i - 1], hi, wi)
+
+                def run_pool2(stream, src=x, dst=xp, planes=F * B * enc_ch[i - 1], hh_=2 * hi, ww_=2 * wi):
+                    _lib.check(lib.mr_maxpool2x2_f32(src.data_ptr(), dst.data_ptr(), planes, hh_, ww_, stream),
+                               "mr_maxpool2x2_f32")
+                self.add(st, f"mask.pool{i}", run_pool2)
+                x = xp
+            self.same_conv(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a)
             self.same_conv(st, f"mask.enc{i}.1", [a], f"{am}.enc.{i}.{i1}.conv.weight", f"{am}.enc.{i}.{i1}.conv.bias", xo)
             m = self.alloc(f"mask.cvf{i}", B, enc_ch[i], hi, wi)
 
@@ -442,8 +475,8 @@ class Plan:
             self.same_conv(st, f"mask.dec{i}.2", [a], f"{am}.dec.{i}.2.conv.weight", f"{am}.dec.{i}.2.conv.bias", xo)
             x_srcs = [xo]
         cv_mask = self.alloc("cv_mask", B, 1, H, W)
-        self.same_conv(st, "mask.classifier", x_srcs, f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
-                       act=ACT_SIGMOID)
+        self.one_out_conv(st, "mask.classifier", x_srcs[0], f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
+                          act=ACT_SIGMOID)
 
         def run_mask(stream):                                                        # :713 (in place)
             _lib.check(lib.mr_apply_mask_f32(cv.data_ptr(), cv_mask.data_ptr(), cv.data_ptr(), B, D, H * W, stream),
@@ -472,8 +505,8 @@ class Plan:
         def head(idx, src, scale_slot):
             hh_, ww_ = src.shape[2], src.shape[3]
             p = self.alloc(f"pred{scale_slot}", B, 1, hh_, ww_)
-            self.same_conv(st, f"depth.head{idx}", [src], f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
-                           p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)                # :556 + :717
+            self.one_out_conv(st, f"depth.head{idx}", src, f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
+                              p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)             # :556 + :717
             preds[scale_slot] = p
 
         r0 = self.alloc("depth.dec0", B, 256, H // 8, W // 8)

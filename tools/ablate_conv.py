@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     names = sys.argv[2].split(",")
     res = {}
     for c in plan.conv_log:
-        if c["name"] not in names: continue
+        if c["name"] not in names or c["spec"] is None: continue
         spec = c["spec"]; cout, cin, kh, kw = spec["w_shape"]
         nph = 1 if spec["phases"] is None else len(spec["phases"])
         srcs = [torch.randn(*s, generator=g).cuda() for s in spec["src_shapes"]]
@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         res[c["name"]] = time_op(fn, reps=20, warm=3) * 1e6
     print("RESULT " + json.dumps(res))
 else:
-    names = "depth.head3,mask.classifier,mask.enc0.0,mask.dec3.1,resnet.l1b0.conv1,depth.enc2.1.conv_y,resnet.l4b0.conv2,depth.dec2.0"
+    names = "mask.enc0.0,mask.dec3.1,resnet.l1b0.conv1,depth.enc2.1.conv_y,resnet.l4b0.conv2,depth.dec2.0"
     table = {}
     for dbg in (0, 1, 2, 4, 8, 3, 7, 15):
         env = dict(os.environ, MR_CONV_DBG=str(dbg))

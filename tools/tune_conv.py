@@ -73,7 +73,7 @@ def main():
     seen = set()
     g = torch.Generator().manual_seed(0)
     for c in plan.conv_log:
-        if c["sig"] in seen:
+        if c["sig"] is None or c["sig"] in seen:
             continue
         seen.add(c["sig"])
         spec = c["spec"]

@@ -148,15 +148,6 @@ int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the torchvision ResNet stem (monorec_model.py:124) */
 int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in_h, int32_t in_w, void* stream);
 
-/* Stride-1 convolution with ONE output channel + bias + activation: the four depth heads
- * (PadSameConv2d + Conv2d(c,1,3) + abs(tanh) + inverse-depth affine, monorec_model.py:521-524,554-557,717) and the
- * mask classifier (Conv2d(48,1,1) + Sigmoid, :340-343).  weight: (1, in_channels, kh, kw) plain nn.Conv2d layout
- * on the device; src (batch,in_channels,H,W); dst (batch,1,H,W); zero padding pad_top/pad_left (+ implied bottom/right). */
-int mr_conv2d_one_out_f32(const float* src, const float* weight, const float* bias, float* dst, int32_t batch,
-                          int32_t in_channels, int32_t height, int32_t width, int32_t kh, int32_t kw,
-                          int32_t pad_top, int32_t pad_left, int32_t activation, float act_p0, float act_p1,
-                          void* stream);
-
 /* nn.MaxPool2d(2) between the MaskModule encoder stages (monorec_model.py:304-316). in_h even, in_w % 4 == 0.
  * (mr_conv2d_f32 can also pool while staging - MR_IN_MAXPOOL2 - but the separate pass + DMA-staged conv is
  * faster on MI355X.) */

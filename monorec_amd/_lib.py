@@ -69,10 +69,6 @@ ABI = {
                                           ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "mr_maxpool3x3s2_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_void_p]),
-    "mr_conv2d_one_out_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                                             ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mr_maxpool2x2_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_void_p]),
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

@@ -88,58 +88,6 @@ __global__ __launch_bounds__(256) void resnet_normalize_kernel(const float4* __r
     }
 }
 
-__device__ __forceinline__ float few_out_activate(float v, int act, float p0, float p1) {
-    switch (act) {
-        case MR_ACT_RELU: return v > 0.f ? v : 0.f;
-        case MR_ACT_LEAKY_RELU: return v > 0.f ? v : v * p0;
-        case MR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case MR_ACT_ABS_TANH_AFFINE: { const float t = fabsf(tanhf(v)); return (1.f - t) * p0 + t * p1; }
-        default: return v;
-    }
-}
-
-// Convolution with ONE output channel (the four depth heads, monorec_model.py:521-524,554-557, and the mask
-// classifier, :340-343): a 16x16 MFMA tile would be 15/16 padding, so this is a plain VALU dot product.
-// Workgroup = TILE x TILE pixels x CG channel groups (CG*TILE*TILE == 256); group g walks channels g, g+CG, ...
-// as an fmaf chain (weights are wave-uniform -> scalar loads), groups are combined through LDS.
-template <int TILE, int CG>
-__global__ __launch_bounds__(256) void conv_one_out_kernel(const float* __restrict__ src, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ dst,
-                                                           int cin, int H, int W, int KH, int KW, int PT, int PL,
-                                                           int act, float p0, float p1) {
-    __shared__ float part[CG][TILE * TILE];
-    const int tid = threadIdx.x;
-    const int g = __builtin_amdgcn_readfirstlane(tid / (TILE * TILE));
-    const int pix = tid % (TILE * TILE);
-    const int oy = blockIdx.y * TILE + pix / TILE, ox = blockIdx.x * TILE + pix % TILE;
-    const float* sb = src + (long long)blockIdx.z * cin * H * W;
-    float acc = 0.f;
-    for (int c = g; c < cin; c += CG) {
-        const float* plane = sb + (long long)c * H * W;
-        const float* wc = w + c * KH * KW;
-        for (int ky = 0; ky < KH; ++ky) {
-            const int y = oy - PT + ky;
-            for (int kx = 0; kx < KW; ++kx) {
-                const int x = ox - PL + kx;
-                float v = 0.f;
-                if (y >= 0 && y < H && x >= 0 && x < W) v = plane[y * W + x];
-                acc = fmaf(v, wc[ky * KW + kx], acc);
-            }
-        }
-    }
-    if (CG > 1) {
-        part[g][pix] = acc;
-        __syncthreads();
-        if (g != 0) return;
-#pragma unroll
-        for (int k = 1; k < CG; ++k) acc += part[k][pix];
-    }
-    if (oy < H && ox < W) {
-        if (bias) acc += bias[0];
-        dst[((long long)blockIdx.z * H + oy) * W + ox] = few_out_activate(acc, act, p0, p1);
-    }
-}
-
 inline unsigned grid_for(long long work_items) {
     long long blocks = (work_items + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -168,23 +116,6 @@ extern "C" int mr_resnet_normalize_f32(const float* src, float* dst, int64_t cou
     if (!src || !dst || count < 4 || (count & 3)) return MR_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(resnet_normalize_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)src, (float4*)dst, (long long)(count / 4));
-    return (int)hipGetLastError();
-}
-
-extern "C" int mr_conv2d_one_out_f32(const float* src, const float* weight, const float* bias, float* dst, int32_t batch,
-                                     int32_t in_channels, int32_t height, int32_t width, int32_t kh, int32_t kw,
-                                     int32_t pad_top, int32_t pad_left, int32_t activation, float act_p0, float act_p1,
-                                     void* stream) {
-    if (!src || !weight || !dst || batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1)
-        return MR_ERR_BAD_ARGUMENT;
-    hipStream_t st = (hipStream_t)stream;
-    if ((long long)height * width >= 32768) {   // enough pixels to fill the chip with 16x16 tiles
-        hipLaunchKernelGGL((conv_one_out_kernel<16, 1>), dim3((width + 15) / 16, (height + 15) / 16, batch), dim3(256), 0, st,
-                           src, weight, bias, dst, in_channels, height, width, kh, kw, pad_top, pad_left, activation, act_p0, act_p1);
-    } else {                                     // small planes: 8x8 tiles, channels split over the 4 waves
-        hipLaunchKernelGGL((conv_one_out_kernel<8, 4>), dim3((width + 7) / 8, (height + 7) / 8, batch), dim3(256), 0, st,
-                           src, weight, bias, dst, in_channels, height, width, kh, kw, pad_top, pad_left, activation, act_p0, act_p1);
-    }
     return (int)hipGetLastError();
 }
 

@@ -199,8 +199,8 @@ class Plan:
         self.keep = []          # packed weights / biases (device tensors kept alive)
         self.stages = {"encoder": [], "cv": [], "main": []}
         self.conv_log = []      # (name, macs, mb, nb, split_k, wgs) for bench / tuning
-        self._ws_floats = 0
-        self._pending_ws = []
+        self._ws_floats = {}      # stage -> floats: stages may run concurrently on different streams,
+        self._pending_ws = []     # so every stage gets its own split-K workspace
         if build:
             self._build()
             self.finalize()
@@ -212,11 +212,12 @@ class Plan:
 
     def finalize(self):
         """Allocate the shared split-K workspace once all launches are known."""
-        ws = torch.empty(max(self._ws_floats, 4), dtype=torch.float32, device=self.device)
-        self.buf["splitk_workspace"] = ws
-        for desc in self._pending_ws:
-            desc.workspace = ws.data_ptr()
+        for stage, floats in self._ws_floats.items():
+            self.buf[f"splitk_workspace.{stage}"] = torch.empty(max(floats, 4), dtype=torch.float32, device=self.device)
+        for stage, desc in self._pending_ws:
+            desc.workspace = self.buf[f"splitk_workspace.{stage}"].data_ptr()
         self._pending_ws = []
+        self._ws_floats = {}
 
     # ------------------------------------------------------------------ buffers / parameters
     def alloc(self, name, *shape):
@@ -282,8 +283,9 @@ class Plan:
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
         if split_k > 1:
-            self._ws_floats = max(self._ws_floats, split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
-            self._pending_ws.append(d)
+            self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
+                                         split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
+            self._pending_ws.append((stage, d))
             d.workspace = 1  # placeholder (non-null) until the shared workspace exists
         lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
         if lds < 0:
@@ -320,26 +322,6 @@ class Plan:
         grid = (math.ceil(hin / stride[0]), math.ceil(win / stride[1]))
         return self.conv(stage, name, srcs, w, self.sd[bkey] if bkey else None, out, stride=stride, pad=(pt, pl),
                          grid=grid, act=act, p0=p0, p1=p1, in_mode=in_mode)
-
-    def one_out_conv(self, stage, name, src, wkey, bkey, out, *, act, p0=0.0, p1=0.0):
-        """PadSameConv2d + Conv2d(c, 1, k) (+ activation) on the VALU kernel mr_conv2d_one_out_f32 (heads, classifier)."""
-        w = self._dev(self.sd[wkey])
-        b = self._dev(self.sd[bkey]) if bkey else None
-        n, cin, h, wd = src.shape
-        assert w.shape[0] == 1 and w.shape[1] == cin and out.shape == (n, 1, h, wd)
-        kh, kw = w.shape[2], w.shape[3]
-        pt, _ = same_pad(h, kh, 1)
-        pl, _ = same_pad(wd, kw, 1)
-        lib = self.lib
-        self.keep += [src, out]
-
-        def run(stream):
-            _lib.check(lib.mr_conv2d_one_out_f32(src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
-                                                 out.data_ptr(), n, cin, h, wd, kh, kw, pt, pl, act, p0, p1, stream), name)
-        self.conv_log.append(dict(name=name, macs=n * h * wd * cin * kh * kw, mb=0, nb=0, split_k=1, ck=0, wgs=0, lds=0,
-                                  cout=1, cin=cin, k=(kh, kw), out=(h, wd), batch=n, phases=1, sig=None, spec=None))
-        self.add(stage, name, run)
-        return out
 
     def conv_relu2(self, stage, name, srcs, prefix, mid, out, stride=1):
         """layers.ConvReLU2 (model/layers.py:308-314): k x 1 stride (s,1), then 1 x k stride (1,s)."""
@@ -475,8 +457,8 @@ class Plan:
             self.same_conv(st, f"mask.dec{i}.2", [a], f"{am}.dec.{i}.2.conv.weight", f"{am}.dec.{i}.2.conv.bias", xo)
             x_srcs = [xo]
         cv_mask = self.alloc("cv_mask", B, 1, H, W)
-        self.one_out_conv(st, "mask.classifier", x_srcs[0], f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
-                          act=ACT_SIGMOID)
+        self.same_conv(st, "mask.classifier", x_srcs, f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
+                       act=ACT_SIGMOID)
 
         def run_mask(stream):                                                        # :713 (in place)
             _lib.check(lib.mr_apply_mask_f32(cv.data_ptr(), cv_mask.data_ptr(), cv.data_ptr(), B, D, H * W, stream),
@@ -505,8 +487,8 @@ class Plan:
         def head(idx, src, scale_slot):
             hh_, ww_ = src.shape[2], src.shape[3]
             p = self.alloc(f"pred{scale_slot}", B, 1, hh_, ww_)
-            self.one_out_conv(st, f"depth.head{idx}", src, f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
-                              p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)             # :556 + :717
+            self.same_conv(st, f"depth.head{idx}", [src], f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
+                           p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)                # :556 + :717
             preds[scale_slot] = p
 
         r0 = self.alloc("depth.dec0", B, 256, H // 8, W // 8)

@@ -136,23 +136,6 @@ def test_refine_transposed_conv(hip_lib, sched):
     assert (out.cpu() - ref).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("cin,k,hw,act", [(24, 3, (64, 96), ACT_ABS_TANH_AFFINE), (256, 3, (8, 16), ACT_ABS_TANH_AFFINE),
-                                          (48, 1, (256, 512), ACT_SIGMOID), (64, 3, (20, 28), ACT_NONE)])
-def test_one_output_channel_conv(hip_lib, cin, k, hw, act):
-    g = torch.Generator().manual_seed(cin + k)
-    x = torch.randn(2, cin, *hw, generator=g)
-    w = torch.randn(1, cin, k, k, generator=g) / math.sqrt(cin * k * k)
-    b = torch.randn(1, generator=g)
-    ref = _act_ref(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2).float(), act, 0.0025, 0.33)
-    sd = {"h.weight": w, "h.bias": b}
-    plan = engine.Plan.bare(DEV, state=sd)
-    out = plan.alloc("out", 2, 1, *hw)
-    out.fill_(float("nan"))
-    plan.one_out_conv("main", "h", x.to(DEV), "h.weight", "h.bias", out, act=act, p0=0.0025, p1=0.33)
-    _run(plan)
-    assert (out.cpu() - ref).abs().max().item() < 1e-5
-
-
 def test_small_kernels(hip_lib):
     lib = hip_lib
     g = torch.Generator().manual_seed(5)

@@ -63,6 +63,8 @@ struct ConvKArgs {
     int IWa;                   // LDS row pitch of the tile (IW, or the 4-aligned superset for dma_x4)
     int g4pt;                  // 16-byte groups per lane per channel plane (dma_x4)
     int xsh[4];                // per phase: columns between the aligned tile origin and the first tap column
+    unsigned gpr_magic;        // floor(r / (IWa/4)) == (r * gpr_magic) >> 16 for r < 256 (dma_x4 prologue)
+    unsigned tiles_x_magic;    // floor(t / tiles_x) == (t * tiles_x_magic) >> 32 for t < 2^16
     int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores
     int ksplit, nchunks, batch, nphase;
     long long wgroup_stride;   // packed floats per cout group
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int ty = (int)(((unsigned long long)(unsigned)tile * a.tiles_x_magic) >> 32);   // tile / tiles_x
+    const int tx = tile - ty * a.tiles_x;
     const int grp = blockIdx.y;
     const int cb0 = grp * MB;
     int z = blockIdx.z;
@@ -318,17 +321,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     const int P = a.IH * a.IWa;
     const int xsh = a.xsh[ph];
 #pragma unroll
-    for (int j = 0; j < MR_MAX_PPT; ++j) {
-        const int p = tid + 256 * j;
-        const int iy = p / a.IWa, ix = p - iy * a.IWa;
-        const int gy = iy_base + iy, gx = ix_base - xsh + ix;
-        loff[j] = p < P ? p : -1;
-        bool inb = p < P && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        int g = 0;
-        if (a.in_mode == MR_IN_DIRECT) g = gy * a.Ws + gx;
-        else if (a.in_mode == MR_IN_UPSAMPLE2) g = (gy >> 1) * a.Ws + (gx >> 1);
-        else g = (2 * gy) * a.Ws + 2 * gx;
-        goff[j] = inb ? g : -1;
+    for (int j = 0; j < MR_MAX_PPT; ++j) { goff[j] = -1; loff[j] = -1; }
+    if (!a.dma_x4) {                                  // dword-DMA / register staging only
+#pragma unroll
+        for (int j = 0; j < MR_MAX_PPT; ++j) {
+            const int p = tid + 256 * j;
+            const int iy = p / a.IWa, ix = p - iy * a.IWa;
+            const int gy = iy_base + iy, gx = ix_base - xsh + ix;
+            loff[j] = p < P ? p : -1;
+            bool inb = p < P && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            int g = 0;
+            if (a.in_mode == MR_IN_DIRECT) g = gy * a.Ws + gx;
+            else if (a.in_mode == MR_IN_UPSAMPLE2) g = (gy >> 1) * a.Ws + (gx >> 1);
+            else g = (2 * gy) * a.Ws + 2 * gx;
+            goff[j] = inb ? g : -1;
+        }
     }
 
     // dwordx4 DMA path: lane l owns the 16-byte groups r = l + 64*i of every channel plane
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int i = 0; i < MR_MAX_G4; ++i) {
             const int r = lane + 64 * i;
-            const int iy = r / gpr, ix4 = r - iy * gpr;
+            const int iy = (int)(((unsigned)r * a.gpr_magic) >> 16), ix4 = r - iy * gpr;   // r / gpr, r < 256
             const int gy = iy_base + iy, gx = ix_base - xsh + 4 * ix4;
             const bool inb = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
             voff4[i] = iy < a.IH ? (inb ? (gy * a.Ws + gx) * 4 : -1) : -2;
@@ -349,8 +356,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int pb = wave * NB + i;
-        prow[i] = pb / a.TWB;
-        pcol[i] = (pb % a.TWB) * 16 + (lane & 15);
+        prow[i] = a.TWB == 2 ? pb >> 1 : pb;
+        pcol[i] = (a.TWB == 2 ? (pb & 1) : 0) * 16 + (lane & 15);
         lbase[i] = (lane >> 4) * a.PLANE + prow[i] * a.SH * a.IWa + pcol[i] * a.SW + xsh;
     }
 
@@ -543,6 +550,9 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.wmax_floats = taps * (ck_max / 4) * mb * 64;
     out->lds_bytes = 2 * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);   // double buffered
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
+    k.gpr_magic = 65536u / (unsigned)(k.IWa >> 2 > 0 ? k.IWa >> 2 : 1) + 1u;
+    k.tiles_x_magic = (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;
+    if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb;
     out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)mr_ceil_div(k.CB, mb),

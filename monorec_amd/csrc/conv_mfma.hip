@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
-    const int ty = (int)(((unsigned long long)(unsigned)tile * a.tiles_x_magic) >> 32);   // tile / tiles_x
+    const int ty = a.tiles_x == 1 ? tile : (int)(((unsigned long long)(unsigned)tile * a.tiles_x_magic) >> 32);   // tile / tiles_x
     const int tx = tile - ty * a.tiles_x;
     const int grp = blockIdx.y;
     const int cb0 = grp * MB;
@@ -551,7 +551,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     out->lds_bytes = 2 * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);   // double buffered
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
     k.gpr_magic = 65536u / (unsigned)(k.IWa >> 2 > 0 ? k.IWa >> 2 : 1) + 1u;
-    k.tiles_x_magic = (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;
+    k.tiles_x_magic = k.tiles_x == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;   // (1 would overflow)
     if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb;

@@ -193,7 +193,7 @@ class MonoRecModel(nn.Module):
                  pretrain_dropout_mode=0, augmentation=None, use_mono=True, use_stereo=False, use_ssim=True,
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
-                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=True):
+                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=True, hip_in_flight=2):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -226,10 +226,12 @@ class MonoRecModel(nn.Module):
                 "monorec_amd implements the default inference configuration of the reference only; "
                 f"unsupported non-default options: {bad} (SURVEY.md section 8 f-4)")
         self._hip_graph = bool(hip_graph)
+        self._in_flight = max(1, int(hip_in_flight))
+        self._next_slot = 0
         self._plans = {}
         self._graphs = {}
-        self._side_stream = None
-        self._enc_stream = None
+        self._streams = {}
+        self._packed_state = None
 
         self._feature_extractor = ResnetEncoder(num_layers=18, pretrained=True)
         if self.freeze_resnet:
@@ -268,17 +270,26 @@ class MonoRecModel(nn.Module):
     def _invalidate(self):
         self._plans = {}
         self._graphs = {}
+        self._packed_state = None
 
     def _apply(self, fn, *a, **k):   # .to() / .cuda(): parameters moved or cast -> repack
         self._invalidate()
         return super()._apply(fn, *a, **k)
 
-    def _plan_for(self, batch, h, w, nf, device):
-        key = (batch, h, w, nf, self.cv_depth_steps, str(device))
+    def _slot_streams(self, slot, device):
+        st = self._streams.get((slot, str(device)))
+        if st is None:
+            st = {n: torch.cuda.Stream(device) for n in ("main", "enc", "side")}
+            self._streams[(slot, str(device))] = st
+        return st
+
+    def _plan_for(self, slot, batch, h, w, nf, device):
+        key = (slot, batch, h, w, nf, self.cv_depth_steps, str(device))
         plan = self._plans.get(key)
         if plan is None:
-            state = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
-            plan = Plan(state, batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
+            if self._packed_state is None or self._packed_state[0] != str(device):
+                self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
+            plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
@@ -288,6 +299,20 @@ class MonoRecModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, data_dict):
+        """Reference contract (monorec_model.py:672-729): fills and returns `data_dict`; the outputs are ordered
+        on the caller's current stream like any PyTorch op.  Equivalent to `self.submit(data_dict).result()`."""
+        return self.submit(data_dict).result()
+
+    def submit(self, data_dict):
+        """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
+        wait for it.  Keyframes are independent, so a stream of keyframes is served with `hip_in_flight` (default 2)
+        of them on the GPU at once - on separate HIP streams and resident buffers - which fills the launch
+        head/tail bubbles that a single batch-1 keyframe leaves on 256 CUs:
+
+            pending.append(model.submit(batch));  out = pending.popleft().result() once len(pending) == hip_in_flight
+
+        The inputs must stay unmodified until `.result()`; outputs are views of the slot's resident buffers and stay
+        valid until that slot is reused (`hip_in_flight` submits later)."""
         if self.training:
             raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
         keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
@@ -307,44 +332,52 @@ class MonoRecModel(nn.Module):
         data_dict["inv_depth_max"] = keyframe.new_tensor([self.inv_depth_min_max[1]])
         data_dict["cv_depth_steps"] = keyframe.new_tensor([self.cv_depth_steps], dtype=torch.int32)
 
-        key, plan = self._plan_for(b, h, w, nf, device)
-        main = torch.cuda.current_stream(device)
-        if self._side_stream is None or self._side_stream.device != device:
-            self._side_stream = torch.cuda.Stream(device)
-            self._enc_stream = torch.cuda.Stream(device)
-        side, enc = self._side_stream, self._enc_stream
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self._in_flight
+        key, plan = self._plan_for(slot, b, h, w, nf, device)
+        streams = self._slot_streams(slot, device)
+        main, enc, side = streams["main"], streams["enc"], streams["side"]
+        caller = torch.cuda.current_stream(device)
         start_time = time.time()
 
-        # 1. pose / intrinsics matrices -> pinned host memory on a side stream (tiny, overlaps the encoder)
-        mats = torch.stack([kf_intrinsics, kf_pose] + intrinsics + poses).float()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            plan.host_mats.copy_(mats, non_blocking=True)
-            mats_done = torch.cuda.Event()
-            mats_done.record(side)
-        mats.record_stream(side)
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(caller)
+        main.wait_event(inputs_ready)
+        with torch.cuda.stream(main):
+            # 1. pose / intrinsics matrices -> pinned host memory on a side stream (tiny, overlaps the encoder)
+            mats = torch.stack([kf_intrinsics, kf_pose] + intrinsics + poses).float()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                plan.host_mats.copy_(mats, non_blocking=True)
+                mats_done = torch.cuda.Event()
+                mats_done.record(side)
+            mats.record_stream(side)
 
-        # 2. images into the plan's resident buffers; ResNet encoder stage (pose independent) on its own stream
-        plan.buf["keyframe"].copy_(keyframe)
-        for f in range(nf):
-            plan.buf["frames"][f].copy_(frames[f])
-        enc.wait_stream(main)
-        self._run_stage(key, plan, "encoder", enc)
-        enc_done = torch.cuda.Event()
-        enc_done.record(enc)
+            # 2. images into the slot's resident buffers; ResNet encoder stage (pose independent) on its own stream
+            plan.buf["keyframe"].copy_(keyframe)
+            for f in range(nf):
+                plan.buf["frames"][f].copy_(frames[f])
+            for t in [keyframe] + frames:
+                t.record_stream(main)
+            enc.wait_stream(main)
+            self._run_stage(key, plan, "encoder", enc)
+            enc_done = torch.cuda.Event()
+            enc_done.record(enc)
 
-        # 3. host 4x4 algebra while the encoder runs, then upload
-        mats_done.synchronize()
-        hm = plan.host_mats
-        kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
-        plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
-        plan.host_geom[b * 9:].copy_(proj.reshape(-1))
-        plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
+            # 3. host 4x4 algebra while the encoder runs, then upload
+            mats_done.synchronize()
+            hm = plan.host_mats
+            kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+            plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
+            plan.host_geom[b * 9:].copy_(proj.reshape(-1))
+            plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
 
-        # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
-        self._run_stage(key, plan, "cv", main)
-        main.wait_event(enc_done)
-        self._run_stage(key, plan, "main", main)
+            # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
+            self._run_stage(key, plan, "cv", main)
+            main.wait_event(enc_done)
+            self._run_stage(key, plan, "main", main)
+            done = torch.cuda.Event()
+            done.record(main)
         data_dict["cv_module_time"] = keyframe.new_tensor([time.time() - start_time])
 
         data_dict["cost_volume"] = plan.buf["cost_volume"]
@@ -354,7 +387,7 @@ class MonoRecModel(nn.Module):
         data_dict["predicted_inverse_depths"] = list(plan.preds)
         data_dict["result"] = data_dict["predicted_inverse_depths"][0]
         data_dict["mask"] = data_dict["cv_mask"]
-        return data_dict
+        return _Pending(data_dict, done, device)
 
     def _run_stage(self, key, plan, stage, stream):
         """Run one stage of the plan on `stream`: eagerly, or (hip_graph) as a captured hipGraph replay."""
@@ -379,6 +412,22 @@ class MonoRecModel(nn.Module):
             entry = graph
         with torch.cuda.stream(stream):
             entry.replay()
+
+
+class _Pending:
+    """Handle of an enqueued forward (MonoRecModel.submit)."""
+
+    def __init__(self, data_dict, done, device):
+        self._data, self._done, self._device = data_dict, done, device
+
+    def result(self):
+        """Order the caller's current stream after the forward and return the output dict."""
+        torch.cuda.current_stream(self._device).wait_event(self._done)
+        return self._data
+
+    def synchronize(self):
+        self._done.synchronize()
+        return self._data
 
 
 def _filter_state_dict(state_dict, data_parallel=False):

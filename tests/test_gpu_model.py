@@ -13,8 +13,8 @@ DEV = "cuda:0"
 RESULT_ATOL = 1e-4          # BASELINE.json north_star: depths within 1e-4 abs of the reference CPU output
 
 
-def _model(depths, graph):
-    m = MonoRecModel(cv_depth_steps=depths, hip_graph=graph)
+def _model(depths, graph, in_flight=1):
+    m = MonoRecModel(cv_depth_steps=depths, hip_graph=graph, hip_in_flight=in_flight)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
     m.load_state_dict(sd)
     return m.to(DEV).eval(), sd
@@ -120,3 +120,29 @@ def test_batch_independence(hip_lib):
             alone = model(_to_dev(one))["result"]
             # the launch schedule (split-K) depends on the batch size, so allow summation-order noise
             assert (alone[0] - full[i]).abs().max().item() < 1e-6
+
+
+def test_two_keyframes_in_flight_equal_sequential_forwards(hip_lib):
+    """MonoRecModel.submit keeps 2 keyframes on the GPU at once (separate streams + resident buffers); every
+    result must equal the strictly sequential forward of the same keyframe, in eager and in hipGraph mode."""
+    batches = [synth.make_batch(1, 64, 96, 2, seed=30 + i) for i in range(6)]
+    seq, _ = _model(8, graph=False, in_flight=1)
+    with torch.no_grad():
+        want = [seq(_to_dev(b))["result"].clone() for b in batches]
+    for graph in (False, True):
+        pipe, _ = _model(8, graph=graph, in_flight=2)
+        got = []
+        for rep in range(3 if graph else 1):         # graph mode: warm-up pass, capture pass, replay pass
+            got = []
+            pending = []
+            with torch.no_grad():
+                for b in batches:
+                    pending.append(pipe.submit(_to_dev(b)))
+                    if len(pending) == 2:
+                        got.append(pending.pop(0).result()["result"].clone())
+                while pending:
+                    got.append(pending.pop(0).result()["result"].clone())
+            torch.cuda.synchronize()
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)

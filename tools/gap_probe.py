@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from monorec_amd import MonoRecModel, synth
 dev = torch.device("cuda:0")
 for graph in (True, False):
-    m = MonoRecModel(cv_depth_steps=32, hip_graph=graph); m.load_state_dict(synth.seeded_state_dict(m.state_dict())); m = m.to(dev).eval()
+    m = MonoRecModel(cv_depth_steps=32, hip_graph=graph, hip_in_flight=1); m.load_state_dict(synth.seeded_state_dict(m.state_dict())); m = m.to(dev).eval()
     b = synth.clone_batch(synth.make_batch(1, 256, 512, 2), dev)
     with torch.no_grad():
         for _ in range(5): m(dict(b))

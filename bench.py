@@ -136,6 +136,7 @@ def main():
 
     import collections
     pending = collections.deque()
+    last = [None]
 
     def step():
         """One forward over one resident batch.  With --in-flight N the result of step i is collected when step
@@ -144,14 +145,13 @@ def main():
         with torch.no_grad():
             pending.append(model.submit(dict(batch_dev)))
             if len(pending) >= args.in_flight:
-                return pending.popleft().result()
-        return None
+                last[0] = pending.popleft().result()
+        return last[0]
 
     def drain():
-        out = None
         while pending:
-            out = pending.popleft().result()
-        return out
+            last[0] = pending.popleft().result()
+        return last[0]
 
     # W untimed warm-up steps (>= 3 so that the hipGraphs are captured), then keep spinning untimed until the
     # chip has been busy for ~1.5 s: a fresh box needs that long to page the code objects in and to ramp its

@@ -106,10 +106,12 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
     static_assert(NSS == 2, "two SSIM rounds expected");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DPI = 2;                 // depth hypotheses per iteration: halves the barriers per plane and
+                                           // doubles the independent gathers in flight per wave
     float* kf = lds;                       // [3][HY][HX] keyframe + 0.5
-    float* wr = kf + 3 * HY * HX;          // [3][HY][HX] warped + 0.5
-    float* es = wr + 3 * HY * HX;          // [SY][SX]   channel-weighted SSIM distance
-    float* sadc = es + SY * SX;            // [D][NT]    sad of the current frame
+    float* wr = kf + 3 * HY * HX;          // [DPI][3][HY][HX] warped + 0.5
+    float* es = wr + DPI * 3 * HY * HX;    // [DPI][SY][SX]   channel-weighted SSIM distance
+    float* sadc = es + DPI * SY * SX;      // [D][NT]    sad of the current frame
     float* num = sadc + a.D * NT;          // [D][NT]    sum_f w_f * sad_f
 
     const int tid = threadIdx.x;
@@ -196,74 +198,86 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
         const float* img = a.frames[f] + (long long)b * 3 * HWp;
         bool valid = own_border;
         float smin = INFINITY;
-        for (int d = 0; d < D; ++d) {
-            const float depth = a.depths[d];
-            // ---- (a) warp own pixel + one halo position ------------------------------------------
-            if (own_in) {
-                const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
-                valid = valid && mask_hit(sp, H, W);                       // monorec_model.py:218-219
+        for (int d = 0; d < D; d += DPI) {
+            // ---- (a) warp own pixel + one halo position, DPI depth planes ---------------------------
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    wr[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
-            }
-            if (has_halo) {
-                const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
+            for (int u = 0; u < DPI; ++u) {
+                const float depth = a.depths[d + u];
+                float* wru = wr + u * 3 * HY * HX;
+                if (own_in) {
+                    const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
+                    valid = valid && mask_hit(sp, H, W);                       // monorec_model.py:218-219
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    wr[(c * HY + hly) * HX + hlx] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+                    for (int c = 0; c < 3; ++c)
+                        wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+                }
+                if (has_halo) {
+                    const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        wru[(c * HY + hly) * HX + hlx] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+                }
             }
             __syncthreads();
             // ---- (b) SSIM distance on tile + 1 px halo -------------------------------------------
 #pragma unroll
             for (int r = 0; r < NSS; ++r) {
                 if (tid + r * NT < SX * SY) {
-                    float e = 0.f;   // zero padding of the 3x3 box (conv3d padding, monorec_model.py:247)
+                    int lyy[3], lxx[3];
                     if (s_in[r]) {
                         const int qy = ty0 - 1 + sly[r], qx = tx0 - 1 + slx[r];
-                        int lyy[3], lxx[3];
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             lyy[t] = reflect_idx(qy + t - 1, H) - (ty0 - 2);
                             lxx[t] = reflect_idx(qx + t - 1, W) - (tx0 - 2);
                         }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
-#pragma unroll
-                            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                                for (int dx = 0; dx < 3; ++dx) {
-                                    const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
-                                    const float x = wr[li], k = kf[li];
-                                    const float xx = x * x, xk = x * k;
-                                    if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
-                                    else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
-                                }
-                            const float mu_x = sx1 / 9.0f, mu_y = kmu[r][c];
-                            const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
-                            const float sig_x = sx2 / 9.0f - mu_x_sq;
-                            const float sig_xy = sxy / 9.0f - mu_xy;
-                            const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
-                            const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
-                            const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
-                            e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
-                        }
                     }
-                    es[sly[r] * SX + slx[r]] = e;
+#pragma unroll
+                    for (int u = 0; u < DPI; ++u) {
+                        const float* wru = wr + u * 3 * HY * HX;
+                        float e = 0.f;   // zero padding of the 3x3 box (conv3d padding, monorec_model.py:247)
+                        if (s_in[r]) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
+#pragma unroll
+                                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                                    for (int dx = 0; dx < 3; ++dx) {
+                                        const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
+                                        const float x = wru[li], k = kf[li];
+                                        const float xx = x * x, xk = x * k;
+                                        if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
+                                        else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
+                                    }
+                                const float mu_x = sx1 / 9.0f, mu_y = kmu[r][c];
+                                const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
+                                const float sig_x = sx2 / 9.0f - mu_x_sq;
+                                const float sig_xy = sxy / 9.0f - mu_xy;
+                                const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
+                                const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
+                                const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
+                                e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
+                            }
+                        }
+                        es[u * SY * SX + sly[r] * SX + slx[r]] = e;
+                    }
                 }
             }
             __syncthreads();
             // ---- (c) 3x3 box sum -> sad ------------------------------------------------------------
-            {
+#pragma unroll
+            for (int u = 0; u < DPI; ++u) {
+                const float* esu = es + u * SY * SX;
                 float s = 0.f;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        const float v = es[(oly + dy) * SX + olx + dx];
+                        const float v = esu[(oly + dy) * SX + olx + dx];
                         s = (dy == 0 && dx == 0) ? v : s + v;
                     }
-                sadc[d * NT + tid] = s;
+                sadc[(d + u) * NT + tid] = s;
                 smin = fminf(smin, s);
             }
         }
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
 template <int TX, int TY>
 int launch_cv(const CvArgs& a, hipStream_t stream) {
     constexpr int NT = TX * TY;
-    const size_t lds = sizeof(float) * (size_t)(2 * 3 * (TY + 4) * (TX + 4) + (TY + 2) * (TX + 2) + 2 * a.D * NT);
+    const size_t lds = sizeof(float) * (size_t)(3 * 3 * (TY + 4) * (TX + 4) + 2 * (TY + 2) * (TX + 2) + 2 * a.D * NT);
     if (lds > 160 * 1024) return MR_ERR_LDS_BUDGET;
     static bool attr_set = false;
     if (!attr_set) {
@@ -330,7 +344,7 @@ extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* fra
     if (!keyframe || !frames || !kinv || !proj || !depths || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
     if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
-    if (num_depths < 2 || num_depths > 64) return MR_ERR_UNSUPPORTED;
+    if (num_depths < 2 || num_depths > 64 || (num_depths & 1)) return MR_ERR_UNSUPPORTED;
     CvArgs a;
     a.keyframe = keyframe;
     for (int f = 0; f < MR_MAX_FRAMES; ++f) {

@@ -199,6 +199,8 @@ def main():
         achieved = conv_flops / conv_s / 1e12
         cv_row = next(r for r in rows if r["name"] == "cost_volume")
         traffic, traffic_src = committed_pmc_traffic() if (args.batch, args.height, args.width, args.frames, args.depths) == (1, 256, 512, 2, 32) else (None, None)
+        shape = (args.batch, args.height, args.width, args.frames, args.depths)
+        cfg_name = {(1, 256, 512, 2, 32): "c2 (BASELINE configs[1])", (8, 256, 512, 4, 64): "c3 (BASELINE configs[2])"}.get(shape, "custom")
         cv_bytes = 4.0 * args.batch * args.height * args.width * (3 + args.depths) * (1 + args.frames)
         result = {
             "metric": "frames/sec (keyframes/s), KITTI 256x512 2-src/32-bin cost-volume inference",
@@ -214,7 +216,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"c2: {args.batch} keyframe(s)/step/GPU, {args.height}x{args.width}, "
+            "config": {"workload": f"{cfg_name}: {args.batch} keyframe(s)/step/GPU, {args.height}x{args.width}, "
                                    f"{args.frames} source frames, {args.depths} depth bins, fp32, random-init weights",
                        "batch_per_gpu": args.batch, "hip_graph": not args.no_graph, "keyframes_in_flight": args.in_flight,
                        "parallelism": f"dp{world} (independent keyframes per rank)"},

@@ -137,7 +137,8 @@ int mr_conv2d_f32(const mr_conv_desc* desc, void* stream);
  *   depths : D depth hypotheses (1/linspace(inv_max, inv_min, D)), far to near
  * keyframe: (batch,3,H,W); frames[f]: (batch,3,H,W), all in [-0.5,0.5].
  * Outputs: cost_volume (batch,D,H,W); sfcv[f] (batch,D,H,W).
- * D must be <= 64, F <= MR_MAX_FRAMES.
+ * D must be even, F <= MR_MAX_FRAMES.  sfcv[f] doubles as scratch for the raw matching cost between the two
+ * internal launches (sad kernel, per-pixel fusion kernel); no other workspace is needed.
  */
 int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
                        const float* kinv, const float* proj, const float* depths,

@@ -1,20 +1,21 @@
-// Fused plane-sweep cost volume for gfx950 (MI355X): one launch replaces
-// CostVolumeModule.forward's per-pixel work, reference model/monorec/monorec_model.py:193-271
-// (+ model/layers.py:63-71 point_projection, :119-137 SSIM, F.grid_sample x2, F.conv3d) - about 60
-// full-tensor ATen passes over (D*F,3,H,W) temporaries in the reference.
+// Plane-sweep cost volume for gfx950 (MI355X): replaces CostVolumeModule.forward's per-pixel work,
+// reference model/monorec/monorec_model.py:193-271 (+ model/layers.py:63-71 point_projection,
+// :119-137 SSIM, F.grid_sample x2, F.conv3d) - about 60 full-tensor ATen passes over (D*F,3,H,W)
+// temporaries in the reference.  Two launches:
 //
-// Workgroup = one TY x TX keyframe tile of one sample (32x16 px / 512 threads for D <= 32,
-// 16x16 px / 256 threads for D <= 64), one thread per pixel.  For every source frame f and depth
-// hypothesis d the workgroup
-//   (a) projects the tile + 2 px halo into frame f and bilinearly samples RGB from HBM/L2 (the 1.5 MB
-//       source image is L2 resident; the footprint of a tile is data dependent so it is gathered,
-//       not LDS-windowed) -> warped tile in LDS,
-//   (b) evaluates the 3x3 SSIM distance on tile + 1 px halo (reflection at image borders), channel
-//       weighted -> LDS,
-//   (c) 3x3 box sum (zero padded) -> sad(f,d,pixel), kept in LDS for all d of the frame.
-// After the depth sweep of a frame the validity mask (all-depth AND of the warped border mask), the
-// soft-min frame weight and the weighted numerator are finished per pixel from LDS; the fused cost
-// volume and the F single-frame volumes are written exactly once (algorithmic HBM bytes only).
+//  A  cv_sad_kernel<TX,TY>   one workgroup per (keyframe tile, source frame, depth chunk); one thread per pixel.
+//     For two depth hypotheses at a time it (a) projects the tile + 2 px halo into the source frame and gathers
+//     RGB bilinearly (the 1.5 MB source image is L2 resident; the footprint of a tile is data dependent, so it
+//     is gathered, not LDS-windowed) -> warped planes in LDS, (b) evaluates the 3x3 SSIM distance on tile + 1 px
+//     (reflection at image borders), channel weighted -> LDS, (c) 3x3 box sum (zero padded) -> sad(f,d,pixel),
+//     stored straight into the single-frame-volume buffer.  Only ~31 KB of LDS per workgroup, so several
+//     workgroups share a CU and hide each other's dependent VALU chains and gather latency (the first, fully
+//     fused version kept every sad of a tile in LDS - 150 KB - ran one workgroup per CU and was 2-5x slower).
+//     The all-depth AND of the warped border mask (validity, :218-219) travels in the sign bit of the last plane
+//     each chunk writes (sad >= 0, so the sign is free).
+//  B  cv_fuse_kernel         one thread per pixel: validity, soft-min frame weights (:257-260), in-place
+//     sfcv = (1 - 2 sad) * valid (:251) and the fused volume (:262-269).  HBM-bound (reads F*D twice - the second
+//     time from L2 - writes F*D + D).
 //
 // Arithmetic follows the reference operation by operation with contraction disabled
 // (-ffp-contract=off) and explicit fmaf where the CPU reference fuses (MKL sgemm k-ascending FMA
@@ -36,7 +37,7 @@ struct CvArgs {
     const float* depths;  // D
     float* cv;
     int F, B, D, H, W;
-    int tiles_x;
+    int tiles_x, nchunk, dchunk;
     float alpha;
     float cw[3];          // channel_weight / 9 (fp32 division, monorec_model.py:141)
     float inv_dm1;        // fp32(1/(D-1)) (python double division, then cast; :258)
@@ -96,27 +97,25 @@ __device__ __forceinline__ bool mask_hit(const Sample& sp, int H, int W) {
 }
 
 template <int TX, int TY>
-__global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
+__global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
     constexpr int NT = TX * TY;
     constexpr int HX = TX + 4, HY = TY + 4;   // warped / keyframe tile with 2 px halo
     constexpr int SX = TX + 2, SY = TY + 2;   // SSIM tile with 1 px halo
     constexpr int NHALO = HX * HY - NT;       // halo positions warped by the first NHALO threads
     constexpr int NSS = (SX * SY + NT - 1) / NT;  // SSIM positions per thread (2)
+    constexpr int DPI = 2;                    // depth hypotheses per iteration
     static_assert(NHALO <= NT, "halo must fit one extra round");
     static_assert(NSS == 2, "two SSIM rounds expected");
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int DPI = 2;                 // depth hypotheses per iteration: halves the barriers per plane and
-                                           // doubles the independent gathers in flight per wave
-    float* kf = lds;                       // [3][HY][HX] keyframe + 0.5
-    float* wr = kf + 3 * HY * HX;          // [DPI][3][HY][HX] warped + 0.5
-    float* es = wr + DPI * 3 * HY * HX;    // [DPI][SY][SX]   channel-weighted SSIM distance
-    float* sadc = es + DPI * SY * SX;      // [D][NT]    sad of the current frame
-    float* num = sadc + a.D * NT;          // [D][NT]    sum_f w_f * sad_f
+    __shared__ float kf[3 * HY * HX];          // keyframe + 0.5
+    __shared__ float wr[DPI * 3 * HY * HX];    // warped + 0.5
+    __shared__ float es[DPI * SY * SX];        // channel-weighted SSIM distance
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W, D = a.D;
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
+    const int f = blockIdx.y / a.nchunk, chunk = blockIdx.y % a.nchunk;
+    const int d_lo = chunk * a.dchunk, d_hi = min(D, d_lo + a.dchunk);
     const int ty0 = (blockIdx.x / a.tiles_x) * TY, tx0 = (blockIdx.x % a.tiles_x) * TX;
     const int HWp = H * W;
     const float* kimg = a.keyframe + (long long)b * 3 * HWp;
@@ -131,7 +130,6 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
     }
 
     // ---- positions owned by this thread ---------------------------------------------------------------
-    // own pixel
     const int oly = tid / TX, olx = tid % TX;
     const int opy = ty0 + oly, opx = tx0 + olx;
     const bool own_in = opy < H && opx < W;
@@ -190,82 +188,80 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
     }
 
     const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;   // fp32(0.01**2), fp32(0.03**2)  layers.py:116-117
-    float wsum = 0.f;                                                   // sum_f weight_f (own pixel)
-    const bool own_border = own_in && opy >= 2 && opy < H - 2 && opx >= 2 && opx < W - 2;  // mask_to_warp[0]
+    const float* P = a.proj + ((long long)b * a.F + f) * 12;
+    const float* img = a.frames[f] + (long long)b * 3 * HWp;
+    float* sad_out = a.sfcv[f] + (long long)b * D * HWp + opy * W + opx;
+    bool hit_all = true;       // all depth planes of this chunk sample the border mask != 0
 
-    for (int f = 0; f < a.F; ++f) {
-        const float* P = a.proj + ((long long)b * a.F + f) * 12;
-        const float* img = a.frames[f] + (long long)b * 3 * HWp;
-        bool valid = own_border;
-        float smin = INFINITY;
-        for (int d = 0; d < D; d += DPI) {
-            // ---- (a) warp own pixel + one halo position, DPI depth planes ---------------------------
+    for (int d = d_lo; d < d_hi; d += DPI) {
+        // ---- (a) warp own pixel + one halo position, DPI depth planes ---------------------------
 #pragma unroll
-            for (int u = 0; u < DPI; ++u) {
-                const float depth = a.depths[d + u];
-                float* wru = wr + u * 3 * HY * HX;
-                if (own_in) {
-                    const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
-                    valid = valid && mask_hit(sp, H, W);                       // monorec_model.py:218-219
+        for (int u = 0; u < DPI; ++u) {
+            const float depth = a.depths[d + u];
+            float* wru = wr + u * 3 * HY * HX;
+            if (own_in) {
+                const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
+                hit_all = hit_all && mask_hit(sp, H, W);                   // monorec_model.py:218-219
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
-                }
-                if (has_halo) {
-                    const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        wru[(c * HY + hly) * HX + hlx] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
-                }
+                for (int c = 0; c < 3; ++c)
+                    wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
             }
-            __syncthreads();
-            // ---- (b) SSIM distance on tile + 1 px halo -------------------------------------------
+            if (has_halo) {
+                const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
 #pragma unroll
-            for (int r = 0; r < NSS; ++r) {
-                if (tid + r * NT < SX * SY) {
-                    int lyy[3], lxx[3];
+                for (int c = 0; c < 3; ++c)
+                    wru[(c * HY + hly) * HX + hlx] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+            }
+        }
+        __syncthreads();
+        // ---- (b) SSIM distance on tile + 1 px halo -------------------------------------------
+#pragma unroll
+        for (int r = 0; r < NSS; ++r) {
+            if (tid + r * NT < SX * SY) {
+                int lyy[3], lxx[3];
+                if (s_in[r]) {
+                    const int qy = ty0 - 1 + sly[r], qx = tx0 - 1 + slx[r];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        lyy[t] = reflect_idx(qy + t - 1, H) - (ty0 - 2);
+                        lxx[t] = reflect_idx(qx + t - 1, W) - (tx0 - 2);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < DPI; ++u) {
+                    const float* wru = wr + u * 3 * HY * HX;
+                    float e = 0.f;   // zero padding of the 3x3 box (conv3d padding, monorec_model.py:247)
                     if (s_in[r]) {
-                        const int qy = ty0 - 1 + sly[r], qx = tx0 - 1 + slx[r];
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) {
-                            lyy[t] = reflect_idx(qy + t - 1, H) - (ty0 - 2);
-                            lxx[t] = reflect_idx(qx + t - 1, W) - (tx0 - 2);
+                        for (int c = 0; c < 3; ++c) {
+                            float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
+#pragma unroll
+                            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) {
+                                    const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
+                                    const float x = wru[li], k = kf[li];
+                                    const float xx = x * x, xk = x * k;
+                                    if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
+                                    else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
+                                }
+                            const float mu_x = sx1 / 9.0f, mu_y = kmu[r][c];
+                            const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
+                            const float sig_x = sx2 / 9.0f - mu_x_sq;
+                            const float sig_xy = sxy / 9.0f - mu_xy;
+                            const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
+                            const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
+                            const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
+                            e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < DPI; ++u) {
-                        const float* wru = wr + u * 3 * HY * HX;
-                        float e = 0.f;   // zero padding of the 3x3 box (conv3d padding, monorec_model.py:247)
-                        if (s_in[r]) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
-#pragma unroll
-                                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                                    for (int dx = 0; dx < 3; ++dx) {
-                                        const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
-                                        const float x = wru[li], k = kf[li];
-                                        const float xx = x * x, xk = x * k;
-                                        if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
-                                        else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
-                                    }
-                                const float mu_x = sx1 / 9.0f, mu_y = kmu[r][c];
-                                const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
-                                const float sig_x = sx2 / 9.0f - mu_x_sq;
-                                const float sig_xy = sxy / 9.0f - mu_xy;
-                                const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
-                                const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
-                                const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
-                                e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
-                            }
-                        }
-                        es[u * SY * SX + sly[r] * SX + slx[r]] = e;
-                    }
+                    es[u * SY * SX + sly[r] * SX + slx[r]] = e;
                 }
             }
-            __syncthreads();
-            // ---- (c) 3x3 box sum -> sad ------------------------------------------------------------
+        }
+        __syncthreads();
+        // ---- (c) 3x3 box sum -> sad, stored raw; the chunk's last plane carries the validity in its sign ----
+        if (own_in) {
 #pragma unroll
             for (int u = 0; u < DPI; ++u) {
                 const float* esu = es + u * SY * SX;
@@ -277,39 +273,65 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
                         const float v = esu[(oly + dy) * SX + olx + dx];
                         s = (dy == 0 && dx == 0) ? v : s + v;
                     }
-                sadc[(d + u) * NT + tid] = s;
-                smin = fminf(smin, s);
+                if (d + u == d_hi - 1 && !hit_all) s = -s;      // sad >= 0: the sign bit is free (-0.0 keeps it)
+                sad_out[(long long)(d + u) * HWp] = s;
             }
         }
-        // ---- frame epilogue (own pixel): single-frame volume, soft-min weight, numerator -----------
-        if (own_in) {
-            const float vm = valid ? 1.f : 0.f;
-            float se = 0.f;
-            for (int d = 0; d < D; ++d) {
-                const float df = sadc[d * NT + tid] - smin;
-                const float ev = expf(-a.alpha * (df * df));                 // monorec_model.py:257
-                se = d == 0 ? ev : se + ev;
-            }
-            float wgt = 1.0f - a.inv_dm1 * (se - 1.0f);                      // :258
-            wgt = wgt * vm;                                                  // :260
-            wsum = f == 0 ? wgt : wsum + wgt;                                // :264
-            float* sf = a.sfcv[f] + (long long)b * D * HWp + opy * W + opx;
-            for (int d = 0; d < D; ++d) {
-                const float s = sadc[d * NT + tid];
-                sf[(long long)d * HWp] = (1.0f - s * 2.0f) * vm;             // :251
-                const float t = s * wgt;                                     // :262
-                num[d * NT + tid] = f == 0 ? t : num[d * NT + tid] + t;
-            }
-        }
-        // sadc of this frame is only re-read by its own thread; the next frame's (a)/(b)/(c) barriers
-        // order the shared wr/es buffers, so no extra barrier is needed here.
     }
-    if (own_in) {
-        float* cvp = a.cv + (long long)b * D * HWp + opy * W + opx;
+}
+
+// Per-pixel frame fusion (monorec_model.py:251-269) over the raw sad values kernel A left in the sfcv buffers.
+__global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
+    const int HWp = a.H * a.W;
+    const int D = a.D;
+    const long long total = (long long)a.B * HWp;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HWp), p = (int)(i % HWp);
+        const int py = p / a.W, px = p % a.W;
+        const bool border = py >= 2 && py < a.H - 2 && px >= 2 && px < a.W - 2;     // mask_to_warp[0], :219
+        float wgt[MR_MAX_FRAMES], vmask[MR_MAX_FRAMES];
+        float wsum = 0.f;
+#pragma unroll
+        for (int f = 0; f < MR_MAX_FRAMES; ++f) {
+            wgt[f] = 0.f; vmask[f] = 0.f;
+            if (f < a.F) {
+                const float* sf = a.sfcv[f] + (long long)b * D * HWp + p;
+                bool valid = border;
+                float smin = INFINITY;
+                for (int d = 0; d < D; ++d) {
+                    const float v = sf[(long long)d * HWp];
+                    valid = valid && !(__float_as_uint(v) & 0x80000000u);
+                    smin = fminf(smin, fabsf(v));
+                }
+                float se = 0.f;
+                for (int d = 0; d < D; ++d) {
+                    const float df = fabsf(sf[(long long)d * HWp]) - smin;
+                    const float ev = expf(-a.alpha * (df * df));                 // :257
+                    se = d == 0 ? ev : se + ev;
+                }
+                const float vm = valid ? 1.f : 0.f;
+                float w = 1.0f - a.inv_dm1 * (se - 1.0f);                        // :258
+                w = w * vm;                                                      // :260
+                wgt[f] = w; vmask[f] = vm;
+                wsum = f == 0 ? w : wsum + w;                                    // :264
+            }
+        }
         const bool nz = wsum != 0.f;
+        float* cvp = a.cv + (long long)b * D * HWp + p;
         for (int d = 0; d < D; ++d) {
-            float v = 0.f;                                                   // :269
-            if (nz) v = 1.0f - 2.0f * (num[d * NT + tid] / wsum);            // :266,268
+            float num = 0.f;
+#pragma unroll
+            for (int f = 0; f < MR_MAX_FRAMES; ++f) {
+                if (f < a.F) {
+                    float* sf = a.sfcv[f] + (long long)b * D * HWp + p + (long long)d * HWp;
+                    const float s = fabsf(*sf);
+                    *sf = (1.0f - s * 2.0f) * vmask[f];                          // :251
+                    const float t = s * wgt[f];                                  // :262
+                    num = f == 0 ? t : num + t;
+                }
+            }
+            float v = 0.f;                                                       // :269
+            if (nz) v = 1.0f - 2.0f * (num / wsum);                              // :266,268
             cvp[(long long)d * HWp] = v;
         }
     }
@@ -317,20 +339,20 @@ __global__ __launch_bounds__(TX * TY) void cost_volume_kernel(const CvArgs a) {
 
 template <int TX, int TY>
 int launch_cv(const CvArgs& a, hipStream_t stream) {
-    constexpr int NT = TX * TY;
-    const size_t lds = sizeof(float) * (size_t)(3 * 3 * (TY + 4) * (TX + 4) + 2 * (TY + 2) * (TX + 2) + 2 * a.D * NT);
-    if (lds > 160 * 1024) return MR_ERR_LDS_BUDGET;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_volume_kernel<TX, TY>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     CvArgs k = a;
     k.tiles_x = (a.W + TX - 1) / TX;
-    const int tiles_y = (a.H + TY - 1) / TY;
-    hipLaunchKernelGGL((cost_volume_kernel<TX, TY>), dim3(k.tiles_x * tiles_y, a.B), dim3(NT), lds, stream, k);
+    const int tiles = k.tiles_x * ((a.H + TY - 1) / TY);
+    // depth chunks: enough workgroups to put >= 4 on every CU, chunks of an even number of planes
+    int nchunk = 1;
+    while ((long long)tiles * a.F * a.B * nchunk < 1024 && (a.D / (nchunk * 2)) >= 4 && (a.D % (nchunk * 4)) == 0) nchunk *= 2;
+    k.nchunk = nchunk;
+    k.dchunk = a.D / nchunk;
+    hipLaunchKernelGGL((cv_sad_kernel<TX, TY>), dim3(tiles, a.F * nchunk, a.B), dim3(TX * TY), 0, stream, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long long total = (long long)a.B * a.H * a.W;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cv_fuse_kernel, dim3(blocks), dim3(256), 0, stream, k);
     return (int)hipGetLastError();
 }
 
@@ -344,7 +366,7 @@ extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* fra
     if (!keyframe || !frames || !kinv || !proj || !depths || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
     if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
-    if (num_depths < 2 || num_depths > 64 || (num_depths & 1)) return MR_ERR_UNSUPPORTED;
+    if (num_depths < 2 || (num_depths & 1)) return MR_ERR_UNSUPPORTED;   // two planes per iteration
     CvArgs a;
     a.keyframe = keyframe;
     for (int f = 0; f < MR_MAX_FRAMES; ++f) {
@@ -354,10 +376,9 @@ extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* fra
     }
     a.kinv = kinv; a.proj = proj; a.depths = depths; a.cv = cost_volume;
     a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
-    a.tiles_x = 0;
+    a.tiles_x = 0; a.nchunk = 1; a.dchunk = num_depths;
     a.alpha = alpha;
     for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / 9.0f;
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
-    if (num_depths <= 32) return launch_cv<32, 16>(a, (hipStream_t)stream);
-    return launch_cv<16, 16>(a, (hipStream_t)stream);
+    return launch_cv<32, 8>(a, (hipStream_t)stream);
 }

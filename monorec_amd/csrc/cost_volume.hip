@@ -88,14 +88,27 @@ __device__ __forceinline__ Sample project(float r0, float r1, float r2, float de
     return o;
 }
 
-__device__ __forceinline__ float bilinear(const float* img, const Sample& sp, int H, int W) {
+// Byte offsets of the four bilinear taps inside one image plane, -1 (out of range for the buffer descriptor,
+// the hardware then returns 0 = grid_sample's padding_mode='zeros') for taps outside the image: no branches.
+struct Taps { int a, b, c, d; };
+
+__device__ __forceinline__ Taps tap_offsets(const Sample& sp, int H, int W) {
     const bool xl = sp.x0 >= 0 && sp.x0 < W, xr = sp.x0 + 1 >= 0 && sp.x0 + 1 < W;
     const bool yt = sp.y0 >= 0 && sp.y0 < H, yb = sp.y0 + 1 >= 0 && sp.y0 + 1 < H;
-    const float* p = img + sp.y0 * W + sp.x0;
-    const float a = (xl && yt) ? p[0] : 0.f;
-    const float b = (xr && yt) ? p[1] : 0.f;
-    const float c = (xl && yb) ? p[W] : 0.f;
-    const float d = (xr && yb) ? p[W + 1] : 0.f;
+    const int o = (sp.y0 * W + sp.x0) * 4;
+    Taps t;
+    t.a = (xl && yt) ? o : -1;
+    t.b = (xr && yt) ? o + 4 : -1;
+    t.c = (xl && yb) ? o + W * 4 : -1;
+    t.d = (xr && yb) ? o + W * 4 + 4 : -1;
+    return t;
+}
+
+__device__ __forceinline__ float bilinear(__amdgpu_buffer_rsrc_t img, int plane_bytes, const Taps& t, const Sample& sp) {
+    const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t.a, plane_bytes, 0));
+    const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t.b, plane_bytes, 0));
+    const float c = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t.c, plane_bytes, 0));
+    const float d = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t.d, plane_bytes, 0));
     return fmaf(d, sp.se, fmaf(c, sp.sw, fmaf(b, sp.ne, a * sp.nw)));
 }
 
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
 
     const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;   // fp32(0.01**2), fp32(0.03**2)  layers.py:116-117
     const float* P = a.proj + ((long long)b * a.F + f) * 12;
-    const float* img = a.frames[f] + (long long)b * 3 * HWp;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000);
     float* sad_out = a.sfcv[f] + (long long)b * D * HWp + opy * W + opx;
     bool hit_all = true;       // all depth planes of this chunk sample the border mask != 0
 
@@ -213,15 +226,17 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
             if (own_in) {
                 const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
                 hit_all = hit_all && mask_hit(sp, H, W);                   // monorec_model.py:218-219
+                const Taps tp = tap_offsets(sp, H, W);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+                    wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img, c * HWp * 4, tp, sp) + 0.5f;
             }
             if (has_halo) {
                 const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
+                const Taps tp = tap_offsets(sp, H, W);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    wru[(c * HY + hly) * HX + hlx] = bilinear(img + c * HWp, sp, H, W) + 0.5f;
+                    wru[(c * HY + hly) * HX + hlx] = bilinear(img, c * HWp * 4, tp, sp) + 0.5f;
             }
         }
         __syncthreads();

@@ -55,9 +55,11 @@ def main():
         if "WRITE_SIZE" in conv:
             d["WRITE_SIZE_KiB_per_dispatch"] = conv["WRITE_SIZE"] / conv_n
         if "FETCH_SIZE" in conv and "WRITE_SIZE" in conv:
-            d["hbm_bytes_per_dispatch"] = (conv["FETCH_SIZE"] + conv["WRITE_SIZE"]) * 1024 / conv_n
-            d["note"] = ("dword (4 B/lane) buffer loads: the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to "
-                         "16 B/lane streams and is NOT applied here (uncalibrated width); WRITE_SIZE as reported")
+            d["hbm_bytes_per_dispatch_raw"] = (conv["FETCH_SIZE"] + conv["WRITE_SIZE"]) * 1024 / conv_n
+            d["hbm_bytes_per_dispatch"] = (2 * conv["FETCH_SIZE"] + conv["WRITE_SIZE"]) * 1024 / conv_n
+            d["note"] = ("inputs and weights are staged with 16 B/lane LDS-DMA: on gfx950 rocprofv3 FETCH_SIZE reports half the "
+                         "bytes of such streams (MI355X_MICROARCH.md, HBM section), so hbm_bytes_per_dispatch = "
+                         "(2*FETCH_SIZE + WRITE_SIZE) * 1024; _raw is uncorrected; WRITE_SIZE as reported")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in conv and "GRBM_GUI_ACTIVE" in conv:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
             d["mfma_util"] = (conv["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (conv["GRBM_GUI_ACTIVE"] / 8)

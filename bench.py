@@ -121,12 +121,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MR_BENCH_ONE_DEVICE=1 (testing only): all ranks share cuda:0 and talk over gloo, so the multi-rank control
+    # flow can be exercised on a 1-GPU box; normally one rank per GPU over RCCL ("nccl" backend on ROCm).
+    one_device = os.environ.get("MR_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    comm_dev = torch.device("cpu") if one_device else dev
 
     from monorec_amd import MonoRecModel, synth
 
@@ -168,7 +176,7 @@ def main():
             torch.cuda.synchronize()
     drain()
     torch.cuda.synchronize()
-    summary = torch.zeros(2, dtype=torch.float64, device=dev)
+    summary = torch.zeros(2, dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -177,7 +185,7 @@ def main():
         step()
     out = drain()
     summary[0] = args.steps * args.batch
-    summary[1] = out["result"].double().mean()
+    summary[1] = out["result"].double().mean().to(comm_dev)
     if world > 1:   # the path's only collective: per-rank summaries, ~16 B per rank
         gathered = [torch.zeros_like(summary) for _ in range(world)]
         dist.all_gather(gathered, summary)
@@ -188,7 +196,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_keyframes = float(sum(g[0].item() for g in gathered))

@@ -167,6 +167,14 @@ int mr_max_over_frames_f32(const float* src, float* dst, int32_t num_frames, int
 int mr_apply_mask_f32(const float* cv, const float* mask, float* dst, int32_t batch, int32_t num_depths,
                       int64_t plane, void* stream);
 
+/* Fused sparse depth metrics, one launch for all seven metrics of configs/evaluate/eval_monorec.json:53-61
+ * (model/metric_functions/sparse_metrics.py:136-252 with utils/util.py:36-118; pred_all_valid=True, no cv-mask):
+ * prediction/target (batch,1,H,W) inverse depths; roi = {y0,y1,x0,x1} host ints or NULL; max_distance <= 0 = None.
+ * sums: batch x 8 doubles on the device, per sample [n_valid, sum|dp-dg|/dg, sum(dp-dg)^2/dg, sum(dp-dg)^2,
+ * sum(log dp - log dg)^2, n(thresh<1.25), n(thresh<1.25^2), n(thresh<1.25^3)]. */
+int mr_sparse_metric_sums_f32(const float* prediction, const float* target, int32_t batch, int32_t height,
+                              int32_t width, const int32_t* roi, float max_distance, double* sums, void* stream);
+
 int mr_abi_version(void);
 const char* mr_error_string(int code);
 

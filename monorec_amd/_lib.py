@@ -76,6 +76,9 @@ ABI = {
                                               ctypes.c_void_p]),
     "mr_apply_mask_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_sparse_metric_sums_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_float,
+                                                 ctypes.c_void_p, ctypes.c_void_p]),
     "mr_abi_version": (ctypes.c_int, []),
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }

@@ -88,6 +88,57 @@ __global__ __launch_bounds__(256) void resnet_normalize_kernel(const float4* __r
     }
 }
 
+// Fused sparse depth metrics (reference model/metric_functions/sparse_metrics.py:136-252 + utils/util.py:36-118):
+// one pass over prediction / ground-truth inverse depth gives, per sample, the 8 sums all seven metrics need:
+//   [0] #valid  [1] sum |dp-dg|/dg  [2] sum (dp-dg)^2/dg  [3] sum (dp-dg)^2  [4] sum (log dp - log dg)^2
+//   [5..7] #(max(dg/dp, dp/dg) < 1.25^k), k = 1,2,3
+// mask (get_mask): gt == 0 or gt < 1/max_distance; depths: relu, clamp_min(1/max_distance), reciprocal.
+// One 1024-thread workgroup per sample, fp32 per element, fp64 accumulation, fixed reduction order.
+__global__ __launch_bounds__(1024) void sparse_metric_sums_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                                  int H, int W, int y0, int y1, int x0, int x1,
+                                                                  float inv_max_dist, double* __restrict__ out) {
+    __shared__ double red[8][16];
+    const int b = blockIdx.x;
+    const float* p = pred + (long long)b * H * W;
+    const float* g = gt + (long long)b * H * W;
+    const int rw = x1 - x0, n = (y1 - y0) * rw;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float t1 = 1.25f, t2 = (float)(1.25 * 1.25), t3 = (float)(1.25 * 1.25 * 1.25);
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int y = y0 + i / rw, x = x0 + i % rw;
+        float gi = g[y * W + x], pi = p[y * W + x];
+        const bool masked = gi == 0.f || (inv_max_dist > 0.f && gi < inv_max_dist);
+        if (masked) continue;
+        pi = fmaxf(pi, 0.f); gi = fmaxf(gi, 0.f);                               // get_positive_depth
+        if (inv_max_dist > 0.f) { pi = fmaxf(pi, inv_max_dist); gi = fmaxf(gi, inv_max_dist); }   // clamp_min
+        const float dp = 1.0f / pi, dg = 1.0f / gi;                             // get_absolute_depth
+        const float d = dp - dg;
+        const float lg = logf(dp) - logf(dg);
+        const float th = fmaxf(dg / dp, dp / dg);
+        acc[0] += 1.0;
+        acc[1] += (double)(fabsf(d) / dg);
+        acc[2] += (double)((d * d) / dg);
+        acc[3] += (double)(d * d);
+        acc[4] += (double)(lg * lg);
+        acc[5] += th < t1 ? 1.0 : 0.0;
+        acc[6] += th < t2 ? 1.0 : 0.0;
+        acc[7] += th < t3 ? 1.0 : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double v = 0;
+        for (int w = 0; w < 16; ++w) v += red[threadIdx.x][w];
+        out[b * 8 + threadIdx.x] = v;
+    }
+}
+
 inline unsigned grid_for(long long work_items) {
     long long blocks = (work_items + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -116,6 +167,18 @@ extern "C" int mr_resnet_normalize_f32(const float* src, float* dst, int64_t cou
     if (!src || !dst || count < 4 || (count & 3)) return MR_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(resnet_normalize_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)src, (float4*)dst, (long long)(count / 4));
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_sparse_metric_sums_f32(const float* prediction, const float* target, int32_t batch, int32_t height,
+                                         int32_t width, const int32_t* roi, float max_distance, double* sums, void* stream) {
+    if (!prediction || !target || !sums || batch < 1 || height < 1 || width < 1) return MR_ERR_BAD_ARGUMENT;
+    int y0 = 0, y1 = height, x0 = 0, x1 = width;
+    if (roi) { y0 = roi[0]; y1 = roi[1]; x0 = roi[2]; x1 = roi[3]; }
+    if (y0 < 0 || x0 < 0 || y1 > height || x1 > width || y1 <= y0 || x1 <= x0) return MR_ERR_BAD_ARGUMENT;
+    const float inv = max_distance > 0.f ? 1.0f / max_distance : 0.f;
+    hipLaunchKernelGGL(sparse_metric_sums_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, prediction, target,
+                       height, width, y0, y1, x0, x1, inv, sums);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,96 @@
+"""Sparse depth metrics of the reference (model/metric_functions/sparse_metrics.py:136-252), same function names
+and signatures, computed by ONE fused HIP reduction (mr_sparse_metric_sums_f32) and one 64*B byte device->host
+copy per batch instead of ~70 full-tensor ATen passes and 7 host syncs (evaluater/evaluater.py:38-50).
+
+`evaluate.py` looks metrics up by name (`getattr(module_metric, met)`, evaluate.py:24): bind this module instead of
+`model.metric` to use them.  The seven calls of one batch share a single kernel launch (the sums are cached on the
+data dict).  Options that the evaluation configs never set (`pred_all_valid=False`, `use_cvmask=True`) raise.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+_CACHE_KEY = "_monorec_amd_metric_sums"
+
+
+def sparse_metric_sums(data_dict, roi=None, max_distance=None):
+    """(B, 8) float64 CPU tensor of per-sample sums; cached on `data_dict` for the (result, target, roi, dist) at hand."""
+    pred, gt = data_dict["result"], data_dict["target"]
+    if not pred.is_cuda:
+        raise RuntimeError("monorec_amd.metrics needs result/target on a HIP device; there is no CPU path")
+    key = (pred.data_ptr(), pred._version, gt.data_ptr(), gt._version, None if roi is None else tuple(roi), max_distance)
+    cached = data_dict.get(_CACHE_KEY)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    lib = _lib.load()
+    pred = pred.contiguous().float()
+    gt = gt.contiguous().float()
+    b, _, h, w = pred.shape
+    assert gt.shape == pred.shape
+    sums = torch.empty(b, 8, dtype=torch.float64, device=pred.device)
+    roi_arr = (ctypes.c_int32 * 4)(*[int(v) for v in roi]) if roi is not None else None
+    stream = torch.cuda.current_stream(pred.device).cuda_stream
+    _lib.check(lib.mr_sparse_metric_sums_f32(pred.data_ptr(), gt.data_ptr(), b, h, w, roi_arr,
+                                             float(max_distance) if max_distance else 0.0, sums.data_ptr(), stream),
+               "mr_sparse_metric_sums_f32")
+    out = sums.cpu()
+    data_dict[_CACHE_KEY] = (key, out)
+    return out
+
+
+def _check(pred_all_valid, use_cvmask):
+    if not pred_all_valid or use_cvmask:
+        raise NotImplementedError("pred_all_valid=False / use_cvmask=True are outside the MI355X hot-path scope")
+
+
+def _batch_ratio(s, col):
+    """mask_mean over the whole batch (utils/util.py:110-118): sum over all samples / number of unmasked entries."""
+    n = s[:, 0].sum()
+    return torch.tensor(float("nan")) if n == 0 else (s[:, col].sum() / n).float()
+
+
+def _per_sample_rms(s, col):
+    """rmse_base / rmse_log_base (sparse_metrics.py:228-239): sqrt of the per-sample masked mean, mean over samples."""
+    return torch.sqrt(s[:, col] / s[:, 0]).mean().float()
+
+
+def abs_rel_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _batch_ratio(sparse_metric_sums(data_dict, roi, max_distance), 1)
+
+
+def sq_rel_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _batch_ratio(sparse_metric_sums(data_dict, roi, max_distance), 2)
+
+
+def rmse_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _per_sample_rms(sparse_metric_sums(data_dict, roi, max_distance), 3)
+
+
+def rmse_log_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _per_sample_rms(sparse_metric_sums(data_dict, roi, max_distance), 4)
+
+
+def a1_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _batch_ratio(sparse_metric_sums(data_dict, roi, max_distance), 5)
+
+
+def a2_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _batch_ratio(sparse_metric_sums(data_dict, roi, max_distance), 6)
+
+
+def a3_sparse_metric(data_dict, roi=None, max_distance=None, pred_all_valid=True, use_cvmask=False):
+    _check(pred_all_valid, use_cvmask)
+    return _batch_ratio(sparse_metric_sums(data_dict, roi, max_distance), 7)
+
+
+SPARSE_METRICS = ("abs_rel_sparse_metric", "sq_rel_sparse_metric", "rmse_sparse_metric", "rmse_log_sparse_metric",
+                  "a1_sparse_metric", "a2_sparse_metric", "a3_sparse_metric")     # configs/evaluate/eval_monorec.json:53-61

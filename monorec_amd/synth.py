@@ -79,6 +79,17 @@ def make_batch(batch=1, height=256, width=512, frames=2, seed=1, hard_pose=False
     }
 
 
+def make_depth_pair(batch=2, height=64, width=96, seed=7, valid_fraction=0.18):
+    """Synthetic (prediction, lidar-like sparse target) inverse-depth maps for the metric path: the target is
+    zero on ~82 % of the pixels (the annotated KITTI depth of the example has 17.6 % valid pixels)
+    and reaches below 1/80 so that the max_distance mask (utils/util.py:101-107) is exercised."""
+    gen = torch.Generator().manual_seed(seed)
+    pred = 0.0025 + (0.33 - 0.0025) * torch.rand(batch, 1, height, width, generator=gen)
+    gt = 0.004 + (0.33 - 0.004) * torch.rand(batch, 1, height, width, generator=gen) ** 2
+    keep = torch.rand(batch, 1, height, width, generator=gen) < valid_fraction
+    return pred.contiguous(), (gt * keep).contiguous()
+
+
 def clone_batch(batch, device=None):
     def cv(v):
         if isinstance(v, torch.Tensor):

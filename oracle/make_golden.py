@@ -181,6 +181,24 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **store)
         report["cases"][name] = {"config": [b, h, w, nf, d, seed, hard, full], "oracle_vs_reference_maxabs": diffs}
         print(name, "ok; oracle == reference on", len(diffs), "tensors")
+    # ---- sparse depth metrics: the real reference functions on seeded (prediction, target) pairs -------------
+    import model.metric_functions.sparse_metrics as ref_metrics          # noqa: reference module (via ref_shims)
+    metric_cases = {"default_eval": (2, 64, 96, 7, None, 80), "roi_no_maxdist": (3, 40, 72, 8, [4, 36, 8, 64], None),
+                    "full_size": (2, 256, 512, 9, None, 80)}
+    metric_fixture = {}
+    for name, (b, h, w, seed, roi, maxd) in metric_cases.items():
+        pred, gt = synth.make_depth_pair(b, h, w, seed)
+        want = {}
+        for fn in ("abs_rel_sparse_metric", "sq_rel_sparse_metric", "rmse_sparse_metric", "rmse_log_sparse_metric",
+                   "a1_sparse_metric", "a2_sparse_metric", "a3_sparse_metric"):
+            want[fn] = float(getattr(ref_metrics, fn)({"result": pred.clone(), "target": gt.clone()}, roi, maxd))
+        got = {k: float(v) for k, v in orc.sparse_metrics(pred, gt, roi, maxd).items()}
+        assert got == want, (name, got, want)
+        metric_fixture[name] = {"config": [b, h, w, seed, roi, maxd], "metrics": want}
+        print("metrics", name, "ok; oracle == reference")
+    with open(os.path.join(GOLDEN, "sparse_metrics.json"), "w") as f:
+        json.dump(metric_fixture, f, indent=1, sort_keys=True)
+    report["metrics_oracle_equals_reference"] = True
     with open(os.path.join(GOLDEN, "PINNING.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print("wrote", GOLDEN)

@@ -315,3 +315,46 @@ def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stag
         "result": preds[0],
         "mask": cv_mask,
     }
+
+
+# ----------------------------------------------------------------------------------------
+# sparse depth metrics (model/metric_functions/sparse_metrics.py:136-252, utils/util.py:36-118)
+# ----------------------------------------------------------------------------------------
+def _masked_mean(t, m, dim=None):
+    """utils.mask_mean (utils/util.py:110-118)."""
+    t = t.clone()
+    t[m] = 0
+    dims = list(range(t.dim())) if dim is None else dim
+    els = 1
+    for d in dims:
+        els *= t.shape[d]
+    return torch.sum(t, dim=dims) / (els - torch.sum(m.to(torch.float), dim=dims))
+
+
+def sparse_metrics(pred, gt, roi=None, max_distance=None):
+    """The seven metrics of configs/evaluate/eval_monorec.json:53-61 on inverse-depth maps (B,1,H,W),
+    pred_all_valid=True, use_cvmask=False.  Returns a dict name -> 0-dim tensor."""
+    if roi is not None:                                                    # preprocess_roi, util.py:36-43
+        pred, gt = pred[:, :, roi[0]:roi[1], roi[2]:roi[3]], gt[:, :, roi[0]:roi[1], roi[2]:roi[3]]
+    mask = gt == 0                                                         # get_mask, util.py:101-107
+    if max_distance:
+        mask = mask | (gt < 1 / max_distance)
+    p, g = torch.relu(pred), torch.relu(gt)                                # get_positive_depth, util.py:59-65
+    if max_distance is not None:                                           # get_absolute_depth, util.py:46-56
+        p, g = torch.clamp_min(p, 1 / max_distance), torch.clamp_min(g, 1 / max_distance)
+    dp, dg = 1 / p, 1 / g
+    out = {}
+    out["abs_rel_sparse_metric"] = _masked_mean(torch.abs(dp - dg) / dg, mask)            # :247-248
+    out["sq_rel_sparse_metric"] = _masked_mean(((dp - dg) ** 2) / dg, mask)               # :251-252
+    thresh = torch.max(dg / dp, dp / dg)
+    out["a1_sparse_metric"] = _masked_mean((thresh < 1.25).float(), mask)                 # :205-207
+    dp1, dg1 = dp.clone(), dg.clone()
+    dp1[mask] = 1
+    dg1[mask] = 1
+    thresh1 = torch.max(dg1 / dp1, dp1 / dg1).float()
+    out["a2_sparse_metric"] = _masked_mean((thresh1 < 1.25 ** 2).float(), mask)           # :210-214
+    out["a3_sparse_metric"] = _masked_mean((thresh1 < 1.25 ** 3).float(), mask)           # :217-221
+    out["rmse_sparse_metric"] = torch.mean(torch.sqrt(_masked_mean((dp1 - dg1) ** 2, mask, dim=[1, 2, 3])))   # :224-228
+    out["rmse_log_sparse_metric"] = torch.mean(torch.sqrt(
+        _masked_mean((torch.log(dp1) - torch.log(dg1)) ** 2, mask, dim=[1, 2, 3])))       # :231-235
+    return out

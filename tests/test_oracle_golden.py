@@ -65,3 +65,13 @@ def test_seeded_weights_are_order_independent():
     a = synth.seeded_state_dict(m.state_dict(), seed=0)
     b = synth.seeded_state_dict(dict(reversed(list(m.state_dict().items()))), seed=0)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_oracle_sparse_metrics_match_reference_fixture():
+    fx = json.load(open(os.path.join(GOLDEN, "sparse_metrics.json")))
+    for name, case in fx.items():
+        b, h, w, seed, roi, maxd = case["config"]
+        pred, gt = synth.make_depth_pair(b, h, w, seed)
+        got = orc.sparse_metrics(pred, gt, roi, maxd)
+        for k, want in case["metrics"].items():
+            assert abs(float(got[k]) - want) <= 2e-6 * max(1.0, abs(want)), (name, k, float(got[k]), want)

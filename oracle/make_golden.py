@@ -39,7 +39,7 @@ CASES = {
 }
 
 
-def sample(t):
+def sample_summary(t):
     """Deterministic compact summary of a tensor (see tests/golden_util.py for the reader)."""
     flat = t.detach().reshape(-1).to(torch.float32)
     stride = max(1, flat.numel() // MAX_SAMPLES)
@@ -169,7 +169,7 @@ def main():
         for k in items_ref:
             diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
             assert diffs[k] == 0.0, f"oracle deviates from the reference on {name}/{k}: {diffs[k]}"
-            sm = sample(items_ref[k])
+            sm = sample_summary(items_ref[k])
             for kk, vv in sm.items():
                 store[f"{k}.{kk}"] = vv
         for k in ("result", "cv_mask"):
@@ -181,6 +181,60 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **store)
         report["cases"][name] = {"config": [b, h, w, nf, d, seed, hard, full], "oracle_vs_reference_maxabs": diffs}
         print(name, "ok; oracle == reference on", len(diffs), "tensors")
+    # ---- the reference's own example sample (example/test_monorec.py: KITTI seq 07, image 169, sources 168/170,
+    #      DVSO poses, annotated lidar depth) through the UNMODIFIED reference dataset class -------------------------
+    cwd = os.getcwd()
+    os.chdir(os.path.join(ref_shims.REFERENCE_ROOT, "example"))
+    try:
+        from data_loader.kitti_odometry_dataset import KittiOdometryDataset     # noqa: reference class
+        ds = KittiOdometryDataset("data/kitti", sequences=["07"], target_image_size=(256, 512), frame_count=2,
+                                  depth_folder="image_depth_annotated", lidar_depth=True, use_dso_poses=True,
+                                  use_index_mask=None)
+        ds._dataset_sizes = [1000]                                                # same hack as example/test_monorec.py:22-25
+        ds._datasets[0].cam2_files = [f"data/kitti/sequences/07/image_2/{i:06d}.png" for i in range(1000)]
+        sample, depth = ds.__getitem__(164)                                       # image 169 (test_monorec.py:38-41)
+    finally:
+        os.chdir(cwd)
+    unsq = lambda v: v.unsqueeze(0) if torch.is_tensor(v) else [t.unsqueeze(0) for t in v]
+    kbatch = {k: unsq(v) for k, v in sample.items() if k not in ("sequence", "image_id")}
+    ktarget = depth.unsqueeze(0)
+    ref = Ref(cv_depth_steps=32).eval()
+    sd = synth.seeded_state_dict(ref.state_dict(), seed=0)
+    ref.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out_ref = ref(synth.clone_batch(kbatch))
+    out_orc = orc.forward(sd, kbatch, cv_depth_steps=32)
+    store = {}
+    items_ref, items_orc = flatten_outputs(out_ref), flatten_outputs(out_orc)
+    diffs = {}
+    for k in items_ref:
+        diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+        assert diffs[k] == 0.0, f"oracle deviates from the reference on kitti_example/{k}: {diffs[k]}"
+        for kk, vv in sample_summary(items_ref[k]).items():
+            store[f"{k}.{kk}"] = vv
+    for k in ("result", "cv_mask"):
+        store[f"{k}.full"] = items_ref[k].numpy()
+    u8 = lambda t: ((t + .5) * 255).round().to(torch.uint8)                      # exact inverse of img/255 - .5
+    assert torch.equal(u8(kbatch["keyframe"]).float() / 255 - .5, kbatch["keyframe"])
+    store["input.keyframe_u8"] = u8(kbatch["keyframe"]).numpy()
+    store["input.frames_u8"] = torch.stack([u8(f) for f in kbatch["frames"]]).numpy()
+    store["input.keyframe_pose"] = kbatch["keyframe_pose"].numpy()
+    store["input.keyframe_intrinsics"] = kbatch["keyframe_intrinsics"].numpy()
+    store["input.poses"] = torch.stack(kbatch["poses"]).numpy()
+    store["input.intrinsics"] = torch.stack(kbatch["intrinsics"]).numpy()
+    store["input.target"] = ktarget.numpy()
+    store["meta"] = np.array([1, 256, 512, 2, 32, -1, 1, 1], dtype=np.int64)
+    import model.metric_functions.sparse_metrics as ref_metrics0               # noqa
+    mvals = {fn: float(getattr(ref_metrics0, fn)({"result": out_ref["result"].clone(), "target": ktarget.clone()}, None, 80))
+             for fn in ("abs_rel_sparse_metric", "sq_rel_sparse_metric", "rmse_sparse_metric", "rmse_log_sparse_metric",
+                        "a1_sparse_metric", "a2_sparse_metric", "a3_sparse_metric")}
+    store["metrics"] = np.array([mvals[k] for k in sorted(mvals)], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLDEN, "kitti_example_169.npz"), **store)
+    report["cases"]["kitti_example_169"] = {"config": "example/test_monorec.py sample, seeded weights",
+                                            "oracle_vs_reference_maxabs": diffs, "reference_metrics": mvals}
+    print("kitti_example_169 ok; oracle == reference on", len(diffs), "tensors; target valid fraction",
+          float((ktarget > 0).float().mean()))
+
     # ---- sparse depth metrics: the real reference functions on seeded (prediction, target) pairs -------------
     import model.metric_functions.sparse_metrics as ref_metrics          # noqa: reference module (via ref_shims)
     metric_cases = {"default_eval": (2, 64, 96, 7, None, 80), "roi_no_maxdist": (3, 40, 72, 8, [4, 36, 8, 64], None),

@@ -69,6 +69,61 @@ def _resnet18(pretrained=False, **_):
     return _ResNet18()
 
 
+class _KittiOdometryStandIn:
+    """Just enough of `pykitti.odometry` (un-vendored pip dependency of the reference) for
+    data_loader/kitti_odometry_dataset.py to read the example sequence: calibration (P_rect_00/20 and baselines
+    from calib.txt), camera file lists / PIL readers and the pose file of `pose_path` (KITTI format: one
+    row-major 3x4 cam0->world matrix per line)."""
+
+    def __init__(self, base_path, sequence, **_):
+        import os
+        from collections import namedtuple
+        import numpy as np
+        self.sequence = sequence
+        self.sequence_path = os.path.join(str(base_path), "sequences", sequence)
+        self.pose_path = os.path.join(str(base_path), "poses")
+        rows = {}
+        with open(os.path.join(self.sequence_path, "calib.txt")) as f:
+            for line in f:
+                if ":" in line:
+                    k, v = line.split(":", 1)
+                    rows[k.strip()] = np.array([float(x) for x in v.split()])
+        p0, p1, p2, p3 = (rows[f"P{i}"].reshape(3, 4) for i in range(4))
+        calib = namedtuple("calib", "P_rect_00 P_rect_10 P_rect_20 P_rect_30 b_gray b_rgb")
+        self.calib = calib(p0, p1, p2, p3, -p1[0, 3] / p1[0, 0], (p2[0, 3] - p3[0, 3]) / p2[0, 0])
+        for cam, folder in ((0, "image_0"), (1, "image_1"), (2, "image_2"), (3, "image_3")):
+            d = os.path.join(self.sequence_path, folder)
+            files = sorted(os.path.join(d, n) for n in os.listdir(d)) if os.path.isdir(d) else []
+            setattr(self, f"cam{cam}_files", files)
+        self.poses = []
+        self._load_poses()
+
+    def _reader(self, cam):
+        from PIL import Image
+        return lambda idx: Image.open(getattr(self, f"cam{cam}_files")[idx])
+
+    def get_cam0(self, idx): return self._reader(0)(idx)
+    def get_cam2(self, idx): return self._reader(2)(idx)
+    def get_cam3(self, idx): return self._reader(3)(idx)
+
+    @property
+    def cam0(self): return (self.get_cam0(i) for i in range(len(self.cam0_files)))
+
+    @property
+    def cam2(self): return (self.get_cam2(i) for i in range(len(self.cam2_files)))
+
+    def _load_poses(self):
+        import os
+        import numpy as np
+        path = os.path.join(str(self.pose_path), self.sequence + ".txt")
+        self.poses = []
+        if os.path.exists(path):
+            for line in open(path):
+                v = np.array([float(x) for x in line.split()])
+                if v.size == 12:
+                    self.poses.append(np.vstack([v.reshape(3, 4), [0, 0, 0, 1]]))
+
+
 def _unavailable(name):
     def f(*a, **k):
         raise RuntimeError(f"{name} is a shim placeholder (training/augmentation only)")
@@ -103,9 +158,16 @@ def install():
         kg.camera, kg.depth = kgc, kgd
         sys.modules.update({"kornia": k, "kornia.augmentation": ka, "kornia.geometry": kg,
                             "kornia.geometry.camera": kgc, "kornia.geometry.depth": kgd})
-    for name in ("pykitti", "cv2"):
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    if "pykitti" not in sys.modules:
+        pk = types.ModuleType("pykitti")
+        pk.odometry = _KittiOdometryStandIn
+        sys.modules["pykitti"] = pk
+    import numpy as _np
+    for alias, typ in (("float", float), ("int", int)):     # removed numpy aliases the 2020 dataset code still uses
+        if not hasattr(_np, alias):
+            setattr(_np, alias, typ)
     if "skimage" not in sys.modules:
         sk = types.ModuleType("skimage")
         skt = types.ModuleType("skimage.transform")

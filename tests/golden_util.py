@@ -15,10 +15,27 @@ class Golden:
         self.seed, self.hard_pose, self.full_model = seed, bool(hard), bool(full)
 
     def names(self):
-        return sorted({k.rsplit(".", 1)[0] for k in self.z.files if k != "meta"})
+        return sorted({k.rsplit(".", 1)[0] for k in self.z.files if k not in ("meta", "metrics") and not k.startswith("input.")})
+
+    def target(self):
+        return torch.from_numpy(self.z["input.target"])
+
+    def reference_metrics(self):
+        names = sorted(["abs_rel_sparse_metric", "sq_rel_sparse_metric", "rmse_sparse_metric", "rmse_log_sparse_metric",
+                        "a1_sparse_metric", "a2_sparse_metric", "a3_sparse_metric"])
+        return dict(zip(names, [float(v) for v in self.z["metrics"]]))
 
     def make_inputs(self):
         from monorec_amd import synth
+        if "input.keyframe_u8" in self.z.files:      # real sample stored with the fixture (uint8 is lossless here)
+            z = self.z
+            img = lambda a: torch.from_numpy(a.astype(np.float32)) / 255 - .5      # kitti_odometry_dataset.py:127-128
+            return {"keyframe": img(z["input.keyframe_u8"]),
+                    "keyframe_pose": torch.from_numpy(z["input.keyframe_pose"]),
+                    "keyframe_intrinsics": torch.from_numpy(z["input.keyframe_intrinsics"]),
+                    "frames": [img(f) for f in z["input.frames_u8"]],
+                    "poses": [torch.from_numpy(p) for p in z["input.poses"]],
+                    "intrinsics": [torch.from_numpy(k) for k in z["input.intrinsics"]]}
         return synth.make_batch(self.batch, self.h, self.w, self.frames, seed=self.seed, hard_pose=self.hard_pose)
 
     def compare(self, name, tensor, atol, rtol=0.0, max_outlier_frac=0.0):

@@ -109,6 +109,33 @@ def test_c2_config_matches_reference_fixture_and_graph_replay(hip_lib):
     assert torch.equal(r_g, r_e)
 
 
+def test_reference_example_sample_with_metrics(hip_lib):
+    """The reference's own example (KITTI 07 / image 169, DVSO poses, lidar ground truth): forward + the seven sparse
+    metrics on device against what the reference model + reference metric functions produced for it."""
+    from monorec_amd import metrics
+    g = Golden("kitti_example_169")
+    batch = g.make_inputs()
+    model, sd = _model(g.depths, graph=False)
+    with torch.no_grad():
+        out = model(_to_dev(batch))
+    info = g.compare("result", out["result"], atol=RESULT_ATOL)
+    print("kitti example result vs reference fixture", info)
+    g.compare("cv_mask", out["cv_mask"], atol=1e-4)
+    for i in range(4):
+        g.compare(f"pred{i}", out["predicted_inverse_depths"][i], atol=RESULT_ATOL)
+    for i in range(5):
+        g.compare(f"feat{i}", out["image_features"][i], atol=2e-4, rtol=1e-4)
+    # real poses are far from the origin (|t| ~ 80 m): the reference's fp32 inverse(pose) @ pose cancellation makes
+    # the projection host-CPU dependent at the 1e-5 level, same tolerance as the synthetic hard-pose case
+    g.compare("cost_volume", out["cost_volume"], atol=2e-4, max_outlier_frac=5e-4)
+    for f in range(g.frames):
+        g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=1e-4, max_outlier_frac=5e-4)
+    data = {"result": out["result"], "target": g.target().to(DEV)}
+    for fn, want in g.reference_metrics().items():
+        got = float(getattr(metrics, fn)(data, None, 80))
+        assert abs(got - want) <= 5e-5 * max(1.0, abs(want)), (fn, got, want)
+
+
 def test_batch_independence(hip_lib):
     """Keyframes are independent: sample i of a batch equals the same sample run alone."""
     model, _ = _model(8, graph=False)

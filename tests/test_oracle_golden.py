@@ -42,6 +42,23 @@ def test_oracle_full_model_matches_reference_fixture(case):
         g.compare(f"pred{i}", t, atol=ATOL)
 
 
+def test_oracle_on_the_reference_example_sample():
+    """KITTI seq 07 image 169 (the reference's example/test_monorec.py sample, read through the reference's own
+    dataset class when the fixture was made): real images, DVSO poses (translation ~80 m), annotated lidar depth."""
+    g = Golden("kitti_example_169")
+    batch = g.make_inputs()
+    assert batch["keyframe"].shape == (1, 3, 256, 512) and len(batch["frames"]) == 2
+    model = MonoRecModel(cv_depth_steps=g.depths)
+    sd = synth.seeded_state_dict(model.state_dict(), seed=0)
+    out = orc.forward(sd, batch, cv_depth_steps=g.depths)
+    g.compare("result", out["result"], atol=1e-4)
+    g.compare("cv_mask", out["cv_mask"], atol=1e-4)
+    g.compare("cost_volume", out["cost_volume"], atol=2e-4, max_outlier_frac=5e-4)
+    got = orc.sparse_metrics(torch.from_numpy(g.z["result.full"]), g.target(), None, 80)
+    for k, want in g.reference_metrics().items():
+        assert abs(float(got[k]) - want) <= 2e-6 * max(1.0, abs(want)), (k, float(got[k]), want)
+
+
 def test_oracle_cost_volume_ragged_size():
     g = Golden("cv_only_ragged")
     cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths)

@@ -22,7 +22,9 @@
 // Epilogue: bias (eval-BatchNorm folded by the host), residual add, activation, scatter with an
 // output step/offset into a channel slice of the destination.  The four output parities of
 // ConvTranspose2d(k4,s2) run as four "phases" of ONE launch.  split_k > 1 writes raw partial sums to a
-// workspace; splitk_epilogue_kernel finishes them in a fixed order (deterministic, no atomics).
+// workspace; splitk_epilogue_kernel finishes them in a fixed order (deterministic, no atomics).  (Finishing
+// inside the launch - last workgroup of a tile to arrive sums the slices - was built and measured: the
+// device-scope release/acquire fences it needs write back / invalidate a whole XCD L2 each, +20 us per layer.)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -67,6 +69,7 @@ struct ConvKArgs {
     unsigned tiles_x_magic;    // floor(t / tiles_x) == (t * tiles_x_magic) >> 32 for t < 2^16
     int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores
     int ksplit, nchunks, batch, nphase;
+    int tiles_y, ngroups, total_wgs;
     long long wgroup_stride;   // packed floats per cout group
     float* ws;
     const float* w[4];         // per phase
@@ -84,15 +87,6 @@ __device__ __forceinline__ float mr_activate(float v, int act, float p0, float p
         }
         default: return v;
     }
-}
-
-__device__ __forceinline__ void mr_store_out(const ConvKArgs& a, int ph, int b, int cout, int oy, int ox, float v) {
-    if (a.bias) v += a.bias[cout];
-    const long long idx = (long long)b * a.dst_bstride +
-                          ((long long)(a.ch_off + cout) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
-                          (ox * a.ostep_w + a.ooff_w[ph]);
-    if (a.res) v += a.res[idx];
-    a.dst[idx] = mr_activate(v, a.act, a.p0, a.p1);
 }
 
 // Stage 16 channel planes of one tile position through a buffer descriptor: an offset of -1 is out of
@@ -177,6 +171,14 @@ __device__ __forceinline__ void dma_global_x1(unsigned lds_byte_addr, const floa
                  "global_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
 }
+// MR_CONV_DBG bit 16 (tools/wg_timeline.py): thread 0 of every workgroup drops 100 MHz timestamps into the workspace
+__device__ __forceinline__ void dbg_stamp(const ConvKArgs& a, int k) {
+    if ((a.dbg & 16) && threadIdx.x == 0) {
+        const long long wg = blockIdx.x;
+        ((unsigned long long*)a.ws)[wg * 12 + k] = k >= 9 ? clock64() : wall_clock64();
+    }
+}
+
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
@@ -211,16 +213,16 @@ __device__ __forceinline__ void cursor_advance(const ConvKArgs& a, ChunkCursor& 
 template <int MB, bool DMA_IN>
 __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCursor& c, float* ldsI, float* ldsW,
                                             unsigned ldsI_addr, unsigned ldsW_addr,
-                                            const float* wgrp, int b, int T, int lane, int wave, int HsWs,
+                                            const float* wgrp, int b, int T, int lane, int wave, int nwave, int HsWs,
                                             const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT],
                                             const int (&voff4)[MR_MAX_G4]) {
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
     const int wfloats = T * (ck >> 2) * MB * 64;
     const float* wsrc = wgrp + c.woff;
     const int n1k = (a.dbg & 4) ? 0 : wfloats >> 8;   // 1 KiB pieces (64 lanes x 16 B)
-    for (int kb = wave; kb < n1k; kb += 4) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
+    for (int kb = wave; kb < n1k; kb += nwave) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
     const int nfrag = (a.dbg & 4) ? 0 : wfloats >> 6; // tail: 256 B pieces (64 lanes x 4 B)
-    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += 4) dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane);
+    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += nwave) dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane);
 
     const int creal = a.src_c[c.s] - c.c0;                            // real (unpadded) channels left
     const int sbase_bytes = (b * a.src_c[c.s] + c.c0) * HsWs * 4;     // byte offset of channel c0 of sample b
@@ -229,7 +231,7 @@ __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCurso
         // one buffer_load_dwordx4 ... lds = 64 lanes x 16 B = up to 256 consecutive floats of one channel plane;
         // wave w streams channels w, w+4, ... of the chunk
         const i32x4 srd = make_srd(a.src[c.s], a.src_bytes[c.s]);
-        for (int cc = wave; cc < ck; cc += 4) {
+        for (int cc = wave; cc < ck; cc += nwave) {
             const unsigned lplane = ldsI_addr + cc * a.PLANE * 4;
             const int so = sbase_bytes + cc * HsWs * 4;
             const bool cok = cc < creal;
@@ -297,18 +299,26 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
 template <int MB, int NB, bool DMA_IN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    dbg_stamp(a, 0);
     // two pipeline buffers, each [CK][PLANE] input tile + [taps][ck4][MB][64] A fragments
     const int ioff = a.CK * a.PLANE;
     const int bufsz = ioff + a.wmax_floats;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+    // 1-D grid, tile fastest: consecutive workgroups go round-robin to the 8 XCDs, so the cout groups of one
+    // tile (ids a multiple of the tile count apart) meet on one XCD and share the input tile in its L2.
+    // (Renumbering XCD-major so that weight blocks are shared instead was measured: no change - the fills are
+    // latency bound, ~1.8 us per chunk from a cold L2, not fabric-bandwidth bound.)
+    const int wg = blockIdx.x;
+    const int tiles_total = a.tiles_x * a.tiles_y;
+    const int tile = wg % tiles_total;
+    const int gz = wg / tiles_total;
+    const int grp = gz % a.ngroups;
     const int ty = a.tiles_x == 1 ? tile : (int)(((unsigned long long)(unsigned)tile * a.tiles_x_magic) >> 32);   // tile / tiles_x
     const int tx = tile - ty * a.tiles_x;
-    const int grp = blockIdx.y;
     const int cb0 = grp * MB;
-    int z = blockIdx.z;
+    int z = gz / a.ngroups;
     const int ph = z % a.nphase; z /= a.nphase;
     const int ks = z % a.ksplit;
     const int b = z / a.ksplit;
@@ -375,46 +385,109 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     ChunkCursor cur = {0, 0, 0};
     for (int q = 0; q < q_lo; ++q) cursor_advance<MB>(a, cur, T);
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
-    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff, voff4);
+    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, 4, HsWs, goff, loff, voff4);
     dma_wait_all();
     __syncthreads();
+    dbg_stamp(a, 1);
     int pb = 0;
     for (int q = q_lo; q < q_hi; ++q) {
         const int ck4 = min(a.CK, a.src_cpad[cur.s] - cur.c0) >> 2;
         float* bcur = lds + pb * bufsz;
         float* bnxt = lds + (pb ^ 1) * bufsz;
         cursor_advance<MB>(a, cur, T);
+        const bool stamp = q == q_lo + 1 || (q == q_lo && q_hi == q_lo + 1);
+        if (stamp) { dbg_stamp(a, 4); dbg_stamp(a, 9); }
         if (q + 1 < q_hi) {
             const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
-            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, HsWs, goff, loff, voff4);
+            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, 4, HsWs, goff, loff, voff4);
         }
+        if (stamp) dbg_stamp(a, 5);
         if (!(a.dbg & 1)) sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
+        if (stamp) dbg_stamp(a, 6);
         dma_wait_all();                                // this wave's share of the next chunk has landed
+        if (stamp) dbg_stamp(a, 7);
         __syncthreads();                               // ... everyone's has, and everyone is done with this buffer
+        if (stamp) { dbg_stamp(a, 8); dbg_stamp(a, 10); }
         pb ^= 1;
     }
-
     // ---- epilogue: D fragment lane l holds pixel (l&15), couts (l>>4)*4 + r ---------------------
     const int CB16 = a.CB * 16;
+    dbg_stamp(a, 2);
+    if (a.dbg & 16) {                                  // stamp 3 = after this thread's stores were accepted
+        if (a.ksplit > 1) return;                      // (the workspace is the stamp buffer here)
+    }
     if (a.dbg & 8) { if (acc[0][0][0] != 123.456f) return; }
+    const int lq4 = (lane >> 4) * 4;
+    if (a.ksplit > 1) {                                // raw partial sums; splitk_epilogue_kernel finishes them
+        const long long plane = (long long)a.Ho * a.Wo;
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
+        for (int m = 0; m < MB; ++m) {
+            const int cout0 = (cb0 + m) * 16 + lq4;
+            if (cout0 >= CB16) continue;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
-            if (oy >= a.Ho || ox >= a.Wo) continue;
+            for (int i = 0; i < NB; ++i) {
+                const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
+                if (oy >= a.Ho || ox >= a.Wo) continue;
+                float* w = a.ws + ((((long long)ks * a.nphase + ph) * a.batch + b) * CB16 + cout0) * plane + (long long)oy * a.Wo + ox;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r * plane] = acc[m][i][r];
+            }
+        }
+        return;
+    }
+    {
+        // bias / residual operands are fetched in batches ahead of the stores that need them: a load issued
+        // between two stores would wait out a full memory round trip per output element
+        const long long chs = (long long)a.dst_H * a.dst_W;
+        float bias[MB][4];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int cout = (cb0 + m) * 16 + (lane >> 4) * 4 + r;
-                if (a.ksplit > 1) {
-                    if (cout < CB16)
-                        a.ws[(((((long long)ks * a.nphase + ph) * a.batch + b) * CB16 + cout) * a.Ho + oy) * a.Wo + ox] = acc[m][i][r];
-                } else if (cout < a.Cout) {
-                    mr_store_out(a, ph, b, cout, oy, ox, acc[m][i][r]);
-                }
+                const int cout = (cb0 + m) * 16 + lq4 + r;
+                bias[m][r] = (a.bias && cout < a.Cout) ? a.bias[cout] : 0.f;
+            }
+        const long long bbase = (long long)b * a.dst_bstride;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int cout0 = (cb0 + m) * 16 + lq4;
+            long long idx0[NB];
+            float rv[NB][4];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
+                const bool ok = oy < a.Ho && ox < a.Wo;
+                idx0[i] = ok ? bbase + ((long long)(a.ch_off + cout0) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
+                                   (ox * a.ostep_w + a.ooff_w[ph])
+                             : -1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rv[i][r] = (a.res && ok && cout0 + r < a.Cout) ? a.res[idx0[i] + r * chs] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (idx0[i] < 0) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cout0 + r < a.Cout) {
+                        float v = acc[m][i][r];
+                        if (a.bias) v += bias[m][r];
+                        if (a.res) v += rv[i][r];
+                        a.dst[idx0[i] + r * chs] = mr_activate(v, a.act, a.p0, a.p1);
+                    }
             }
         }
     }
+    if (a.dbg & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(a, 3); }
+}
+
+__device__ __forceinline__ void mr_store_out(const ConvKArgs& a, int ph, int b, int cout, int oy, int ox, float v) {
+    if (a.bias) v += a.bias[cout];
+    const long long idx = (long long)b * a.dst_bstride +
+                          ((long long)(a.ch_off + cout) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
+                          (ox * a.ostep_w + a.ooff_w[ph]);
+    if (a.res) v += a.res[idx];
+    a.dst[idx] = mr_activate(v, a.act, a.p0, a.p1);
 }
 
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvKArgs a) {
@@ -456,7 +529,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     if (d->out_h < 1 || d->out_w < 1 || d->out_channels < 1 || !d->dst) return MR_ERR_BAD_ARGUMENT;
     const int mb = d->cout_blocks_per_wg, nb = d->pixel_blocks_per_wave;
     if (!valid_mb(mb) || !(nb == 1 || nb == 2 || nb == 4) || !valid_ck(d->chunk_channels)) return MR_ERR_BAD_ARGUMENT;
-    if (d->split_k < 1 || (d->split_k > 1 && !d->workspace)) return MR_ERR_BAD_ARGUMENT;
+    if (d->split_k < 1) return MR_ERR_BAD_ARGUMENT;
     const int nphase = d->num_phases <= 1 ? 1 : d->num_phases;
     if (nphase != 1 && nphase != 4) return MR_ERR_BAD_ARGUMENT;
     ConvKArgs& k = out->k;
@@ -548,15 +621,21 @@ int derive(const mr_conv_desc* d, Derived* out) {
         if (c > ck_max) ck_max = c;
     }
     k.wmax_floats = taps * (ck_max / 4) * mb * 64;
-    out->lds_bytes = 2 * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);   // double buffered
+    // two pipeline buffers - one when no workgroup ever streams a second chunk
+    const int nbuf = mr_ceil_div(nchunks, d->split_k) > 1 ? 2 : 1;
+    out->lds_bytes = nbuf * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
     k.gpr_magic = 65536u / (unsigned)(k.IWa >> 2 > 0 ? k.IWa >> 2 : 1) + 1u;
     k.tiles_x_magic = k.tiles_x == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;   // (1 would overflow)
     if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb;
-    out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)mr_ceil_div(k.CB, mb),
-                     (unsigned)(d->batch * d->split_k * nphase));
+    k.tiles_y = tiles_y;
+    k.ngroups = mr_ceil_div(k.CB, mb);
+    const long long total = (long long)k.tiles_x * tiles_y * k.ngroups * d->batch * d->split_k * nphase;
+    if (total >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
+    k.total_wgs = (int)total;
+    out->grid = dim3((unsigned)total);
     return 0;
 }
 
@@ -644,6 +723,7 @@ extern "C" int mr_conv2d_f32(const mr_conv_desc* desc, void* stream_) {
     Derived dv;
     int rc = derive(desc, &dv);
     if (rc != 0) return rc;
+    if (desc->split_k > 1 && !desc->workspace) return MR_ERR_BAD_ARGUMENT;
     hipStream_t stream = (hipStream_t)stream_;
     switch (dv.mb) {
         case 1: rc = launch_nb<1>(dv, stream); break;

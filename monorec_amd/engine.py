@@ -98,10 +98,13 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb):
                 tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
 
 
-def lds_bytes(geo, taps, cpads, mb, ck):
-    """Dynamic LDS of one workgroup: two pipeline buffers of (input tile + A fragments of the largest chunk)."""
+def lds_bytes(geo, taps, cpads, mb, ck, split_k=1):
+    """Dynamic LDS of one workgroup: pipeline buffers of (input tile + A fragments of the largest chunk) - two,
+    or one when no workgroup streams a second chunk (mirrors derive() in csrc/conv_mfma.hip)."""
     ck_max = max(min(c, ck) for c in cpads)
-    return 2 * 4 * (ck * geo["plane"] + taps * (ck_max // 4) * mb * 64)
+    nchunks = sum(math.ceil(c / ck) for c in cpads)
+    nbuf = 2 if math.ceil(nchunks / split_k) > 1 else 1
+    return nbuf * 4 * (ck * geo["plane"] + taps * (ck_max // 4) * mb * 64)
 
 
 TUNED = {}          # signature -> (mb, nb, split_k, ck); filled from tuned_schedules.json when present
@@ -140,16 +143,16 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
             for ck in (8, 16, 32, 64):
                 if ck > 16 and ck // 2 >= max(cpads):
                     continue
-                if lds_bytes(geo, taps, cpads, mb, ck) > lds_cap:
-                    continue
                 nchunks = sum(math.ceil(c / ck) for c in cpads)
                 wgs = geo["tiles"] * groups * batch * phases
                 for sk in (1, 2, 4, 8, 16):
                     if sk > nchunks:
                         break
+                    lds = lds_bytes(geo, taps, cpads, mb, ck, sk)
+                    if lds > lds_cap:
+                        continue
                     out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, wgs=wgs * sk, nchunks=nchunks,
-                                    eff=geo["tile_eff"] * cb / (groups * mb),
-                                    lds=lds_bytes(geo, taps, cpads, mb, ck)))
+                                    eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
     return out
 
 
@@ -211,7 +214,7 @@ class Plan:
         return cls(state or {}, 1, 32, 32, 1, 4, (0.33, 0.0025), device, schedule_override=schedule_override, build=False)
 
     def finalize(self):
-        """Allocate the shared split-K workspace once all launches are known."""
+        """Allocate the per-stage split-K workspace once all launches are known."""
         for stage, floats in self._ws_floats.items():
             self.buf[f"splitk_workspace.{stage}"] = torch.empty(max(floats, 4), dtype=torch.float32, device=self.device)
         for stage, desc in self._pending_ws:

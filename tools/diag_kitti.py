@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Diagnostic (GPU box): HIP model vs local-CPU oracle vs committed reference outputs on the KITTI example sample."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_util import Golden
+from monorec_amd import synth
+from monorec_amd.model import MonoRecModel
+from oracle import monorec_oracle as orc
+
+g = Golden(sys.argv[1] if len(sys.argv) > 1 else "kitti_example_169")
+batch = g.make_inputs()
+m = MonoRecModel(cv_depth_steps=g.depths, hip_in_flight=1)
+sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+m.load_state_dict(sd); m = m.to("cuda:0").eval()
+with torch.no_grad():
+    out = m(synth.clone_batch(batch, "cuda:0"))
+torch.cuda.synchronize()
+ref = orc.forward(sd, batch, cv_depth_steps=g.depths)
+
+
+def flat(o):
+    d = {"result": o["result"], "cv_mask": o["cv_mask"], "cost_volume": o["cost_volume"]}
+    for i, t in enumerate(o["single_frame_cvs"]): d[f"sfcv{i}"] = t
+    for i, t in enumerate(o["image_features"]): d[f"feat{i}"] = t
+    for i, t in enumerate(o["predicted_inverse_depths"]): d[f"pred{i}"] = t
+    return {k: v.detach().cpu().float() for k, v in d.items()}
+
+
+H, O = flat(out), flat(ref)
+for k in H:
+    stride = int(g.z[k + ".stride"])
+    if (k + ".full") in g.z.files:
+        want = torch.from_numpy(g.z[k + ".full"]).reshape(-1); h = H[k].reshape(-1); o = O[k].reshape(-1)
+    else:
+        want = torch.from_numpy(g.z[k + ".samples"]); h = H[k].reshape(-1)[::stride]; o = O[k].reshape(-1)[::stride]
+    st = lambda d: "max %.2e p99 %.2e frac>1e-4 %.2e" % (d.max(), np.percentile(d.numpy(), 99), (d > 1e-4).float().mean())
+    print(f"{k:12s} hip-fixture {st((h - want).abs())} | oracle_here-fixture {st((o - want).abs())} | hip-oracle_here {st((H[k] - O[k]).abs().reshape(-1))}")
+# unmasked cost volume straight from the kernels vs local oracle
+cvo, sfo = orc.cost_volume(batch, steps=g.depths)
+print("mask mean", float(H["cv_mask"].mean()), "oracle", float(O["cv_mask"].mean()))

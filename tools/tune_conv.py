@@ -35,6 +35,30 @@ def time_op(fn, reps=5, warm=2):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def time_op_streams(fn, streams, reps=5, warm=2):
+    """Per-launch time with the same launch repeated round-robin on several streams: what a layer costs when
+    keyframes are in flight side by side (head / tail bubbles of one launch filled by the other)."""
+    base = torch.cuda.current_stream()
+    for s in streams:
+        for _ in range(warm):
+            fn(s.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(base)
+    for s in streams:
+        s.wait_event(e0)
+    for _ in range(reps):
+        for s in streams:
+            fn(s.cuda_stream)
+    for s in streams:
+        e = torch.cuda.Event()
+        e.record(s)
+        base.wait_event(e)
+    e1.record(base)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (reps * len(streams))
+
+
 def build_candidate(spec, sched, tensors):
     plan = engine.Plan.bare(DEV, schedule_override={"t": sched})
     srcs, out, res, weight, bias, phase_w = tensors
@@ -57,6 +81,9 @@ def main():
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--merge", action="store_true", help="keep entries already in the table for other shapes")
     ap.add_argument("--max-cands", type=int, default=90)
+    ap.add_argument("--streams", type=int, default=1, help="time each candidate on this many concurrent streams")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--lds-cap", type=int, default=80 * 1024)
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
@@ -71,6 +98,7 @@ def main():
     report = []
     t_start = time.time()
     seen = set()
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
     g = torch.Generator().manual_seed(0)
     for c in plan.conv_log:
         if c["sig"] is None or c["sig"] in seen:
@@ -81,7 +109,7 @@ def main():
         src_channels = [s[1] for s in spec["src_shapes"]]
         nph = 1 if spec["phases"] is None else len(spec["phases"])
         cands = engine.candidate_schedules(cout, src_channels, kh, kw, spec["stride"][0], spec["stride"][1],
-                                           spec["grid"][0], spec["grid"][1], c["batch"], nph)
+                                           spec["grid"][0], spec["grid"][1], c["batch"], nph, lds_cap=args.lds_cap)
         # prune: split-K only while the launch is short of ~8 workgroups per CU; drop tiny grids
         keep = []
         for cd in cands:
@@ -105,7 +133,7 @@ def main():
             sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"])
             try:
                 p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w))
-                t = time_op(fn)
+                t = time_op(fn, reps=args.reps) if args.streams <= 1 else time_op_streams(fn, streams, reps=args.reps)
             except RuntimeError as e:
                 rows.append((sched, None, str(e)[:60]))
                 continue

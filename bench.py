@@ -75,7 +75,7 @@ def time_layers(model, batch_dev, plan_key, reps=5):
     for (name, _), t in zip(ops, acc):
         c = macs.get(name)
         rows.append({"name": name, "seconds": t, "macs": c["macs"] if c else 0,
-                     "sched": [c["mb"], c["nb"], c["split_k"]] if c else None, "wgs": c["wgs"] if c else None,
+                     "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4)] if c else None, "wgs": c["wgs"] if c else None,
                      "tflops": (2 * c["macs"] / t / 1e12) if c and t > 0 else None})
     return rows
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 1
+#define MR_ABI_VERSION 2
 
 #define MR_ERR_BAD_ARGUMENT (-1)
 #define MR_ERR_UNSUPPORTED  (-2)
@@ -105,6 +105,11 @@ typedef struct mr_conv_desc {
     int32_t num_phases;
     const float* phase_weights[4];
     int32_t phase_pad_top[4], phase_pad_left[4], phase_out_off_h[4], phase_out_off_w[4];
+    /* schedule, continued: waves per workgroup, 4 (0 = default) or 8.  8 waves share one LDS tile of twice the
+     * rows: same LDS and DMA traffic per output as 4 waves with 2x pixel_blocks_per_wave, but two waves per
+     * SIMD from every workgroup, which hides the chunk-fill stalls.  8 needs the direct-read dwordx4 path
+     * (in_mode DIRECT, no in_transform, src_w % 4 == 0); otherwise MR_ERR_UNSUPPORTED. */
+    int32_t waves_per_wg;
 } mr_conv_desc;
 
 /* number of floats of the packed weight image for a conv with the given source split and schedule

@@ -50,6 +50,7 @@ class ConvDesc(ctypes.Structure):
         ("phase_weights", ctypes.c_void_p * 4),
         ("phase_pad_top", ctypes.c_int32 * 4), ("phase_pad_left", ctypes.c_int32 * 4),
         ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4),
+        ("waves_per_wg", ctypes.c_int32),
     ]
 
 
@@ -104,7 +105,7 @@ def load():
             raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 1:
+    if lib.mr_abi_version() != 2:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

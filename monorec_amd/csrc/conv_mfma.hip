@@ -67,7 +67,8 @@ struct ConvKArgs {
     int xsh[4];                // per phase: columns between the aligned tile origin and the first tap column
     unsigned gpr_magic;        // floor(r / (IWa/4)) == (r * gpr_magic) >> 16 for r < 256 (dma_x4 prologue)
     unsigned tiles_x_magic;    // floor(t / tiles_x) == (t * tiles_x_magic) >> 32 for t < 2^16
-    int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores
+    int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores,
+                               // 16 per-workgroup timestamps (tools/wg_timeline.py)
     int ksplit, nchunks, batch, nphase;
     int tiles_y, ngroups, total_wgs;
     long long wgroup_stride;   // packed floats per cout group
@@ -277,6 +278,16 @@ template <int MB, int NB>
 __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
                                             const int (&lbase)[NB], int ck4, int lane) {
     const float* wl = ldsW + lane;
+    // MB = NB = 1 has a single accumulator: every MFMA waits for the previous one to retire.  Two partial sums
+    // (even / odd channel quads) keep two MFMAs in flight; they are added once per chunk.
+    constexpr bool DUAL = MB * NB == 1;
+    f32x4 acc2[MB][NB];
+    if (DUAL) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc2[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int kh = 0; kh < a.KH; ++kh) {
         for (int kw = 0; kw < a.KW; ++kw) {
             const int tapoff = kh * a.IWa + kw;
@@ -284,20 +295,26 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
             int c4 = 0;
             for (; c4 + 4 <= ck4; c4 += 4) {          // manual 4x unroll: LDS reads of 4 k-steps overlap
                 kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
-                kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 1, (c4 + 1) * 4 * a.PLANE + tapoff);
+                kstep<MB, NB>(DUAL ? acc2 : acc, wt, ldsI, lbase, c4 + 1, (c4 + 1) * 4 * a.PLANE + tapoff);
                 kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 2, (c4 + 2) * 4 * a.PLANE + tapoff);
-                kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 3, (c4 + 3) * 4 * a.PLANE + tapoff);
+                kstep<MB, NB>(DUAL ? acc2 : acc, wt, ldsI, lbase, c4 + 3, (c4 + 3) * 4 * a.PLANE + tapoff);
             }
             for (; c4 < ck4; ++c4) kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
         }
+    }
+    if (DUAL) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc[m][i] += acc2[m][i];
     }
 }
 
 // DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
 // max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
 // make hipcc drain vmcnt before every sweep and spill SGPRs).
-template <int MB, int NB, bool DMA_IN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
+template <int MB, int NB, bool DMA_IN, int WV>
+__global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     dbg_stamp(a, 0);
     // two pipeline buffers, each [CK][PLANE] input tile + [taps][ck4][MB][64] A fragments
@@ -385,7 +402,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     ChunkCursor cur = {0, 0, 0};
     for (int q = 0; q < q_lo; ++q) cursor_advance<MB>(a, cur, T);
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
-    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, 4, HsWs, goff, loff, voff4);
+    dbg_stamp(a, 11);                                  // setup done, first DMA goes out
+    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
     dma_wait_all();
     __syncthreads();
     dbg_stamp(a, 1);
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         if (stamp) { dbg_stamp(a, 4); dbg_stamp(a, 9); }
         if (q + 1 < q_hi) {
             const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
-            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, 4, HsWs, goff, loff, voff4);
+            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
         }
         if (stamp) dbg_stamp(a, 5);
         if (!(a.dbg & 1)) sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
@@ -515,7 +533,7 @@ namespace {
 struct Derived {
     ConvKArgs k;
     size_t lds_bytes;
-    int mb, nb;
+    int mb, nb, wv;
     dim3 grid;
 };
 
@@ -528,6 +546,8 @@ int derive(const mr_conv_desc* d, Derived* out) {
     if (d->stride_w > 2) return MR_ERR_UNSUPPORTED;
     if (d->out_h < 1 || d->out_w < 1 || d->out_channels < 1 || !d->dst) return MR_ERR_BAD_ARGUMENT;
     const int mb = d->cout_blocks_per_wg, nb = d->pixel_blocks_per_wave;
+    const int wv = d->waves_per_wg == 0 ? 4 : d->waves_per_wg;
+    if (wv != 4 && wv != 8) return MR_ERR_BAD_ARGUMENT;
     if (!valid_mb(mb) || !(nb == 1 || nb == 2 || nb == 4) || !valid_ck(d->chunk_channels)) return MR_ERR_BAD_ARGUMENT;
     if (d->split_k < 1) return MR_ERR_BAD_ARGUMENT;
     const int nphase = d->num_phases <= 1 ? 1 : d->num_phases;
@@ -586,7 +606,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.bias = d->bias; k.res = d->residual;
     k.act = d->activation; k.p0 = d->act_p0; k.p1 = d->act_p1;
     k.TWB = d->out_w >= 32 ? 2 : 1;
-    k.TH = 4 * nb / k.TWB;
+    k.TH = wv * nb / k.TWB;
     k.tiles_x = mr_ceil_div(d->out_w, k.TWB * 16);
     const int tiles_y = mr_ceil_div(d->out_h, k.TH);
     k.IH = (k.TH - 1) * k.SH + k.KH;
@@ -607,8 +627,8 @@ int derive(const mr_conv_desc* d, Derived* out) {
     else { plane |= 1; }
     k.PLANE = plane;
     k.ppt = mr_ceil_div(k.IH * k.IWa, 256);
-    if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED;
     k.g4pt = mr_ceil_div(k.IH * (k.IWa >> 2), 64);
+    if (!(k.dma_x4 && k.g4pt <= MR_MAX_G4) && k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED;   // per-position staging only
     if (k.dma_x4 && k.g4pt > MR_MAX_G4) { k.dma_x4 = 0; k.IWa = k.IW; for (int p = 0; p < 4; ++p) k.xsh[p] = 0;
         plane = k.IH * k.IW; if (k.SW == 1) { while ((plane & 31) != 16) ++plane; } else { plane |= 1; }
         k.PLANE = plane; k.ppt = mr_ceil_div(k.IH * k.IW, 256); if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED; }
@@ -629,7 +649,8 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.tiles_x_magic = k.tiles_x == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;   // (1 would overflow)
     if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
-    out->mb = mb; out->nb = nb;
+    out->mb = mb; out->nb = nb; out->wv = wv;
+    if (wv == 8 && !k.dma_x4) return MR_ERR_UNSUPPORTED;
     k.tiles_y = tiles_y;
     k.ngroups = mr_ceil_div(k.CB, mb);
     const long long total = (long long)k.tiles_x * tiles_y * k.ngroups * d->batch * d->split_k * nphase;
@@ -639,32 +660,39 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB, bool DMA_IN>
+template <int MB, int NB, bool DMA_IN, int WV>
 int launch(const Derived& dv, hipStream_t stream) {
     static bool attr_set = false;  // raise the dynamic-LDS ceiling once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN>), dv.grid, dim3(256), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
 template <int MB>
 int launch_nb(const Derived& dv, hipStream_t stream) {
+    if (dv.wv == 8) {                                  // dwordx4 DMA path only (derive() checked)
+        switch (dv.nb) {
+            case 1: return launch<MB, 1, true, 8>(dv, stream);
+            case 2: return launch<MB, 2, true, 8>(dv, stream);
+            default: return launch<MB, 4, true, 8>(dv, stream);
+        }
+    }
     if (dv.k.dma_in) {
         switch (dv.nb) {
-            case 1: return launch<MB, 1, true>(dv, stream);
-            case 2: return launch<MB, 2, true>(dv, stream);
-            default: return launch<MB, 4, true>(dv, stream);
+            case 1: return launch<MB, 1, true, 4>(dv, stream);
+            case 2: return launch<MB, 2, true, 4>(dv, stream);
+            default: return launch<MB, 4, true, 4>(dv, stream);
         }
     }
     switch (dv.nb) {
-        case 1: return launch<MB, 1, false>(dv, stream);
-        case 2: return launch<MB, 2, false>(dv, stream);
-        default: return launch<MB, 4, false>(dv, stream);
+        case 1: return launch<MB, 1, false, 4>(dv, stream);
+        case 2: return launch<MB, 2, false, 4>(dv, stream);
+        default: return launch<MB, 4, false, 4>(dv, stream);
     }
 }
 

@@ -81,10 +81,10 @@ def transposed_phase_weights(wt):
     return out
 
 
-def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb):
-    """Tile geometry used by mr_conv2d_f32 for a given NB (mirrors derive() in csrc/conv_mfma.hip)."""
+def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4):
+    """Tile geometry used by mr_conv2d_f32 for a given NB / waves per workgroup (mirrors derive() in csrc/conv_mfma.hip)."""
     twb = 2 if out_w >= 32 else 1
-    th = 4 * nb // twb
+    th = waves * nb // twb
     ih, iw = (th - 1) * sh + kh, (twb * 16 - 1) * sw + kw
     iw = (iw + 3 + 3) // 4 * 4          # upper bound: 4-aligned superset used by the dwordx4 DMA path
     plane = ih * iw
@@ -107,7 +107,7 @@ def lds_bytes(geo, taps, cpads, mb, ck, split_k=1):
     return nbuf * 4 * (ck * geo["plane"] + taps * (ck_max // 4) * mb * 64)
 
 
-TUNED = {}          # signature -> (mb, nb, split_k, ck); filled from tuned_schedules.json when present
+TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
 
 
 def _load_tuned():
@@ -132,27 +132,30 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
     cpads = [(c + 3) // 4 * 4 for c in src_channels]
     taps = kh * kw
     out = []
-    for nb in (4, 2, 1):
-        geo = conv_geometry(out_h, out_w, kh, kw, sh, sw, nb)
-        if geo["ppt"] > 6:
-            continue
-        for mb in (6, 4, 3, 2, 1):
-            if mb > cb and mb != 1:
+    for waves in (4, 8):
+        for nb in (4, 2, 1):
+            geo = conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves)
+            if waves == 4 and geo["ppt"] > 6:
                 continue
-            groups = math.ceil(cb / mb)
-            for ck in (8, 16, 32, 64):
-                if ck > 16 and ck // 2 >= max(cpads):
+            if waves == 8 and geo["ih"] * (geo["iw"] // 4) > 256:      # dwordx4 groups per lane <= 4
+                continue
+            for mb in (6, 4, 3, 2, 1):
+                if mb > cb and mb != 1:
                     continue
-                nchunks = sum(math.ceil(c / ck) for c in cpads)
-                wgs = geo["tiles"] * groups * batch * phases
-                for sk in (1, 2, 4, 8, 16):
-                    if sk > nchunks:
-                        break
-                    lds = lds_bytes(geo, taps, cpads, mb, ck, sk)
-                    if lds > lds_cap:
+                groups = math.ceil(cb / mb)
+                for ck in (8, 16, 32, 64):
+                    if ck > 16 and ck // 2 >= max(cpads):
                         continue
-                    out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, wgs=wgs * sk, nchunks=nchunks,
-                                    eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
+                    nchunks = sum(math.ceil(c / ck) for c in cpads)
+                    wgs = geo["tiles"] * groups * batch * phases
+                    for sk in (1, 2, 4, 8, 16):
+                        if sk > nchunks:
+                            break
+                        lds = lds_bytes(geo, taps, cpads, mb, ck, sk)
+                        if lds > lds_cap:
+                            continue
+                        out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, wgs=wgs * sk, nchunks=nchunks,
+                                        eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
     return out
 
 
@@ -165,6 +168,8 @@ def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, pha
         return TUNED[sig]
     best = None
     for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=80 * 1024):
+        if c["waves"] != 4:          # 8-wave workgroups only through the measured table
+            continue
         reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
         fill = min(1.0, c["wgs"] / 768.0)
         per_wg_steps = c["nchunks"] / c["split_k"]
@@ -257,7 +262,8 @@ class Plan:
         nph = 1 if phases is None else len(phases)
         sched = self.schedule_override.get(name) or choose_schedule(cout, src_channels, kh, kw, stride[0], stride[1],
                                                                     out_h, out_w, n, nph)
-        mb, nb, split_k, ck = sched
+        mb, nb, split_k, ck = sched[:4]
+        waves = sched[4] if len(sched) > 4 else 4
         d = ConvDesc()
         for i, s in enumerate(srcs):
             d.src[i] = s.data_ptr()
@@ -285,6 +291,7 @@ class Plan:
             d.residual = residual.data_ptr()
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
+        d.waves_per_wg = waves
         if split_k > 1:
             self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
                                          split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
@@ -294,9 +301,9 @@ class Plan:
         if lds < 0:
             _lib.check(int(lds), f"plan {name} sched={sched}")
         macs = nph * n * out_h * out_w * cout * cin * kh * kw
-        geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb)
+        geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves)
         wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
-        self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, ck=ck, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
                                   sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph),
                                   spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),

@@ -60,6 +60,12 @@ CONV_CASES = [
     ((256,), 1, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 1, 8, 32)),
     ((512,), 512, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 4, 32)),
     ((32,), 24, (3, 3), (1, 1), (1, 1), (24, 40), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 4, 1, 16)),
+    # 8 waves per workgroup (fifth schedule entry): ragged sizes, residual, split-K, stride 2, concatenated sources
+    ((32,), 48, (3, 3), (1, 1), (1, 1), (40, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 4, 1, 8, 8)),
+    ((64,), 64, (3, 3), (1, 1), (1, 1), (20, 24), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 1, 1, 32, 8)),
+    ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 2, 4, 16, 8)),
+    ((64,), 128, (3, 3), (2, 2), (1, 1), (32, 64), 1, ACT_RELU, IN_DIRECT, TF_NONE, False, (2, 1, 1, 8, 8)),
+    ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (4, 1, 1, 16, 8)),
 ]
 
 

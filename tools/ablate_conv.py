@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         res_t = torch.randn(*spec["out_shape"], generator=g).cuda() if spec["residual"] else None
         w = torch.randn(cout, cin, kh, kw, generator=g) * 0.05; b = torch.randn(cout, generator=g)
         pw = [torch.randn(cout, cin, kh, kw, generator=g) * 0.05 for _ in range(nph)] if nph > 1 else None
-        sched = (c["mb"], c["nb"], c["split_k"], c["ck"])
+        sched = (c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4))
         p, fn = build_candidate(spec, sched, (srcs, out, res_t, w if nph == 1 else None, b, pw))
         res[c["name"]] = time_op(fn, reps=20, warm=3) * 1e6
     print("RESULT " + json.dumps(res))

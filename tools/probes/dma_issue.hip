@@ -12,10 +12,10 @@
 constexpr int N = 16;
 typedef float f4 __attribute__((ext_vector_type(4)));
 // cold variant: every workgroup streams its own never-touched 64 KiB x rounds from a 4 GiB buffer (L2 and MALL miss)
-__global__ __launch_bounds__(256) void kcold(const float* src, unsigned long long* out, int rounds, size_t wg_stride_floats) {
+__global__ __launch_bounds__(256) void kcold(const float* src, unsigned long long* out, int rounds, size_t wg_stride_floats, size_t istride, size_t rstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* g = src + (size_t)blockIdx.x * wg_stride_floats + wave * N * 256 + lane * 4;
+    const float* g = src + (size_t)blockIdx.x * wg_stride_floats + wave * N * istride + lane * 4;
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds + wave * N * 1024);
     __syncthreads();
     const unsigned long long c0 = clock64();
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void kcold(const float* src, unsigned long lon
         for (int i = 0; i < N; ++i) {
             unsigned keep;
             asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(lbase + i * 1024), "v"(g + (size_t)r * 4 * N * 256 + i * 256) : "memory");
+                         : "=&s"(keep) : "s"(lbase + i * 1024), "v"(g + (size_t)r * rstride + i * istride) : "memory");
         }
         iss += clock64() - a0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -98,21 +98,27 @@ int main() {
         if (hipMalloc(&big, bytes) == hipSuccess) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&kcold), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             unsigned long long* o2; hipMalloc(&o2, 1024 * 8 * 4 * 8);
-            const int rounds = 8;
-            size_t off = 0;
-            for (int wgs : {32, 64, 128, 256, 512}) {
-                const size_t stride = (size_t)rounds * 4 * N * 256;          // floats per workgroup
-                kcold<<<wgs, 256, 4 * N * 1024, 0>>>(big + off, o2, rounds, stride);
+            const int rounds = 4;
+            for (int mode = 0; mode < 3; ++mode)
+            for (int wgs : {128, 256}) {
+                // mode 0: each instruction 1 KiB contiguous after the previous (one page per workgroup round)
+                // mode 1: every instruction in its own 512 KiB region (a conv tile row block of another channel plane)
+                // mode 2: every instruction in its own 2 MiB + 4 KiB region
+                const size_t istride = mode == 0 ? 256 : (mode == 1 ? (512u << 10) / 4 : ((2u << 20) + 4096) / 4);
+                const size_t wgstride = mode == 0 ? (size_t)rounds * 4 * N * 256 : 1024;      // tiles of one plane
+                const size_t rstride = mode == 0 ? (size_t)4 * N * 256 : (size_t)4 * N * istride;
+                const size_t need = (size_t)rounds * rstride + (size_t)wgs * wgstride + 4 * N * istride;
+                if (need * 4 > bytes) { printf("skip mode %d\n", mode); continue; }
+                kcold<<<wgs, 256, 4 * N * 1024, 0>>>(big, o2, rounds, wgstride, istride, rstride);
                 hipDeviceSynchronize();
-                off += (size_t)wgs * stride;
                 std::vector<unsigned long long> h(wgs * 8 * 4);
                 hipMemcpy(h.data(), o2, h.size() * 8, hipMemcpyDeviceToHost);
                 std::vector<double> iss, tot;
                 for (int b = 0; b < wgs; ++b) for (int w = 0; w < 4; ++w) { iss.push_back((double)h[(b * 8 + w) * 4]); tot.push_back((double)h[(b * 8 + w) * 4 + 1]); }
                 std::sort(iss.begin(), iss.end()); std::sort(tot.begin(), tot.end());
                 const double clk = tot[tot.size() / 2], bytes_wg = rounds * 4.0 * N * 1024;
-                printf("cold  %3d WGs x 4 waves, %d rounds of 64 KiB: issue %.0f clk/round/wave (%.0f per instr), round trip %.0f clk/round -> %.1f B/clk/WG, ~%.2f TB/s total at 2.1 GHz\n",
-                       wgs, rounds, iss[iss.size() / 2] / rounds, iss[iss.size() / 2] / rounds / N, clk / rounds, bytes_wg / clk, wgs * bytes_wg / clk * 2.1e9 / 1e12);
+                printf("cold mode %d %3d WGs x 4 waves, %d rounds of 64 KiB: issue %.0f clk/round/wave (%.0f per instr), round trip %.0f clk/round -> %.1f B/clk/WG\n",
+                       mode, wgs, rounds, iss[iss.size() / 2] / rounds, iss[iss.size() / 2] / rounds / N, clk / rounds, bytes_wg / clk);
             }
         } else printf("cold: hipMalloc failed\n");
     }

@@ -130,7 +130,7 @@ def main():
         best = None
         rows = []
         for cd in keep:
-            sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"])
+            sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"], cd["waves"])
             try:
                 p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w))
                 t = time_op(fn, reps=args.reps) if args.streams <= 1 else time_op_streams(fn, streams, reps=args.reps)

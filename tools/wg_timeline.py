@@ -6,7 +6,7 @@ import json
 import os
 import sys
 
-os.environ["MR_CONV_DBG"] = "16"
+os.environ["MR_CONV_DBG"] = os.environ.get("MR_TL_DBG", "16")
 import numpy as np
 import torch
 
@@ -39,7 +39,7 @@ def main():
         w = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
         b = torch.randn(cout, generator=g)
         pw = [torch.randn(cout, cin, kh, kw, generator=g) * 0.05 for _ in range(nph)] if nph > 1 else None
-        sched = (c["mb"], c["nb"], 1, c["ck"])          # stamps live in the workspace: split_k forced to 1
+        sched = (c["mb"], c["nb"], 1, c["ck"], c.get("waves", 4))          # stamps live in the workspace: split_k forced to 1
         p, fn = build_candidate(spec, sched, (srcs, out, res_t, w if nph == 1 else None, b, pw))
         desc = [k for k in p.keep if isinstance(k, _lib.ConvDesc)][0]
         wgs = p.conv_log[0]["wgs"]
@@ -62,7 +62,7 @@ def main():
         rows[c["name"]] = dict(sched=sched, wgs=wgs, lds=c["lds"], mmac=round(c["macs"] / 1e6, 1),
                                event_us=round(e0.elapsed_time(e1) * 1e3, 1),
                                span_us=round(float(t[:, 3].max() - t0), 2),
-                               start_after_first=q(t[:, 0] - t0), first_chunk=q(t[:, 1] - t[:, 0]),
+                               start_after_first=q(t[:, 0] - t0), setup=q(t[:, 11] - t[:, 0]), first_chunk=q(t[:, 1] - t[:, 0]),
                                k_loop=q(t[:, 2] - t[:, 1]), stores=q(t[:, 3] - t[:, 2]), wg_total=q(t[:, 3] - t[:, 0]),
                                chunk_issue=q(t[:, 5] - t[:, 4]), chunk_sweep=q(t[:, 6] - t[:, 5]),
                                chunk_dma_wait=q(t[:, 7] - t[:, 6]), chunk_barrier=q(t[:, 8] - t[:, 7]),

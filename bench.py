@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
-    ap.add_argument("--spinup-seconds", type=float, default=1.5, help="minimum untimed spin-up before the timed steps")
+    ap.add_argument("--spinup-seconds", type=float, default=3.0, help="minimum untimed spin-up before the timed steps")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="keyframes kept in flight per GPU (MonoRecModel.submit); 1 = strictly one forward at a time")
     ap.add_argument("--graph", action="store_true",

@@ -167,6 +167,13 @@ int mr_resnet_normalize_f32(const float* src, float* dst, int64_t count, void* s
  * src is (F, count) contiguous. */
 int mr_max_over_frames_f32(const float* src, float* dst, int32_t num_frames, int64_t count, void* stream);
 
+/* Both consumers of a MaskModule encoder stage output in one pass: pooled = MaxPool2d(2) per frame (next stage input,
+ * monorec_model.py:304-316) and frame_max = max over the frames (cv_feats[i], :365).
+ * src (F, planes, in_h, in_w) -> pooled (F, planes, in_h/2, in_w/2), frame_max (planes, in_h, in_w);
+ * planes = batch * channels, in_h even, in_w % 4 == 0. */
+int mr_pool2x2_framemax_f32(const float* src, float* pooled, float* frame_max, int32_t num_frames, int64_t planes,
+                            int32_t in_h, int32_t in_w, void* stream);
+
 /* cost_volume = (1 - cv_mask) * cost_volume (monorec_model.py:713); mask (batch,1,H,W), cv (batch,D,H,W).
  * dst may alias cv. */
 int mr_apply_mask_f32(const float* cv, const float* mask, float* dst, int32_t batch, int32_t num_depths,

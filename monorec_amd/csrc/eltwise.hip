@@ -76,6 +76,37 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
     }
 }
 
+// The MaskModule encoder needs both of a stage's output: its 2x2 max-pool per frame (input of the next stage,
+// monorec_model.py:304-316) and its maximum over the frames (cv_feats, :365).  One pass reads the stage output once:
+// thread = 2 rows x 4 columns of one (sample, channel) plane, all F frames.
+__global__ __launch_bounds__(256) void pool2x2_framemax_kernel(const float* __restrict__ src, float2* __restrict__ pooled,
+                                                               float* __restrict__ fmax, int F, long long planes, int H, int W) {
+    const int Ho = H >> 1, Wo2 = W >> 2;
+    const long long per_frame = planes * Ho * Wo2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < per_frame; i += (long long)gridDim.x * 256) {
+        const int x2 = (int)(i % Wo2), oy = (int)((i / Wo2) % Ho);
+        const long long p = i / ((long long)Wo2 * Ho);
+        float4 ma, mb;
+        for (int f = 0; f < F; ++f) {
+            const float* s = src + (((long long)f * planes + p) * H + 2 * oy) * W + 4 * x2;
+            const float4 a = *(const float4*)s;
+            const float4 b = *(const float4*)(s + W);
+            float2 o;
+            o.x = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, b.y));
+            o.y = fmaxf(fmaxf(a.z, a.w), fmaxf(b.z, b.w));
+            pooled[(long long)f * per_frame + i] = o;
+            if (f == 0) { ma = a; mb = b; }
+            else {
+                ma.x = fmaxf(ma.x, a.x); ma.y = fmaxf(ma.y, a.y); ma.z = fmaxf(ma.z, a.z); ma.w = fmaxf(ma.w, a.w);
+                mb.x = fmaxf(mb.x, b.x); mb.y = fmaxf(mb.y, b.y); mb.z = fmaxf(mb.z, b.z); mb.w = fmaxf(mb.w, b.w);
+            }
+        }
+        float* d = fmax + (p * H + 2 * oy) * W + 4 * x2;
+        *(float4*)d = ma;
+        *(float4*)(d + W) = mb;
+    }
+}
+
 // ResnetEncoder input normalisation ((x + 0.5) - 0.45) / 0.225 (monorec_model.py:691 + :120); 16 B per lane.
 __global__ __launch_bounds__(256) void resnet_normalize_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
                                                                long long count4) {
@@ -160,6 +191,15 @@ extern "C" int mr_maxpool2x2_f32(const float* src, float* dst, int64_t planes, i
     if (!src || !dst || planes < 1 || in_h < 2 || in_w < 4 || (in_h & 1) || (in_w & 3)) return MR_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(planes * (in_h / 2) * (in_w / 4))), dim3(256), 0,
                        (hipStream_t)stream, src, (float2*)dst, (long long)planes, in_h, in_w);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_pool2x2_framemax_f32(const float* src, float* pooled, float* frame_max, int32_t num_frames, int64_t planes,
+                                       int32_t in_h, int32_t in_w, void* stream) {
+    if (!src || !pooled || !frame_max || num_frames < 1 || planes < 1 || in_h < 2 || in_w < 4 || (in_h & 1) || (in_w & 3))
+        return MR_ERR_BAD_ARGUMENT;
+    hipLaunchKernelGGL(pool2x2_framemax_kernel, dim3(grid_for(planes * (in_h / 2) * (in_w / 4))), dim3(256), 0,
+                       (hipStream_t)stream, src, (float2*)pooled, frame_max, num_frames, (long long)planes, in_h, in_w);
     return (int)hipGetLastError();
 }
 

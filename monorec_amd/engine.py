@@ -433,24 +433,25 @@ class Plan:
             i0, i1 = (0, 1) if i == 0 else (1, 2)       # index 0 of stages 1-4 is the MaxPool
             a = self.alloc(f"mask.enc{i}.a", F * B, enc_ch[i], hi, wi)
             xo = self.alloc(f"mask.enc{i}.x", F * B, enc_ch[i], hi, wi)
-            if i > 0:      # nn.MaxPool2d(2) as its own HBM-bound pass; the conv then stages by LDS-DMA
-                xp = self.alloc(f"mask.enc{i}.pool", F * B, enc_ch[i - 1], hi, wi)
-
-                def run_pool2(stream, src=x, dst=xp, planes=F * B * enc_ch[i - 1], hh_=2 * hi, ww_=2 * wi):
-                    _lib.check(lib.mr_maxpool2x2_f32(src.data_ptr(), dst.data_ptr(), planes, hh_, ww_, stream),
-                               "mr_maxpool2x2_f32")
-                self.add(st, f"mask.pool{i}", run_pool2)
-                x = xp
             self.same_conv(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a)
             self.same_conv(st, f"mask.enc{i}.1", [a], f"{am}.enc.{i}.{i1}.conv.weight", f"{am}.enc.{i}.{i1}.conv.bias", xo)
             m = self.alloc(f"mask.cvf{i}", B, enc_ch[i], hi, wi)
-
-            def run_max(stream, src=xo, dst=m, count=B * enc_ch[i] * hi * wi):
-                _lib.check(lib.mr_max_over_frames_f32(src.data_ptr(), dst.data_ptr(), F, count, stream),
-                           "mr_max_over_frames_f32")
-            self.add(st, f"mask.max{i}", run_max)
             cvf.append(m)
-            x = xo
+            if i < 4:
+                # nn.MaxPool2d(2) of the next stage (its own HBM-bound pass: the conv then stages by LDS-DMA) and the
+                # maximum over the frames, both from one read of this stage's output
+                xp = self.alloc(f"mask.enc{i + 1}.pool", F * B, enc_ch[i], hi // 2, wi // 2)
+
+                def run_pool_max(stream, src=xo, dst=xp, mx=m, planes=B * enc_ch[i], hh_=hi, ww_=wi):
+                    _lib.check(lib.mr_pool2x2_framemax_f32(src.data_ptr(), dst.data_ptr(), mx.data_ptr(), F, planes, hh_, ww_,
+                                                           stream), "mr_pool2x2_framemax_f32")
+                self.add(st, f"mask.poolmax{i}", run_pool_max)
+                x = xp
+            else:
+                def run_max(stream, src=xo, dst=m, count=B * enc_ch[i] * hi * wi):
+                    _lib.check(lib.mr_max_over_frames_f32(src.data_ptr(), dst.data_ptr(), F, count, stream),
+                               "mr_max_over_frames_f32")
+                self.add(st, f"mask.max{i}", run_max)
         st = "main"
         x_srcs = [cvf[4], feats[3]]                                                  # :372
         for i in range(4):

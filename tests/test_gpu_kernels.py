@@ -159,6 +159,12 @@ def test_small_kernels(hip_lib):
     pind, pout = pin.to(DEV), torch.empty(6, 10, 12, device=DEV)
     _lib.check(lib.mr_maxpool2x2_f32(pind.data_ptr(), pout.data_ptr(), 6, 20, 24, _stream()))
     assert torch.equal(pout.cpu(), F.max_pool2d(pin, 2))
+    # fused MaxPool2d(2) per frame + max over frames (MaskModule encoder stage output, both consumers in one pass)
+    st = torch.randn(3, 2 * 5, 12, 16, generator=g)                      # (F, B*C, H, W)
+    std = st.to(DEV)
+    pooled, fmx = torch.empty(3, 10, 6, 8, device=DEV), torch.empty(10, 12, 16, device=DEV)
+    _lib.check(lib.mr_pool2x2_framemax_f32(std.data_ptr(), pooled.data_ptr(), fmx.data_ptr(), 3, 10, 12, 16, _stream()))
+    assert torch.equal(pooled.cpu(), F.max_pool2d(st, 2)) and torch.equal(fmx.cpu(), st.max(0)[0])
     nin = torch.rand(2, 3, 8, 12, generator=g) - 0.5
     nind, nout = nin.to(DEV), torch.empty(2, 3, 8, 12, device=DEV)
     _lib.check(lib.mr_resnet_normalize_f32(nind.data_ptr(), nout.data_ptr(), nin.numel(), _stream()))

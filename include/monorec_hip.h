@@ -33,6 +33,7 @@ extern "C" {
 
 #define MR_MAX_SOURCES 3
 #define MR_MAX_FRAMES  8
+#define MR_MAX_VOTE_MASKS 8   /* masks voted over by mr_pointcloud_append_f32 (the reference buffers 5) */
 
 /* ---- activation codes for mr_conv2d_f32 (epilogue, applied after bias [+ residual]) ---- */
 enum {
@@ -186,6 +187,31 @@ int mr_apply_mask_f32(const float* cv, const float* mask, float* dst, int32_t ba
  * sum(log dp - log dg)^2, n(thresh<1.25), n(thresh<1.25^2), n(thresh<1.25^3)]. */
 int mr_sparse_metric_sums_f32(const float* prediction, const float* target, int32_t batch, int32_t height,
                               int32_t width, const int32_t* roi, float max_distance, double* sums, void* stream);
+
+/* ---- point-cloud path: create_pointcloud.py + utils/ply_utils.py -------------------------------
+ *
+ * Static-scene mask of one keyframe, create_pointcloud.py:76-77:
+ *   mask = (cv_mask >= threshold); out = (F.conv2d(mask, ones(mask_fill+1, mask_fill+1), padding=mask_fill//2) < 1)
+ * i.e. 1 where no moving pixel lies within +-mask_fill/2 (zero padding), else 0.  cv_mask, out: (batch,1,H,W);
+ * mask_fill even (reference: 32, threshold .1). */
+int mr_static_mask_f32(const float* cv_mask, float* out, int32_t batch, int32_t height, int32_t width,
+                       float threshold, int32_t mask_fill, void* stream);
+
+/* One PLYSaver.add_depthmap (utils/ply_utils.py:34-53) preceded by the mask vote of create_pointcloud.py:90-92:
+ *   vote   = (sum_k static_masks[k]) > vote_above            (num_masks = 0: no masking; reference: 5 masks, > 4)
+ *   depth  = 1 / (inv_depth * vote);  keep = min_d <= depth <= max_d, inside roi (y0,y1,x0,x1; python slice
+ *            semantics; NULL = whole image), and uniform > dropout when `uniform` (the torch.rand_like of :45) is given
+ *   point  = pose @ [depth * (kinv @ (x, y, 1)); 1]           (model/layers.py:56-61, ply_utils.py:47-49)
+ *   colour = (image + .5) * 255
+ * Kept points are appended in the reference's order (batch, then pixel row-major) as 6 floats x y z r g b to
+ * `records` starting at record *cursor; *cursor (device memory) is advanced by the number of kept points even
+ * beyond `capacity_records` (nothing is written past the capacity - the caller checks).  No host synchronisation.
+ * inv_depth/uniform (batch,1,H,W), image (batch,3,H,W), kinv batch x 9 (inverse(intrinsics)[:3,:3]), pose batch x 16. */
+int mr_pointcloud_append_f32(const float* inv_depth, const float* const* static_masks, int32_t num_masks,
+                             float vote_above, const float* image, const float* kinv, const float* pose,
+                             const float* uniform, float dropout, float min_d, float max_d, const int32_t* roi,
+                             int32_t batch, int32_t height, int32_t width, float* records, int64_t capacity_records,
+                             int64_t* cursor, void* stream);
 
 int mr_abi_version(void);
 const char* mr_error_string(int code);

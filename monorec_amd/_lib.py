@@ -82,6 +82,13 @@ ABI = {
     "mr_sparse_metric_sums_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_float,
                                                  ctypes.c_void_p, ctypes.c_void_p]),
+    "mr_static_mask_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
+    "mr_pointcloud_append_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                                ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_abi_version": (ctypes.c_int, []),
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }

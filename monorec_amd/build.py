@@ -18,6 +18,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("conv_mfma.hip", []),
     ("cost_volume.hip", ["-ffp-contract=off"]),
+    ("pointcloud.hip", ["-ffp-contract=off"]),
     ("eltwise.hip", []),
 ]
 

@@ -146,3 +146,31 @@ def seeded_state_dict(template_state_dict, seed=0):
             bound *= 0.5  # keep tanh / sigmoid heads out of saturation
         out[key] = ((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(torch.float32)
     return out
+
+
+def make_pointcloud_case(batch=1, height=64, width=96, seed=3, num_masks=5):
+    """Seeded inputs of the point-cloud path (create_pointcloud.py): predicted inverse depth, keyframe, intrinsics,
+    pose, `num_masks` cv_mask maps with a few 'moving object' blobs (>= 0.1) and the uniform numbers that stand
+    for torch.rand_like in PLYSaver.add_depthmap."""
+    gen = torch.Generator().manual_seed(seed)
+    inv_depth = 0.0025 + (0.5 - 0.0025) * torch.rand(batch, 1, height, width, generator=gen) ** 2
+    image = _texture(gen, batch, height, width)
+    intrinsics = make_intrinsics(height, width, batch)
+    pose = torch.eye(4).unsqueeze(0).repeat(batch, 1, 1)
+    ang = 0.3 * (torch.rand(batch, generator=gen) - 0.5)
+    pose[:, 0, 0], pose[:, 0, 2], pose[:, 2, 0], pose[:, 2, 2] = torch.cos(ang), torch.sin(ang), -torch.sin(ang), torch.cos(ang)
+    pose[:, :3, 3] = 40.0 * (torch.rand(batch, 3, generator=gen) - 0.5)
+    cv_masks = []
+    yy, xx = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
+    for _ in range(num_masks):
+        m = 0.09 * torch.rand(batch, 1, height, width, generator=gen)          # background stays below the 0.1 threshold
+        for b in range(batch):
+            for _ in range(2):
+                cy, cx = torch.rand(2, generator=gen)
+                r = 2.0 + 3.0 * float(torch.rand(1, generator=gen))
+                blob = ((yy - float(cy) * height) ** 2 + (xx - float(cx) * width) ** 2) < r * r
+                m[b, 0][blob] = 0.1 + 0.9 * float(torch.rand(1, generator=gen))
+        cv_masks.append(m.contiguous())
+    uniform = torch.rand(batch, 1, height, width, generator=gen)
+    return dict(inv_depth=inv_depth.contiguous(), image=image, intrinsics=intrinsics, pose=pose.contiguous(),
+                cv_masks=cv_masks, uniform=uniform)

@@ -256,6 +256,47 @@ def main():
     with open(os.path.join(GOLDEN, "sparse_metrics.json"), "w") as f:
         json.dump(metric_fixture, f, indent=1, sort_keys=True)
     report["metrics_oracle_equals_reference"] = True
+
+    # ---- point-cloud path: the real PLYSaver / Backprojection and the mask lines of create_pointcloud.py ----------------
+    import torch.nn.functional as F
+    from utils.ply_utils import PLYSaver as RefPLYSaver                  # noqa: reference class (via ref_shims)
+    pc_cases = {"small_roi_dropout": dict(b=2, h=64, w=96, seed=3, min_d=3, max_d=30, roi=[8, 60, 10, 90], dropout=.75, use_mask=True),
+                "no_mask_full": dict(b=1, h=40, w=72, seed=4, min_d=3, max_d=400, roi=None, dropout=0, use_mask=False),
+                "c2_size": dict(b=1, h=256, w=512, seed=5, min_d=3, max_d=20, roi=[40, 256, 48, 464], dropout=.75, use_mask=True)}
+    pc_fixture = {}
+    for name, cfg in pc_cases.items():
+        case = synth.make_pointcloud_case(cfg["b"], cfg["h"], cfg["w"], cfg["seed"])
+        # create_pointcloud.py:75-77, verbatim semantics on the reference side
+        ref_masks = []
+        for cvm in case["cv_masks"]:
+            m = (cvm >= .1).to(dtype=torch.float32)
+            ref_masks.append((F.conv2d(m, m.new_ones((1, 1, 33, 33)), padding=16) < 1).to(dtype=torch.float32))
+        for a, cvm in zip(ref_masks, case["cv_masks"]):
+            assert torch.equal(a, orc.static_mask(cvm, 32)), name
+        depth = case["inv_depth"].clone()
+        if cfg["use_mask"]:
+            depth *= (torch.sum(torch.stack(ref_masks), dim=0) > 5 - 1).to(dtype=torch.float32)      # :90-92
+        saver = RefPLYSaver(cfg["h"], cfg["w"], min_d=cfg["min_d"], max_d=cfg["max_d"], batch_size=cfg["b"], roi=cfg["roi"],
+                            dropout=cfg["dropout"])
+        # PLYSaver draws torch.rand_like(depth) (:45); hand it the fixture's uniform numbers through the global generator
+        real_rand_like = torch.rand_like
+        torch.rand_like = lambda t, *a, **k: case["uniform"].to(t.dtype)
+        try:
+            saver.add_depthmap(depth, case["image"].clone(), case["intrinsics"].clone(), case["pose"].clone())
+        finally:
+            torch.rand_like = real_rand_like
+        ref_rec = torch.tensor(saver.data, dtype=torch.float32).view(-1, 6)
+        got = orc.pointcloud_records(case["inv_depth"], case["image"], case["intrinsics"], case["pose"], cfg["min_d"], cfg["max_d"],
+                                     cfg["roi"], cfg["dropout"], case["uniform"], ref_masks if cfg["use_mask"] else None, 1)
+        assert got.shape == ref_rec.shape and torch.equal(got, ref_rec), (name, got.shape, ref_rec.shape)
+        np.savez_compressed(os.path.join(GOLDEN, f"pointcloud_{name}.npz"), records=ref_rec.numpy(),
+                            static_mask_sum=np.array([float(m.sum()) for m in ref_masks]),
+                            static_mask0=np.packbits(ref_masks[0].numpy().astype(np.uint8)))
+        pc_fixture[name] = dict(cfg, points=int(ref_rec.shape[0]))
+        print("pointcloud", name, "ok; oracle == reference;", ref_rec.shape[0], "points")
+    with open(os.path.join(GOLDEN, "pointcloud_cases.json"), "w") as f:
+        json.dump(pc_fixture, f, indent=1, sort_keys=True)
+    report["pointcloud_oracle_equals_reference"] = True
     with open(os.path.join(GOLDEN, "PINNING.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print("wrote", GOLDEN)

@@ -358,3 +358,45 @@ def sparse_metrics(pred, gt, roi=None, max_distance=None):
     out["rmse_log_sparse_metric"] = torch.mean(torch.sqrt(
         _masked_mean((torch.log(dp1) - torch.log(dg1)) ** 2, mask, dim=[1, 2, 3])))       # :231-235
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# point-cloud path: create_pointcloud.py:76-94, utils/ply_utils.py:34-53, model/layers.py:43-61
+# ----------------------------------------------------------------------------------------
+def static_mask(cv_mask, mask_fill=32, threshold=0.1):
+    """create_pointcloud.py:76-77: 1 where no pixel with cv_mask >= threshold lies in the (mask_fill+1)^2 window."""
+    moving = (cv_mask >= threshold).to(torch.float32)
+    box = F.conv2d(moving, moving.new_ones((1, 1, mask_fill + 1, mask_fill + 1)), padding=mask_fill // 2)
+    return (box < 1).to(torch.float32)
+
+
+def vote_mask(static_masks, min_hits=1):
+    """create_pointcloud.py:90: a pixel survives when more than len - min_hits of the buffered masks are 1."""
+    return (torch.sum(torch.stack(static_masks), dim=0) > len(static_masks) - min_hits).to(torch.float32)
+
+
+def pointcloud_records(inv_depth, image, intrinsics, extrinsics, min_d=3, max_d=400, roi=None, dropout=0.0,
+                       uniform=None, static_masks=None, min_hits=1):
+    """(N, 6) x y z r g b records in the order PLYSaver.add_depthmap appends them (utils/ply_utils.py:34-53).
+    `uniform` stands for the torch.rand_like(depth) of :45."""
+    b, _, h, w = inv_depth.shape
+    if static_masks:
+        inv_depth = inv_depth * vote_mask(static_masks, min_hits)                          # create_pointcloud.py:91-92
+    depth = 1 / inv_depth                                                                  # :36
+    colour = (image + .5) * 255                                                            # :37
+    keep = (min_d <= depth) & (depth <= max_d)                                             # :38
+    if roi is not None:                                                                    # :39-43
+        keep[:, :, :roi[0], :] = False
+        keep[:, :, roi[1]:, :] = False
+        keep[:, :, :, :roi[2]] = False
+        keep[:, :, :, roi[3]:] = False
+    if dropout > 0:                                                                        # :44-45
+        keep = keep & (uniform > dropout)
+    yy, xx = torch.meshgrid([torch.arange(0., float(h)), torch.arange(0., float(w))], indexing="ij")   # layers.py:49-54
+    pix = torch.stack([xx.reshape(-1), yy.reshape(-1), torch.ones(h * w)], 0).unsqueeze(0).repeat(b, 1, 1)
+    rays = torch.matmul(torch.inverse(intrinsics)[:, :3, :3], pix)                         # layers.py:57
+    cam = depth.view(b, 1, -1) * rays                                                      # :58
+    cam_h = torch.cat([cam, torch.ones(b, 1, h * w)], 1)                                   # :59
+    world = (extrinsics @ cam_h)[:, :3, :]                                                 # ply_utils.py:48-49
+    rec = torch.cat([world, colour.view_as(world)], dim=1).permute(0, 2, 1)                # :50
+    return rec[keep.view(b, 1, -1).permute(0, 2, 1).expand(-1, -1, 6)].view(-1, 6)        # :51

@@ -213,6 +213,30 @@ int mr_pointcloud_append_f32(const float* inv_depth, const float* const* static_
                              int32_t batch, int32_t height, int32_t width, float* records, int64_t capacity_records,
                              int64_t* cursor, void* stream);
 
+/* ---- input pipeline: KittiOdometryDataset.preprocess_image, kitti_odometry_dataset.py:120-134 ------
+ *
+ * img.crop(box) -> img.resize((W,H), Image.BILINEAR) -> float32 / 255 - .5 -> CHW (a 1-channel image is stacked 3x),
+ * Pillow's resampling (Resample.c: scaled triangle filter, 22-bit fixed-point weights, horizontal pass into an 8-bit
+ * intermediate, then vertical) reproduced bit for bit.
+ *
+ * Host side, once per (size, box): the coefficient tables of one axis for a crop [in0, in1) of an axis of in_size
+ * pixels resized to out_size.  ksize = mr_resample_ksize_bilinear(in0, in1, out_size); bounds: out_size x 2 ints
+ * (first source index, tap count), coeffs: out_size x ksize ints (unused taps 0).  For a cropped image pass
+ * in_size = in1 - in0, in0 = 0 (Image.crop materialises the crop before the resize). */
+int32_t mr_resample_ksize_bilinear(int32_t in0, int32_t in1, int32_t out_size);
+int mr_resample_coeffs_bilinear(int32_t in_size, int32_t in0, int32_t in1, int32_t out_size, int32_t* bounds,
+                                int32_t* coeffs);
+
+/* Device side: src = decoded image in device memory, uint8, interleaved (src_h, src_w, channels), channels 1 or 3;
+ * box = integer crop (x0, y0, x1, y1) as Image.crop rounds it; tables (device memory) for the cropped size;
+ * max_tile_rows = max over output row tiles [16t, 16t+16) of the source rows they touch
+ * (vbounds[last].first + vbounds[last].count - vbounds[first].first); dst (3, out_h, out_w) fp32. */
+int mr_preprocess_image_u8_f32(const uint8_t* src, int32_t src_h, int32_t src_w, int32_t channels,
+                               int64_t row_stride_bytes, const int32_t* box, int32_t out_h, int32_t out_w,
+                               const int32_t* hbounds, const int32_t* hcoeffs, int32_t hksize,
+                               const int32_t* vbounds, const int32_t* vcoeffs, int32_t vksize,
+                               int32_t max_tile_rows, float* dst, void* stream);
+
 int mr_abi_version(void);
 const char* mr_error_string(int code);
 

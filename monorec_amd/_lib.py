@@ -89,6 +89,14 @@ ABI = {
                                                 ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                 ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "mr_resample_ksize_bilinear": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mr_resample_coeffs_bilinear": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.c_void_p, ctypes.c_void_p]),
+    "mr_preprocess_image_u8_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                                  ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                  ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_abi_version": (ctypes.c_int, []),
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }

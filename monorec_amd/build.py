@@ -19,6 +19,7 @@ SOURCES = [
     ("conv_mfma.hip", []),
     ("cost_volume.hip", ["-ffp-contract=off"]),
     ("pointcloud.hip", ["-ffp-contract=off"]),
+    ("preprocess.hip", ["-ffp-contract=off"]),
     ("eltwise.hip", []),
 ]
 

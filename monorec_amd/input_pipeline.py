@@ -1,0 +1,137 @@
+"""Input pipeline on the MI355X: the per-frame work of the reference's
+`KittiOdometryDataset` (data_loader/kitti_odometry_dataset.py) between the decoded image and the model input.
+
+    crop box / intrinsics of the target size   compute_target_intrinsics, format_intrinsics  (:318-349, :366-375)
+    crop -> PIL bilinear resize -> /255 - .5 -> CHW    preprocess_image (:120-134)      -> `ImagePreprocessor` (one launch)
+    keyframe + neighbouring frames per sample  __getitem__ (:248-258)                  -> `FrameCache.sample`
+
+The reference decodes and resizes every image three times with `frame_count = 2` (once as keyframe, twice as a
+source frame of its neighbours); `FrameCache` keeps the preprocessed frames of the last few indices in HBM, so a
+sequential sweep decodes each PNG once and runs one resize launch per *new* frame.  PNG decoding stays on the host
+(PIL, as in the reference); everything after it runs on the device, bit-identical to Pillow's integer resampling.
+There is no CPU fallback for the resize."""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def compute_target_intrinsics(p_cam, orig_size, target_image_size):
+    """kitti_odometry_dataset.py:318-349.  p_cam: 3x4 rectified projection (numpy), orig_size (H, W).
+    Returns ((f_x, f_y, c_x, c_y) normalised to the target size, crop box (x0, y0, x1, y1))."""
+    r_orig = orig_size[0] / orig_size[1]
+    r_target = target_image_size[0] / target_image_size[1]
+    if r_orig >= r_target:
+        new_height = r_target * orig_size[1]
+        box = (0, (orig_size[0] - new_height) // 2, orig_size[1], orig_size[0] - (orig_size[0] - new_height) // 2)
+        c_x = p_cam[0, 2] / orig_size[1]
+        c_y = (p_cam[1, 2] - (orig_size[0] - new_height) / 2) / new_height
+        rescale = orig_size[1] / target_image_size[1]
+    else:
+        new_width = orig_size[0] / r_target
+        box = ((orig_size[1] - new_width) // 2, 0, orig_size[1] - (orig_size[1] - new_width) // 2, orig_size[0])
+        c_x = (p_cam[0, 2] - (orig_size[1] - new_width) / 2) / new_width
+        c_y = p_cam[1, 2] / orig_size[0]
+        rescale = orig_size[0] / target_image_size[0]
+    f_x = p_cam[0, 0] / target_image_size[1] / rescale
+    f_y = p_cam[1, 1] / target_image_size[0] / rescale
+    return (f_x, f_y, c_x, c_y), box
+
+
+def format_intrinsics(intrinsics, target_image_size):
+    """kitti_odometry_dataset.py:366-375: 4x4 intrinsics matrix in pixels of the target size."""
+    k = torch.zeros(4, 4)
+    k[0, 0] = intrinsics[0] * target_image_size[1]
+    k[1, 1] = intrinsics[1] * target_image_size[0]
+    k[0, 2] = intrinsics[2] * target_image_size[1]
+    k[1, 2] = intrinsics[3] * target_image_size[0]
+    k[2, 2] = 1
+    k[3, 3] = 1
+    return k
+
+
+def _axis_tables(lib, in_size, out_size):
+    ks = int(lib.mr_resample_ksize_bilinear(0, in_size, out_size))
+    if ks < 0:
+        _lib.check(ks, "mr_resample_ksize_bilinear")
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coeffs = np.zeros((out_size, ks), dtype=np.int32)
+    _lib.check(lib.mr_resample_coeffs_bilinear(in_size, 0, in_size, out_size, bounds.ctypes.data, coeffs.ctypes.data),
+               "mr_resample_coeffs_bilinear")
+    return ks, bounds, coeffs
+
+
+class ImagePreprocessor:
+    """`preprocess_image` (kitti_odometry_dataset.py:120-134) for one source image size: crop box (as `Image.crop`
+    rounds it), Pillow-exact bilinear resize to `target_image_size`, `/255 - .5`, CHW - one launch per image."""
+
+    def __init__(self, orig_size, target_image_size, crop_box=None, device="cuda:0"):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("monorec_amd.input_pipeline: a HIP device is required - there is no CPU fallback")
+        self.orig_h, self.orig_w = int(orig_size[0]), int(orig_size[1])
+        self.out_h, self.out_w = int(target_image_size[0]), int(target_image_size[1])
+        if crop_box is None:
+            crop_box = (0, 0, self.orig_w, self.orig_h)
+        self.box = tuple(int(round(v)) for v in crop_box)                   # PIL: Image.crop rounds the box
+        cw, ch = self.box[2] - self.box[0], self.box[3] - self.box[1]
+        self.hks, hb, hk = _axis_tables(self.lib, cw, self.out_w)
+        self.vks, vb, vk = _axis_tables(self.lib, ch, self.out_h)
+        self.max_rows = max(int(vb[min(t + 15, self.out_h - 1), 0] + vb[min(t + 15, self.out_h - 1), 1] - vb[t, 0])
+                            for t in range(0, self.out_h, 16))
+        up = lambda a: torch.from_numpy(a).to(self.device)
+        self.hb, self.hk, self.vb, self.vk = up(hb), up(hk), up(vb), up(vk)
+        self._box_c = (ctypes.c_int32 * 4)(*self.box)
+
+    def __call__(self, image, out=None):
+        """image: uint8 (H, W, 3) or (H, W), numpy / CPU tensor (uploaded) or device tensor -> float32 (3, h, w) on the device."""
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image))
+        if image.dtype != torch.uint8 or image.dim() not in (2, 3):
+            raise ValueError("expected a uint8 (H, W[, 3]) image")
+        channels = 1 if image.dim() == 2 else image.shape[2]
+        if (image.shape[0], image.shape[1]) != (self.orig_h, self.orig_w) or channels not in (1, 3):
+            raise ValueError(f"image of shape {tuple(image.shape)} does not match this preprocessor ({self.orig_h}x{self.orig_w})")
+        if not image.is_cuda:
+            image = image.contiguous().pin_memory().to(self.device, non_blocking=True)
+        image = image.contiguous()
+        if out is None:
+            out = torch.empty(3, self.out_h, self.out_w, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mr_preprocess_image_u8_f32(
+            image.data_ptr(), self.orig_h, self.orig_w, channels, self.orig_w * channels, self._box_c, self.out_h, self.out_w,
+            self.hb.data_ptr(), self.hk.data_ptr(), self.hks, self.vb.data_ptr(), self.vk.data_ptr(), self.vks,
+            self.max_rows, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "mr_preprocess_image_u8_f32")
+        return out
+
+
+class FrameCache:
+    """Preprocessed frames by index, least recently used evicted.  `load(index)` returns the decoded uint8 image
+    (the reference: `dataset.get_cam2(index)` / `get_cam0`, a PIL image - `np.asarray` of it works)."""
+
+    def __init__(self, load, preprocessor, capacity=8):
+        self.load, self.pre, self.capacity = load, preprocessor, capacity
+        self._frames = OrderedDict()
+        self.decoded = 0                       # number of images decoded + resized so far
+
+    def frame(self, index):
+        if index in self._frames:
+            self._frames.move_to_end(index)
+            return self._frames[index]
+        img = self.load(index)
+        t = self.pre(np.asarray(img))
+        self.decoded += 1
+        self._frames[index] = t
+        while len(self._frames) > self.capacity:
+            self._frames.popitem(last=False)
+        return t
+
+    def sample(self, index, frame_count=2, dilation=1, offset_d=0):
+        """keyframe and source frames of `__getitem__` (kitti_odometry_dataset.py:248-255): returns
+        (keyframe (3,H,W), [frames], [source indices])."""
+        offs = [i for i in range(-(frame_count // 2) * dilation, ((frame_count + 1) // 2) * dilation + 1, dilation) if i != 0]
+        idx = [index + i + offset_d for i in offs]
+        return self.frame(index), [self.frame(j) for j in idx], idx

@@ -174,3 +174,16 @@ def make_pointcloud_case(batch=1, height=64, width=96, seed=3, num_masks=5):
     uniform = torch.rand(batch, 1, height, width, generator=gen)
     return dict(inv_depth=inv_depth.contiguous(), image=image, intrinsics=intrinsics, pose=pose.contiguous(),
                 cv_masks=cv_masks, uniform=uniform)
+
+
+def make_u8_image(height, width, channels=3, seed=11):
+    """Seeded uint8 test image (smooth texture + noise + hard edges) as numpy (H, W, 3) or (H, W)."""
+    import numpy as np
+    gen = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, channels, max(height // 16, 2), max(width // 16, 2), generator=gen)
+    img = F.interpolate(low, size=(height, width), mode="bicubic", align_corners=False)
+    img = img + 0.15 * torch.rand(1, channels, height, width, generator=gen)
+    img[:, :, height // 3: height // 3 + 5, :] = 1.0                    # a saturated bar and a black bar: clipping paths
+    img[:, :, :, width // 4: width // 4 + 3] = 0.0
+    a = (img.clamp(0, 1) * 255).round().to(torch.uint8)[0].permute(1, 2, 0).contiguous().numpy()
+    return a[:, :, 0].copy() if channels == 1 else a

@@ -196,6 +196,18 @@ def main():
         ds._dataset_sizes = [1000]                                                # same hack as example/test_monorec.py:22-25
         ds._datasets[0].cam2_files = [f"data/kitti/sequences/07/image_2/{i:06d}.png" for i in range(1000)]
         sample, depth = ds.__getitem__(164)                                       # image 169 (test_monorec.py:38-41)
+        # ---- input-pipeline pins (row f-3) on the same dataset object: crop box / intrinsics / preprocess_image
+        from PIL import Image
+        from oracle import input_oracle
+        from monorec_amd import input_pipeline
+        p_cam = ds._datasets[0].calib.P_rect_20
+        intr, box = input_pipeline.compute_target_intrinsics(p_cam, (370, 1226), (256, 512))
+        assert tuple(box) == tuple(ds._crop_boxes[0]) == tuple(input_oracle.crop_box_for(370, 1226, 256, 512))
+        assert torch.equal(input_pipeline.format_intrinsics(intr, (256, 512)), ds._intrinsics[0])
+        for img_id, ref_t in ((169, sample["keyframe"]), (168, sample["frames"][0]), (170, sample["frames"][1])):
+            raw = np.array(Image.open(f"data/kitti/sequences/07/image_2/{img_id:06d}.png"))
+            assert torch.equal(input_oracle.preprocess_image(raw, box, 256, 512), ref_t), img_id
+        print("input pipeline: oracle == reference preprocess_image on the 3 example frames; crop box / intrinsics equal")
     finally:
         os.chdir(cwd)
     unsq = lambda v: v.unsqueeze(0) if torch.is_tensor(v) else [t.unsqueeze(0) for t in v]
@@ -297,6 +309,25 @@ def main():
     with open(os.path.join(GOLDEN, "pointcloud_cases.json"), "w") as f:
         json.dump(pc_fixture, f, indent=1, sort_keys=True)
     report["pointcloud_oracle_equals_reference"] = True
+    report["input_pipeline_oracle_equals_reference_on_example_frames"] = True
+
+    # ---- input pipeline fixtures: Pillow itself (the dependency preprocess_image calls) on seeded images -----------------
+    from PIL import Image
+    from oracle import input_oracle
+    pre_cases = {"kitti_colour": (370, 1226, 3, 256, 512), "kitti_grey": (376, 1241, 1, 256, 512), "upscale": (50, 60, 3, 64, 96),
+                 "mixed": (33, 47, 3, 33, 20), "tall": (120, 90, 3, 32, 64)}
+    store = {}
+    for name, (h, w, c, oh, ow) in pre_cases.items():
+        img = synth.make_u8_image(h, w, c, seed=11)
+        box = input_oracle.crop_box_for(h, w, oh, ow)
+        want = np.array(Image.fromarray(img).crop(box).resize((ow, oh), resample=Image.BILINEAR))
+        x0, y0, x1, y1 = (int(round(v)) for v in box)
+        got = input_oracle.resize_bilinear_u8(np.ascontiguousarray(img[y0:y1, x0:x1]), oh, ow)
+        assert np.array_equal(got, want), name
+        store[name] = want
+        store[name + ".cfg"] = np.array([h, w, c, oh, ow], dtype=np.int64)
+        print("preprocess", name, "ok; oracle == Pillow", Image.__version__ if hasattr(Image, "__version__") else "")
+    np.savez_compressed(os.path.join(GOLDEN, "preprocess_cases.npz"), **store)
     with open(os.path.join(GOLDEN, "PINNING.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print("wrote", GOLDEN)

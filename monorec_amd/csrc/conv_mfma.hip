@@ -401,7 +401,8 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int q_lo = (ks * a.nchunks) / a.ksplit, q_hi = ((ks + 1) * a.nchunks) / a.ksplit;
+    const int q_lo = a.ks_shift >= 0 ? (ks * a.nchunks) >> a.ks_shift : (ks * a.nchunks) / a.ksplit;
+    const int q_hi = a.ks_shift >= 0 ? ((ks + 1) * a.nchunks) >> a.ks_shift : ((ks + 1) * a.nchunks) / a.ksplit;
     const int T = a.KH * a.KW;
     const float* wgrp = a.w[ph] + (long long)grp * a.wgroup_stride;
 

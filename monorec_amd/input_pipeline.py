@@ -20,37 +20,37 @@ from . import _lib
 
 
 def compute_target_intrinsics(p_cam, orig_size, target_image_size):
-    """kitti_odometry_dataset.py:318-349.  p_cam: 3x4 rectified projection (numpy), orig_size (H, W).
-    Returns ((f_x, f_y, c_x, c_y) normalised to the target size, crop box (x0, y0, x1, y1))."""
-    r_orig = orig_size[0] / orig_size[1]
-    r_target = target_image_size[0] / target_image_size[1]
-    if r_orig >= r_target:
-        new_height = r_target * orig_size[1]
-        box = (0, (orig_size[0] - new_height) // 2, orig_size[1], orig_size[0] - (orig_size[0] - new_height) // 2)
-        c_x = p_cam[0, 2] / orig_size[1]
-        c_y = (p_cam[1, 2] - (orig_size[0] - new_height) / 2) / new_height
-        rescale = orig_size[1] / target_image_size[1]
-    else:
-        new_width = orig_size[0] / r_target
-        box = ((orig_size[1] - new_width) // 2, 0, orig_size[1] - (orig_size[1] - new_width) // 2, orig_size[0])
-        c_x = (p_cam[0, 2] - (orig_size[1] - new_width) / 2) / new_width
-        c_y = p_cam[1, 2] / orig_size[0]
-        rescale = orig_size[0] / target_image_size[0]
-    f_x = p_cam[0, 0] / target_image_size[1] / rescale
-    f_y = p_cam[1, 1] / target_image_size[0] / rescale
-    return (f_x, f_y, c_x, c_y), box
+    """Centre crop to the target aspect ratio and the intrinsics of the cropped, resized image - the rule of
+    kitti_odometry_dataset.py:318-349 (same floating-point expressions, so the numbers are bit-identical).
+    p_cam: 3x4 rectified projection (numpy), orig_size / target_image_size: (H, W).
+    Returns ((f_x, f_y, c_x, c_y) as fractions of the target size, crop box (x0, y0, x1, y1))."""
+    src_h, src_w = orig_size
+    dst_h, dst_w = target_image_size
+    aspect = dst_h / dst_w
+    if src_h / src_w >= aspect:                      # source too tall: keep all columns, drop rows top and bottom
+        kept = aspect * src_w
+        margin = (src_h - kept) // 2
+        box = (0, margin, src_w, src_h - margin)
+        centre = (p_cam[0, 2] / src_w, (p_cam[1, 2] - (src_h - kept) / 2) / kept)
+        shrink = src_w / dst_w
+    else:                                            # source too wide: keep all rows, drop columns left and right
+        kept = src_h / aspect
+        margin = (src_w - kept) // 2
+        box = (margin, 0, src_w - margin, src_h)
+        centre = ((p_cam[0, 2] - (src_w - kept) / 2) / kept, p_cam[1, 2] / src_h)
+        shrink = src_h / dst_h
+    focal = (p_cam[0, 0] / dst_w / shrink, p_cam[1, 1] / dst_h / shrink)
+    return (focal[0], focal[1], centre[0], centre[1]), box
 
 
 def format_intrinsics(intrinsics, target_image_size):
-    """kitti_odometry_dataset.py:366-375: 4x4 intrinsics matrix in pixels of the target size."""
-    k = torch.zeros(4, 4)
-    k[0, 0] = intrinsics[0] * target_image_size[1]
-    k[1, 1] = intrinsics[1] * target_image_size[0]
-    k[0, 2] = intrinsics[2] * target_image_size[1]
-    k[1, 2] = intrinsics[3] * target_image_size[0]
-    k[2, 2] = 1
-    k[3, 3] = 1
-    return k
+    """Fractional (f_x, f_y, c_x, c_y) -> 4x4 pixel intrinsics of the target size (kitti_odometry_dataset.py:366-375)."""
+    f_x, f_y, c_x, c_y = intrinsics
+    h, w = target_image_size
+    return torch.tensor([[f_x * w, 0.0, c_x * w, 0.0],
+                         [0.0, f_y * h, c_y * h, 0.0],
+                         [0.0, 0.0, 1.0, 0.0],
+                         [0.0, 0.0, 0.0, 1.0]], dtype=torch.float32)
 
 
 def _axis_tables(lib, in_size, out_size):

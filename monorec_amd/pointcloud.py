@@ -122,18 +122,10 @@ class PLYSaver(torch.nn.Module):
     def save(self, file):
         """utils/ply_utils.py:18-32 (same header, binary little-endian float records)."""
         data = self.data
-        length = len(data) // 6
-        header = "ply\n" \
-                 "format binary_little_endian 1.0\n" \
-                 f"element vertex {length}\n" \
-                 f"property float x\n" \
-                 f"property float y\n" \
-                 f"property float z\n" \
-                 f"property float red\n" \
-                 f"property float green\n" \
-                 f"property float blue\n" \
-                 f"end_header\n"
-        file.write(header.encode(encoding="ascii"))
+        fields = ("x", "y", "z", "red", "green", "blue")
+        lines = ["ply", "format binary_little_endian 1.0", f"element vertex {len(data) // 6}"]
+        lines += [f"property float {name}" for name in fields] + ["end_header"]
+        file.write(("\n".join(lines) + "\n").encode("ascii"))
         data.tofile(file)
 
 

@@ -237,6 +237,13 @@ int mr_preprocess_image_u8_f32(const uint8_t* src, int32_t src_h, int32_t src_w,
                                const int32_t* vbounds, const int32_t* vcoeffs, int32_t vksize,
                                int32_t max_tile_rows, float* dst, void* stream);
 
+/* Sparse lidar ground truth, preprocess_depth_annotated_lidar (kitti_odometry_dataset.py:184-211): the 16-bit depth PNG
+ * (depth * 256, 0 = no return) -> inverse depth 256 / value scattered to the nearest cell of the (out_h, out_w) grid of
+ * the cropped (box = x0, y0, x1, y1; NULL = none) and rescaled image; colliding samples: last one in row-major source
+ * order wins, like numpy's fancy assignment.  owner_scratch: out_h * out_w ints of device scratch.  dst (out_h, out_w). */
+int mr_lidar_inverse_depth_u16_f32(const uint16_t* depth_png, int32_t src_h, int32_t src_w, const int32_t* box,
+                                   int32_t out_h, int32_t out_w, int32_t* owner_scratch, float* dst, void* stream);
+
 int mr_abi_version(void);
 const char* mr_error_string(int code);
 

@@ -71,6 +71,35 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreArgs a) {
     }
 }
 
+// ---- sparse lidar ground truth: preprocess_depth_annotated_lidar (kitti_odometry_dataset.py:184-211) ----------------
+// Every non-zero pixel of the 16-bit depth PNG (depth * 256) inside the crop box becomes one inverse-depth sample
+// 256 / value at the nearest cell (np.around, half to even) of the target grid; when several samples fall into one
+// cell numpy's fancy assignment keeps the last one in row-major source order.  Pass 1 elects that sample per cell
+// (atomicMax of the source index), pass 2 writes it - same double arithmetic as numpy, deterministic.
+__global__ __launch_bounds__(256) void lidar_elect_kernel(const unsigned short* __restrict__ png, int H, int W, int x0, int y0,
+                                                          int x1, int y1, int out_h, int out_w, int* __restrict__ owner) {
+    const long long n = (long long)H * W;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (png[i] == 0) continue;
+        const int r = (int)(i / W), c = (int)(i - (long long)r * W);
+        if (r < y0 || r >= y1 || c < x0 || c >= x1) continue;
+        double ty = (double)(r - y0) / (double)(y1 - y0) * (double)out_h;          // :205
+        double tx = (double)(c - x0) / (double)(x1 - x0) * (double)out_w;          // :206
+        ty = fmin(fmax(ty, 0.0), (double)(out_h - 1));
+        tx = fmin(fmax(tx, 0.0), (double)(out_w - 1));
+        const int cy = (int)rint(ty), cx = (int)rint(tx);                          // np.around
+        atomicMax(owner + cy * out_w + cx, (int)i);
+    }
+}
+
+__global__ __launch_bounds__(256) void lidar_write_kernel(const unsigned short* __restrict__ png, const int* __restrict__ owner,
+                                                          int cells, float* __restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cells; i += gridDim.x * 256) {
+        const int o = owner[i];
+        out[i] = o >= 0 ? (float)(256.0 / (double)png[o]) : 0.f;                   // :191, then float32 (:211)
+    }
+}
+
 double triangle(double x) {
     if (x < 0.0) x = -x;
     return x < 1.0 ? 1.0 - x : 0.0;
@@ -134,5 +163,24 @@ extern "C" int mr_preprocess_image_u8_f32(const uint8_t* src, int32_t src_h, int
     a.max_rows = max_tile_rows; a.dst = dst;
     dim3 grid((out_w + PT_W - 1) / PT_W, (out_h + PT_H - 1) / PT_H);
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_lidar_inverse_depth_u16_f32(const uint16_t* depth_png, int32_t src_h, int32_t src_w, const int32_t* box,
+                                              int32_t out_h, int32_t out_w, int32_t* owner_scratch, float* dst, void* stream) {
+    if (!depth_png || !owner_scratch || !dst || src_h < 1 || src_w < 1 || out_h < 1 || out_w < 1) return MR_ERR_BAD_ARGUMENT;
+    if ((long long)src_h * src_w >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
+    int x0 = 0, y0 = 0, x1 = src_w, y1 = src_h;
+    if (box) { x0 = box[0]; y0 = box[1]; x1 = box[2]; y1 = box[3]; }
+    if (x1 <= x0 || y1 <= y0) return MR_ERR_BAD_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    const int cells = out_h * out_w;
+    hipError_t e = hipMemsetAsync(owner_scratch, 0xff, (size_t)cells * sizeof(int), st);      // -1 everywhere
+    if (e != hipSuccess) return (int)e;
+    const long long n = (long long)src_h * src_w;
+    hipLaunchKernelGGL(lidar_elect_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
+                       depth_png, src_h, src_w, x0, y0, x1, y1, out_h, out_w, owner_scratch);
+    hipLaunchKernelGGL(lidar_write_kernel, dim3((unsigned)((cells + 255) / 256 < 2048 ? (cells + 255) / 256 : 2048)), dim3(256), 0, st,
+                       depth_png, owner_scratch, cells, dst);
     return (int)hipGetLastError();
 }

@@ -108,6 +108,30 @@ class ImagePreprocessor:
         return out
 
 
+def lidar_inverse_depth(depth_png, crop_box, target_image_size, device="cuda:0"):
+    """`preprocess_depth_annotated_lidar` (kitti_odometry_dataset.py:184-211): uint16 depth PNG array (H, W), numpy / tensor
+    -> sparse inverse-depth target (target_h, target_w) float32 on the device (add the channel dim like `:238`)."""
+    lib = _lib.load()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("monorec_amd.input_pipeline: a HIP device is required - there is no CPU fallback")
+    if isinstance(depth_png, np.ndarray):
+        if depth_png.dtype != np.uint16:
+            raise ValueError("expected the 16-bit depth PNG as a uint16 array")
+        depth_png = torch.from_numpy(np.ascontiguousarray(depth_png).view(np.int16))
+    if depth_png.dtype not in (torch.int16, torch.uint16) or depth_png.dim() != 2:
+        raise ValueError("expected a (H, W) 16-bit image")
+    src = depth_png.contiguous().to(device, non_blocking=True)
+    h, w = src.shape
+    th, tw = int(target_image_size[0]), int(target_image_size[1])
+    box = None if crop_box is None else (ctypes.c_int32 * 4)(*[int(v) for v in crop_box])
+    owner = torch.empty(th * tw, dtype=torch.int32, device=device)
+    out = torch.empty(th, tw, dtype=torch.float32, device=device)
+    _lib.check(lib.mr_lidar_inverse_depth_u16_f32(src.data_ptr(), h, w, box, th, tw, owner.data_ptr(), out.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "mr_lidar_inverse_depth_u16_f32")
+    return out
+
+
 class FrameCache:
     """Preprocessed frames by index, least recently used evicted.  `load(index)` returns the decoded uint8 image
     (the reference: `dataset.get_cam2(index)` / `get_cam0`, a PIL image - `np.asarray` of it works)."""

@@ -99,3 +99,27 @@ def preprocess_image(img_u8, crop_box, target_h, target_w):
     out = resize_bilinear_u8(np.ascontiguousarray(img_u8), target_h, target_w)
     t = torch.tensor(out.astype(np.float32)) / 255 - .5                  # :127-128
     return torch.stack((t, t, t)) if t.dim() == 2 else t.permute(2, 0, 1)  # :129-132
+
+
+def lidar_inverse_depth(depth_png, crop_box, target_h, target_w):
+    """preprocess_depth_annotated_lidar (kitti_odometry_dataset.py:184-211) on the decoded uint16 PNG array."""
+    import torch
+    d = depth_png.astype(np.float64)
+    h, w = d.shape
+    rows, cols = np.nonzero(d)                                             # row-major order (:187)
+    inv = 256.0 / d[rows, cols]                                            # :189-190
+    pts = np.stack([rows.astype(np.float64), cols.astype(np.float64), inv])
+    if crop_box is not None:                                               # :194-200
+        x0, y0, x1, y1 = crop_box
+        sel = (y0 <= pts[0]) & (pts[0] < y1) & (x0 <= pts[1]) & (pts[1] < x1)
+        pts = pts[:, sel]
+        pts[0] -= y0
+        pts[1] -= x0
+        ch, cw = y1 - y0, x1 - x0
+    else:
+        ch, cw = h, w
+    pts[0] = np.clip(pts[0] / ch * target_h, 0, target_h - 1)              # :205
+    pts[1] = np.clip(pts[1] / cw * target_w, 0, target_w - 1)              # :206
+    out = np.zeros((target_h, target_w))
+    out[np.around(pts[0]).astype(int), np.around(pts[1]).astype(int)] = pts[2]   # :209 (last write wins)
+    return torch.tensor(out, dtype=torch.float32)

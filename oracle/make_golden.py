@@ -208,6 +208,16 @@ def main():
             raw = np.array(Image.open(f"data/kitti/sequences/07/image_2/{img_id:06d}.png"))
             assert torch.equal(input_oracle.preprocess_image(raw, box, 256, 512), ref_t), img_id
         print("input pipeline: oracle == reference preprocess_image on the 3 example frames; crop box / intrinsics equal")
+        lidar_png = np.array(Image.open("data/kitti/sequences/07/image_depth_annotated/000169.png"))
+        assert lidar_png.dtype == np.uint16 or lidar_png.max() < 65536
+        lidar_png = lidar_png.astype(np.uint16)
+        # (the sample's own target also folds the same PNG in as "DSO depth" - dso_depth defaults to on; the lidar
+        #  function is pinned on its own output)
+        lidar_ref = ds.preprocess_depth_annotated_lidar(Image.open("data/kitti/sequences/07/image_depth_annotated/000169.png"), box)
+        assert torch.equal(input_oracle.lidar_inverse_depth(lidar_png, box, 256, 512), lidar_ref), "lidar target"
+        lidar_idx = np.flatnonzero(lidar_png).astype(np.int32)
+        lidar_val = lidar_png.reshape(-1)[lidar_idx]
+        print("input pipeline: oracle == reference preprocess_depth_annotated_lidar;", lidar_idx.size, "lidar returns")
     finally:
         os.chdir(cwd)
     unsq = lambda v: v.unsqueeze(0) if torch.is_tensor(v) else [t.unsqueeze(0) for t in v]
@@ -238,6 +248,9 @@ def main():
     store["input.poses"] = torch.stack(kbatch["poses"]).numpy()
     store["input.intrinsics"] = torch.stack(kbatch["intrinsics"]).numpy()
     store["input.target"] = ktarget.numpy()
+    store["input.lidar_idx"], store["input.lidar_val"] = lidar_idx, lidar_val      # the raw 370x1226 depth PNG, sparse
+    store["input.lidar_shape"] = np.array(lidar_png.shape, dtype=np.int64)
+    store["input.lidar_target"] = lidar_ref.numpy()                                # preprocess_depth_annotated_lidar of it
     store["meta"] = np.array([1, 256, 512, 2, 32, -1, 1, 1], dtype=np.int64)
     import model.metric_functions.sparse_metrics as ref_metrics0               # noqa
     mvals = {fn: float(getattr(ref_metrics0, fn)({"result": out_ref["result"].clone(), "target": ktarget.clone()}, None, 80))

@@ -158,6 +158,19 @@ def test_reference_example_sample_with_metrics(hip_lib):
         assert abs(got - want) <= 1e-2 * max(1.0, abs(want)), (fn, got, want)
 
 
+def test_c5_shape_in_fp32(hip_lib):
+    """BASELINE configs[4] shape (512x1024, 4 source frames, 48 depth bins) through the fp32 path against the CPU
+    oracle - the shape the bf16 configuration is defined on; the bf16 kernels themselves are not built yet."""
+    model, sd = _model(48, graph=False)
+    batch = synth.make_batch(1, 512, 1024, 4, seed=5)
+    with torch.no_grad():
+        out = model(_to_dev(batch))
+    torch.cuda.synchronize()
+    ref_out = orc.forward(sd, batch, cv_depth_steps=48)
+    assert out["result"].shape == (1, 1, 512, 1024) and len(out["single_frame_cvs"]) == 4
+    _check_against(out, ref_out, "c5-shape fp32")
+
+
 def test_batch_independence(hip_lib):
     """Keyframes are independent: sample i of a batch equals the same sample run alone."""
     model, _ = _model(8, graph=False)

@@ -90,3 +90,37 @@ def test_frame_cache_decodes_each_image_once(hip_lib):
         assert torch.equal(kf.cpu(), input_oracle.preprocess_image(imgs[idx], box, 256, 512))
         assert torch.equal(frames[1].cpu(), input_oracle.preprocess_image(imgs[idx + 1], box, 256, 512))
     assert cache.decoded == 8                                           # the reference decodes 18 images for these 6 samples
+
+
+def _lidar_fixture():
+    z = np.load(os.path.join(GOLDEN, "kitti_example_169.npz"))
+    h, w = (int(v) for v in z["input.lidar_shape"])
+    png = np.zeros(h * w, dtype=np.uint16)
+    png[z["input.lidar_idx"]] = z["input.lidar_val"]
+    return png.reshape(h, w), torch.from_numpy(z["input.lidar_target"])
+
+
+def test_oracle_lidar_target_matches_reference_fixture():
+    """The example's annotated-lidar PNG (stored sparsely) -> preprocess_depth_annotated_lidar output of the reference."""
+    png, want = _lidar_fixture()
+    box = input_oracle.crop_box_for(370, 1226, 256, 512)
+    got = input_oracle.lidar_inverse_depth(png, box, 256, 512)
+    assert torch.equal(got, want) and int((want > 0).sum()) > 30000
+    # collisions exist (79 826 returns -> 35 684 cells), so the last-write-wins order is exercised
+    assert int((png > 0).sum()) > int((want > 0).sum())
+
+
+@pytest.mark.gpu
+def test_hip_lidar_target_is_bit_exact(hip_lib):
+    png, want = _lidar_fixture()
+    box = input_oracle.crop_box_for(370, 1226, 256, 512)
+    got = input_pipeline.lidar_inverse_depth(png, box, (256, 512), device=DEV)
+    assert torch.equal(got.cpu(), want)
+    # no crop, other size, synthetic returns incl. value 1 (inverse depth 256) and the 65535 maximum
+    rng = np.random.default_rng(3)
+    syn = np.zeros((90, 130), dtype=np.uint16)
+    idx = rng.choice(90 * 130, 4000, replace=False)
+    syn.reshape(-1)[idx] = rng.integers(1, 65536, 4000).astype(np.uint16)
+    syn[0, 0], syn[89, 129] = 1, 65535
+    assert torch.equal(input_pipeline.lidar_inverse_depth(syn, None, (32, 48), device=DEV).cpu(),
+                       input_oracle.lidar_inverse_depth(syn, None, 32, 48))

@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --bf16
 NON_CONV_OPS = ("resnet.maxpool", "cost_volume", "mask.max", "apply_mask")
 
 
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--spinup-seconds", type=float, default=3.0, help="minimum untimed spin-up before the timed steps")
+    ap.add_argument("--bf16", action="store_true",
+                    help="convolutions on the bf16 MFMA (BASELINE configs[4] numerics; outside the 1e-4 parity bar - never the headline)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="keyframes kept in flight per GPU (MonoRecModel.submit); 1 = strictly one forward at a time")
     ap.add_argument("--graph", action="store_true",
@@ -138,7 +141,7 @@ def main():
 
     from monorec_amd import MonoRecModel, synth
 
-    model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight)
+    model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16)
     sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -225,15 +228,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if args.bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {args.batch} keyframe(s)/step/GPU, {args.height}x{args.width}, "
-                                   f"{args.frames} source frames, {args.depths} depth bins, fp32, random-init weights",
+                                   f"{args.frames} source frames, {args.depths} depth bins, "
+                                   + ("bf16 MFMA convolutions (fp32 storage and cost volume), " if args.bf16 else "fp32, ") + "random-init weights",
                        "batch_per_gpu": args.batch, "hip_graph": args.graph, "keyframes_in_flight": args.in_flight,
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4_f32)",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
+                         "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4_f32)",
+                         "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / (BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS), "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
                          "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
                          "algorithmic_gflop_per_step": conv_flops / 1e9, "conv_ms_per_step": conv_s * 1e3},
             "cost_volume_kernel": {"bound": "hbm", "us": cv_row["seconds"] * 1e6, "algorithmic_MB": cv_bytes / 1e6,

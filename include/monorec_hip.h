@@ -27,6 +27,9 @@ extern "C" {
 
 #define MR_ABI_VERSION 2
 
+#define MR_COMPUTE_F32  0
+#define MR_COMPUTE_BF16 1
+
 #define MR_ERR_BAD_ARGUMENT (-1)
 #define MR_ERR_UNSUPPORTED  (-2)
 #define MR_ERR_LDS_BUDGET   (-3)
@@ -111,6 +114,12 @@ typedef struct mr_conv_desc {
      * SIMD from every workgroup, which hides the chunk-fill stalls.  8 needs the direct-read dwordx4 path
      * (in_mode DIRECT, no in_transform, src_w % 4 == 0); otherwise MR_ERR_UNSUPPORTED. */
     int32_t waves_per_wg;
+    /* MR_COMPUTE_F32 (0, default): v_mfma_f32_16x16x4_f32, exact fp32 products - the path that meets the 1e-4 parity bar.
+     * MR_COMPUTE_BF16: v_mfma_f32_16x16x16_bf16 - packed_weights / phase_weights from mr_conv_pack_weights_bf16, the
+     * activations (still fp32 in memory) are rounded to bf16 (nearest even) as the B fragment is formed, fp32 accumulate:
+     * the numerics of "bf16 weights and activations, fp32 accumulate" (BASELINE configs[4]).  chunk_channels in
+     * {16, 32, 64}; LDS-DMA staged inputs only (in_mode DIRECT / UPSAMPLE2, no in_transform). */
+    int32_t compute_dtype;
 } mr_conv_desc;
 
 /* number of floats of the packed weight image for a conv with the given source split and schedule
@@ -126,6 +135,14 @@ size_t mr_conv_packed_weight_floats(int32_t out_channels, const int32_t* src_cha
 int mr_conv_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels,
                              int32_t num_src, int32_t kh, int32_t kw, int32_t cout_blocks_per_wg,
                              int32_t chunk_channels, float* dst);
+
+/* The same two functions for MR_COMPUTE_BF16 launches: sources padded to multiples of 16 channels, weights rounded to bf16
+ * (nearest even), 4 bf16 per lane and k-step (layout in csrc/conv_layout.h).  `dst` is still sized in floats. */
+size_t mr_conv_packed_weight_floats_bf16(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                         int32_t kh, int32_t kw, int32_t cout_blocks_per_wg, int32_t chunk_channels);
+int mr_conv_pack_weights_bf16(const float* weight, int32_t out_channels, const int32_t* src_channels,
+                              int32_t num_src, int32_t kh, int32_t kw, int32_t cout_blocks_per_wg,
+                              int32_t chunk_channels, float* dst);
 
 /* bytes of dynamic LDS the launch will request (for planning / tests); negative MR_ERR_* if invalid */
 int64_t mr_conv2d_lds_bytes(const mr_conv_desc* desc);

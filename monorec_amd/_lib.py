@@ -51,6 +51,7 @@ class ConvDesc(ctypes.Structure):
         ("phase_pad_top", ctypes.c_int32 * 4), ("phase_pad_left", ctypes.c_int32 * 4),
         ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4),
         ("waves_per_wg", ctypes.c_int32),
+        ("compute_dtype", ctypes.c_int32),
     ]
 
 
@@ -61,6 +62,11 @@ ABI = {
     "mr_conv_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv_packed_weight_floats_bf16": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mr_conv_pack_weights_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv2d_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(ConvDesc)]),
     "mr_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "mr_cost_volume_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,

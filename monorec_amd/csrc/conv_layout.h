@@ -34,3 +34,12 @@ MR_HD static inline int mr_chunks_of(int c, int ck) { return mr_ceil_div(mr_pad4
 MR_HD static inline int64_t mr_chunk_weight_floats(int ckq, int taps, int mb) {
     return (int64_t)taps * (ckq / 4) * mb * 64;
 }
+
+// ---- bf16 MFMA mode (v_mfma_f32_16x16x16_bf16: weights stored as bf16, activations rounded to bf16 when the B fragment is
+// formed, fp32 accumulate).  One k-step = 16 input channels of one tap; sources are padded to multiples of 16.  Lane
+// (l&15 = cout, g = l>>4) holds, as its 4 consecutive k elements j = 0..3, channels c0 + 16*c16 + 4*j + g - element j of
+// lane group g is channel 4j+g, not 4g+j, so that the four lane groups of a B read touch neighbouring channel planes
+// (plane stride = 16 mod 32 banks: conflict free) exactly like the fp32 path.  Packed order
+//   [g][chunk][tap][c16][m] -> 64 lanes x 4 bf16 (8 bytes per lane) = 128 floats.
+MR_HD static inline int mr_pad16(int c) { return (c + 15) & ~15; }
+MR_HD static inline int mr_pad_channels(int c, int bf16) { return bf16 ? mr_pad16(c) : mr_pad4(c); }

@@ -70,6 +70,7 @@ struct ConvKArgs {
     int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores,
                                // 16 per-workgroup timestamps (tools/wg_timeline.py)
     int ksplit, nchunks, batch, nphase;
+    int bf16;                  // 1: bf16 MFMA mode (weights bf16, activations rounded to bf16 in the B fragment)
     int tiles_y, ngroups, ks_shift;   // ks_shift: log2(ksplit) or -1
     long long wgroup_stride;   // packed floats per cout group
     float* ws;
@@ -201,7 +202,7 @@ struct ChunkCursor {
 template <int MB>
 __device__ __forceinline__ void cursor_advance(const ConvKArgs& a, ChunkCursor& c, int T) {
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
-    c.woff += (long long)T * (ck >> 2) * MB * 64;
+    c.woff += (long long)T * ck * MB * (a.bf16 ? 8 : 16);
     c.c0 += a.CK;
     if (c.c0 >= a.src_cpad[c.s]) { c.c0 = 0; ++c.s; }
 }
@@ -218,7 +219,7 @@ __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCurso
                                             const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT],
                                             const int (&voff4)[MR_MAX_G4]) {
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
-    const int wfloats = T * (ck >> 2) * MB * 64;
+    const int wfloats = T * ck * MB * (a.bf16 ? 8 : 16);
     const float* wsrc = wgrp + c.woff;
     const int n1k = (a.dbg & 4) ? 0 : wfloats >> 8;   // 1 KiB pieces (64 lanes x 16 B)
     for (int kb = wave; kb < n1k; kb += nwave) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
@@ -310,10 +311,64 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
     }
 }
 
+// ---- bf16 MFMA sweep: one v_mfma_f32_16x16x16_bf16 per (cout block, pixel block) and 16 input channels of a tap -------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x4 pack_bf16x4(float x0, float x1, float x2, float x3) {   // round to nearest even
+    const bf16x2 lo = __builtin_convertvector((f32x2){x0, x1}, bf16x2);
+    const bf16x2 hi = __builtin_convertvector((f32x2){x2, x3}, bf16x2);
+    union { bf16x2 h[2]; s16x4 v; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void kstep_bf16(f32x4 (&acc)[MB][NB], const float* __restrict__ wt, const float* __restrict__ ldsI,
+                                           const int (&lbase)[NB], int c16, int off, int plane4) {
+    s16x4 av[MB], bv[NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const f32x2 raw = *(const f32x2*)(wt + (c16 * MB + m) * 128);       // wt already includes lane * 2
+        union { f32x2 f; s16x4 v; } u;
+        u.f = raw;
+        av[m] = u.v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float* p = ldsI + lbase[i] + off;                            // channel (lane >> 4) of this 16-channel step
+        bv[i] = pack_bf16x4(p[0], p[plane4], p[2 * plane4], p[3 * plane4]);   // channels g, 4+g, 8+g, 12+g
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[i], acc[m][i], 0, 0, 0);
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void sweep_chunk_bf16(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
+                                                 const int (&lbase)[NB], int ck16, int lane) {
+    const float* wl = ldsW + lane * 2;
+    const int plane4 = 4 * a.PLANE;
+    for (int kh = 0; kh < a.KH; ++kh) {
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int tapoff = kh * a.IWa + kw;
+            const float* wt = wl + (kh * a.KW + kw) * ck16 * (MB * 128);
+            int c16 = 0;
+            for (; c16 + 2 <= ck16; c16 += 2) {
+                kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
+                kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16 + 1, (c16 + 1) * 16 * a.PLANE + tapoff, plane4);
+            }
+            for (; c16 < ck16; ++c16) kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
+        }
+    }
+}
+
 // DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
 // max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
 // make hipcc drain vmcnt before every sweep and spill SGPRs).
-template <int MB, int NB, bool DMA_IN, int WV>
+template <int MB, int NB, bool DMA_IN, int WV, bool BF16>
 __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     dbg_stamp(a, 0);
@@ -428,7 +483,10 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
             issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
         }
         if (stamp) dbg_stamp(a, 5);
-        if (!(a.dbg & 1)) sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
+        if (!(a.dbg & 1)) {
+            if (BF16) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
+            else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
+        }
         if (stamp) dbg_stamp(a, 6);
         dma_wait_all();                                // this wave's share of the next chunk has landed
         if (stamp) dbg_stamp(a, 7);
@@ -574,16 +632,20 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.in_mode = d->in_mode;
     k.in_tf = d->in_transform;
     k.CK = d->chunk_channels;
+    const int bf16 = d->compute_dtype == MR_COMPUTE_BF16 ? 1 : 0;
+    if (d->compute_dtype != MR_COMPUTE_F32 && !bf16) return MR_ERR_BAD_ARGUMENT;
+    if (bf16 && k.CK < 16) return MR_ERR_BAD_ARGUMENT;
+    k.bf16 = bf16;
     int nchunks = 0, cpad_total = 0;
     for (int s = 0; s < d->num_src; ++s) {
         if (!d->src[s] || d->src_channels[s] < 1) return MR_ERR_BAD_ARGUMENT;
         k.src[s] = d->src[s];
         k.src_c[s] = d->src_channels[s];
-        k.src_cpad[s] = mr_pad4(d->src_channels[s]);
+        k.src_cpad[s] = mr_pad_channels(d->src_channels[s], bf16);
         const long long sbytes = (long long)d->batch * d->src_channels[s] * d->src_h * d->src_w * 4;
         if (sbytes >= (1ll << 31)) return MR_ERR_UNSUPPORTED;   // 32-bit byte offsets in the SRD path
         k.src_bytes[s] = (int)sbytes;
-        nchunks += mr_chunks_of(d->src_channels[s], k.CK);
+        nchunks += mr_ceil_div(k.src_cpad[s], k.CK);
         cpad_total += k.src_cpad[s];
     }
     if (d->split_k > nchunks) return MR_ERR_BAD_ARGUMENT;
@@ -642,13 +704,13 @@ int derive(const mr_conv_desc* d, Derived* out) {
         k.PLANE = plane; k.ppt = mr_ceil_div(k.IH * k.IW, 256); if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED; }
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
     const int taps = k.KH * k.KW;
-    k.wgroup_stride = (long long)taps * (cpad_total / 4) * mb * 64;
+    k.wgroup_stride = (long long)taps * cpad_total * mb * (bf16 ? 8 : 16);
     int ck_max = 0;                                              // largest chunk of any source
     for (int s = 0; s < d->num_src; ++s) {
         const int c = k.src_cpad[s] < k.CK ? k.src_cpad[s] : k.CK;
         if (c > ck_max) ck_max = c;
     }
-    k.wmax_floats = taps * (ck_max / 4) * mb * 64;
+    k.wmax_floats = taps * ck_max * mb * (bf16 ? 8 : 16);
     // two pipeline buffers - one when no workgroup ever streams a second chunk
     const int nbuf = mr_ceil_div(nchunks, d->split_k) > 1 ? 2 : 1;
     out->lds_bytes = nbuf * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);
@@ -659,6 +721,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb; out->wv = wv;
     if (wv == 8 && !k.dma_x4) return MR_ERR_UNSUPPORTED;
+    if (bf16 && !k.dma_in) return MR_ERR_UNSUPPORTED;                 // bf16 mode: LDS-DMA staged inputs only
     k.tiles_y = tiles_y;
     k.ngroups = mr_ceil_div(k.CB, mb);
     k.ks_shift = -1;
@@ -668,39 +731,36 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB, bool DMA_IN, int WV>
+template <int MB, int NB, bool DMA_IN, int WV, bool BF16>
 int launch(const Derived& dv, hipStream_t stream) {
     static bool attr_set = false;  // raise the dynamic-LDS ceiling once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
+}
+
+template <int MB, int NB>
+int launch_variant(const Derived& dv, hipStream_t stream) {
+    if (dv.k.bf16) {                                   // LDS-DMA staging only (derive() checked)
+        if (dv.wv == 8) return launch<MB, NB, true, 8, true>(dv, stream);
+        return launch<MB, NB, true, 4, true>(dv, stream);
+    }
+    if (dv.wv == 8) return launch<MB, NB, true, 8, false>(dv, stream);     // dwordx4 DMA path only (derive() checked)
+    if (dv.k.dma_in) return launch<MB, NB, true, 4, false>(dv, stream);
+    return launch<MB, NB, false, 4, false>(dv, stream);
 }
 
 template <int MB>
 int launch_nb(const Derived& dv, hipStream_t stream) {
-    if (dv.wv == 8) {                                  // dwordx4 DMA path only (derive() checked)
-        switch (dv.nb) {
-            case 1: return launch<MB, 1, true, 8>(dv, stream);
-            case 2: return launch<MB, 2, true, 8>(dv, stream);
-            default: return launch<MB, 4, true, 8>(dv, stream);
-        }
-    }
-    if (dv.k.dma_in) {
-        switch (dv.nb) {
-            case 1: return launch<MB, 1, true, 4>(dv, stream);
-            case 2: return launch<MB, 2, true, 4>(dv, stream);
-            default: return launch<MB, 4, true, 4>(dv, stream);
-        }
-    }
     switch (dv.nb) {
-        case 1: return launch<MB, 1, false, 4>(dv, stream);
-        case 2: return launch<MB, 2, false, 4>(dv, stream);
-        default: return launch<MB, 4, false, 4>(dv, stream);
+        case 1: return launch_variant<MB, 1>(dv, stream);
+        case 2: return launch_variant<MB, 2>(dv, stream);
+        default: return launch_variant<MB, 4>(dv, stream);
     }
 }
 
@@ -741,6 +801,59 @@ extern "C" int mr_conv_pack_weights_f32(const float* weight, int32_t out_channel
                                     v = weight[((size_t)cout * cin_total + (cin_off + cl)) * taps + tap];
                                 dst[o++] = v;
                             }
+            }
+            cin_off += src_channels[s];
+        }
+    }
+    return 0;
+}
+
+namespace {
+uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+}  // namespace
+
+extern "C" size_t mr_conv_packed_weight_floats_bf16(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                                    int32_t kh, int32_t kw, int32_t mb, int32_t ck) {
+    if (!src_channels || num_src < 1 || !valid_mb(mb) || !valid_ck(ck) || ck < 16) return 0;
+    const int groups = mr_ceil_div(mr_ceil_div(out_channels, 16), mb);
+    int cpad_total = 0;
+    for (int s = 0; s < num_src; ++s) cpad_total += mr_pad16(src_channels[s]);
+    return (size_t)groups * kh * kw * (cpad_total / 16) * mb * 128;
+}
+
+extern "C" int mr_conv_pack_weights_bf16(const float* weight, int32_t out_channels, const int32_t* src_channels,
+                                         int32_t num_src, int32_t kh, int32_t kw, int32_t mb, int32_t ck, float* dst) {
+    if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES) return MR_ERR_BAD_ARGUMENT;
+    if (!valid_mb(mb) || !valid_ck(ck) || ck < 16) return MR_ERR_BAD_ARGUMENT;
+    const int groups = mr_ceil_div(mr_ceil_div(out_channels, 16), mb);
+    const int taps = kh * kw;
+    int cin_total = 0;
+    for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
+    uint16_t* o = (uint16_t*)dst;
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = mr_pad16(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += ck) {
+                const int ckq = cpad - c0 < ck ? cpad - c0 : ck;
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int c16 = 0; c16 < ckq / 16; ++c16)
+                        for (int m = 0; m < mb; ++m)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 4; ++j) {
+                                    const int cout = (g * mb + m) * 16 + (lane & 15);
+                                    const int cl = c0 + c16 * 16 + 4 * j + (lane >> 4);     // element j of lane group g: channel 4j+g
+                                    float v = 0.f;
+                                    if (cout < out_channels && cl < src_channels[s])
+                                        v = weight[((size_t)cout * cin_total + (cin_off + cl)) * taps + tap];
+                                    *o++ = bf16_rne(v);
+                                }
             }
             cin_off += src_channels[s];
         }

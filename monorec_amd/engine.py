@@ -35,19 +35,21 @@ def same_pad(n, k, s):
     return math.floor(total / 2), math.ceil(total / 2)
 
 
-def pack_conv_weight(weight, src_channels, mb, ck):
+def pack_conv_weight(weight, src_channels, mb, ck, bf16=False):
     """(Cout, sum(src_channels), kh, kw) fp32 CPU tensor -> packed A-fragment stream (CPU tensor) for a
-    launch with `mb` cout blocks per workgroup and `ck` channels per LDS chunk (csrc/conv_layout.h)."""
+    launch with `mb` cout blocks per workgroup and `ck` channels per LDS chunk (csrc/conv_layout.h);
+    bf16=True: the bf16 stream of MR_COMPUTE_BF16 launches."""
     lib = _lib.load()
     w = weight.detach().to(torch.float32).contiguous().cpu()
     cout, cin, kh, kw = w.shape
     assert cin == sum(src_channels), (cin, src_channels)
     sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
-    n = lib.mr_conv_packed_weight_floats(cout, sc, len(src_channels), kh, kw, mb, ck)
+    count, pack = ((lib.mr_conv_packed_weight_floats_bf16, lib.mr_conv_pack_weights_bf16) if bf16 else
+                   (lib.mr_conv_packed_weight_floats, lib.mr_conv_pack_weights_f32))
+    n = count(cout, sc, len(src_channels), kh, kw, mb, ck)
     assert n > 0, (mb, ck)
     out = torch.empty(n, dtype=torch.float32)
-    _lib.check(lib.mr_conv_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), kh, kw, mb, ck, out.data_ptr()),
-               "mr_conv_pack_weights_f32")
+    _lib.check(pack(w.data_ptr(), cout, sc, len(src_channels), kh, kw, mb, ck, out.data_ptr()), "mr_conv_pack_weights")
     return out
 
 
@@ -98,13 +100,13 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4):
                 tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
 
 
-def lds_bytes(geo, taps, cpads, mb, ck, split_k=1):
+def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False):
     """Dynamic LDS of one workgroup: pipeline buffers of (input tile + A fragments of the largest chunk) - two,
     or one when no workgroup streams a second chunk (mirrors derive() in csrc/conv_mfma.hip)."""
     ck_max = max(min(c, ck) for c in cpads)
     nchunks = sum(math.ceil(c / ck) for c in cpads)
     nbuf = 2 if math.ceil(nchunks / split_k) > 1 else 1
-    return nbuf * 4 * (ck * geo["plane"] + taps * (ck_max // 4) * mb * 64)
+    return nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if bf16 else 16))
 
 
 TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
@@ -122,14 +124,16 @@ def _load_tuned():
 _load_tuned()
 
 
-def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases):
-    return f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
+def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False):
+    return (f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
+            + ("_bf16" if bf16 else ""))
 
 
-def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024):
+def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False):
     """All launchable (mb, nb, split_k, ck) for a conv, with the workgroup count of each."""
     cb = (cout + 15) // 16
-    cpads = [(c + 3) // 4 * 4 for c in src_channels]
+    unit = 16 if bf16 else 4
+    cpads = [(c + unit - 1) // unit * unit for c in src_channels]
     taps = kh * kw
     out = []
     for waves in (4, 8):
@@ -143,7 +147,7 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                 if mb > cb and mb != 1:
                     continue
                 groups = math.ceil(cb / mb)
-                for ck in (8, 16, 32, 64):
+                for ck in ((16, 32, 64) if bf16 else (8, 16, 32, 64)):
                     if ck > 16 and ck // 2 >= max(cpads):
                         continue
                     nchunks = sum(math.ceil(c / ck) for c in cpads)
@@ -151,7 +155,7 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                     for sk in (1, 2, 4, 8, 16):
                         if sk > nchunks:
                             break
-                        lds = lds_bytes(geo, taps, cpads, mb, ck, sk)
+                        lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16)
                         if lds > lds_cap:
                             continue
                         out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, wgs=wgs * sk, nchunks=nchunks,
@@ -159,15 +163,15 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
     return out
 
 
-def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1):
+def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, bf16=False):
     """(MB, NB, split_k, CK) for mr_conv2d_f32.  A tuned table (tools/tune_conv.py, measured on MI355X)
     wins; otherwise a model: biggest register tile that still puts >= 3 workgroups on each of the 256 CUs,
     deepest chunk that keeps >= 3 workgroups' LDS on a CU, split-K only to fill the machine."""
-    sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases)
+    sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16)
     if sig in TUNED:
         return TUNED[sig]
     best = None
-    for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=80 * 1024):
+    for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=80 * 1024, bf16=bf16):
         if c["waves"] != 4:          # 8-wave workgroups only through the measured table
             continue
         reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
@@ -190,7 +194,7 @@ class Plan:
     """Buffers + launch list for one input shape. `state` is a CPU state dict with the reference keys."""
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
-                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True):
+                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -202,6 +206,7 @@ class Plan:
         self.alpha = float(alpha)
         self.cw = (ctypes.c_float * 3)(*[float(torch.tensor(c, dtype=torch.float32)) for c in channel_weights])
         self.schedule_override = schedule_override or {}
+        self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
         self.buf = {}
         self.keep = []          # packed weights / biases (device tensors kept alive)
@@ -214,9 +219,9 @@ class Plan:
             self.finalize()
 
     @classmethod
-    def bare(cls, device, state=None, schedule_override=None):
+    def bare(cls, device, state=None, schedule_override=None, bf16=False):
         """Plan without the network: lets tests / micro-benchmarks launch single ops through the C ABI."""
-        return cls(state or {}, 1, 32, 32, 1, 4, (0.33, 0.0025), device, schedule_override=schedule_override, build=False)
+        return cls(state or {}, 1, 32, 32, 1, 4, (0.33, 0.0025), device, schedule_override=schedule_override, build=False, bf16=bf16)
 
     def finalize(self):
         """Allocate the per-stage split-K workspace once all launches are known."""
@@ -260,8 +265,9 @@ class Plan:
         assert cin == sum(src_channels), (name, cin, src_channels)
         out_h, out_w = grid
         nph = 1 if phases is None else len(phases)
+        bf16 = self.bf16 and in_mode != IN_MAXPOOL2 and tf == TF_NONE       # bf16 mode needs the LDS-DMA staging
         sched = self.schedule_override.get(name) or choose_schedule(cout, src_channels, kh, kw, stride[0], stride[1],
-                                                                    out_h, out_w, n, nph)
+                                                                    out_h, out_w, n, nph, bf16)
         mb, nb, split_k, ck = sched[:4]
         waves = sched[4] if len(sched) > 4 else 4
         d = ConvDesc()
@@ -278,12 +284,12 @@ class Plan:
         d.dst_plane_h, d.dst_plane_w = out.shape[2], out.shape[3]
         d.out_step_h, d.out_step_w, d.out_off_h, d.out_off_w = out_step[0], out_step[1], out_off[0], out_off[1]
         if phases is None:
-            d.packed_weights = self._dev(pack_conv_weight(weight, src_channels, mb, ck)).data_ptr()
+            d.packed_weights = self._dev(pack_conv_weight(weight, src_channels, mb, ck, bf16)).data_ptr()
             d.num_phases = 1
         else:
             d.num_phases = nph
             for i, (wp, pt, pl, oh, ow) in enumerate(phases):
-                d.phase_weights[i] = self._dev(pack_conv_weight(wp, src_channels, mb, ck)).data_ptr()
+                d.phase_weights[i] = self._dev(pack_conv_weight(wp, src_channels, mb, ck, bf16)).data_ptr()
                 d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh, ow
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         if residual is not None:
@@ -292,6 +298,7 @@ class Plan:
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
         d.waves_per_wg = waves
+        d.compute_dtype = 1 if bf16 else 0
         if split_k > 1:
             self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
                                          split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
@@ -305,7 +312,7 @@ class Plan:
         wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
         self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
-                                  sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph),
+                                  sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16), bf16=bf16,
                                   spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),
                                             stride=tuple(stride), pad=tuple(pad), grid=(out_h, out_w), in_mode=in_mode,
                                             tf=tf, act=act, p0=p0, p1=p1, residual=residual is not None,

@@ -193,7 +193,7 @@ class MonoRecModel(nn.Module):
                  pretrain_dropout_mode=0, augmentation=None, use_mono=True, use_stereo=False, use_ssim=True,
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
-                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2):
+                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -227,6 +227,8 @@ class MonoRecModel(nn.Module):
                 f"unsupported non-default options: {bad} (SURVEY.md section 8 f-4)")
         self._hip_graph = bool(hip_graph)
         self._in_flight = max(1, int(hip_in_flight))
+        self._bf16 = bool(hip_bf16)     # convolutions on the bf16 MFMA (weights/activations rounded to bf16, fp32 accumulate):
+                                        # BASELINE configs[4]; NOT within the 1e-4 parity bar of the fp32 default
         self._next_slot = 0
         self._plans = {}
         self._graphs = {}
@@ -290,7 +292,7 @@ class MonoRecModel(nn.Module):
             if self._packed_state is None or self._packed_state[0] != str(device):
                 self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
             plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
-                        alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights)
+                        alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()

@@ -217,3 +217,35 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
                for c in plan.conv_log)
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 4        # the four Refine transposed convolutions
     assert len(plan.stages["encoder"]) == 22 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
+
+
+def test_bf16_weight_packing_layout(hip_lib):
+    """mr_conv_pack_weights_bf16: lane (cout l&15, group g = l>>4), element j = channel 16*c16 + 4*j + g of the chunk, rounded
+    to bf16 (nearest even), sources padded to 16 channels (csrc/conv_layout.h)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(2)
+    srcs, cout, kh, kw, mb, ck = [20, 5], 40, 3, 1, 2, 32
+    w = torch.randn(cout, sum(srcs), kh, kw, generator=g)
+    packed = engine.pack_conv_weight(w, srcs, mb, ck, bf16=True)
+    u16 = packed.numpy().view(np.uint16)
+    want_bits = (w.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
+    o = 0
+    groups = -(-(-(-cout // 16)) // mb)
+    for grp in range(groups):
+        cin_off = 0
+        for sc in srcs:
+            cpad = -(-sc // 16) * 16
+            for c0 in range(0, cpad, ck):
+                ckq = min(ck, cpad - c0)
+                for tap in range(kh * kw):
+                    for c16 in range(ckq // 16):
+                        for m in range(mb):
+                            blk = u16[o:o + 256].reshape(64, 4)
+                            o += 256
+                            for lane in (0, 17, 35, 63):
+                                for j in range(4):
+                                    co, cl = (grp * mb + m) * 16 + (lane & 15), c0 + c16 * 16 + 4 * j + (lane >> 4)
+                                    exp = want_bits[co, cin_off + cl, tap // kw, tap % kw] if co < cout and cl < sc else 0
+                                    assert blk[lane, j] == exp, (grp, sc, c0, tap, c16, m, lane, j)
+            cin_off += sc
+    assert o == u16.size

@@ -176,6 +176,63 @@ def test_small_kernels(hip_lib):
     assert torch.equal(cvd.cpu(), (1 - mask) * cv)
 
 
+BF16_CASES = [
+    # (srcs_c, cout, k, stride, pad, hw, batch, act, in_mode, residual, (mb, nb, split_k, ck, waves))
+    ((32,), 32, (3, 3), (1, 1), (1, 1), (40, 64), 2, ACT_LEAKY_RELU, IN_DIRECT, False, (2, 4, 1, 16, 4)),
+    ((3,), 64, (7, 7), (2, 2), (3, 3), (64, 96), 1, ACT_RELU, IN_DIRECT, False, (2, 2, 1, 16, 4)),
+    ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_LEAKY_RELU, IN_DIRECT, False, (3, 1, 4, 16, 4)),
+    ((64,), 64, (3, 3), (1, 1), (1, 1), (20, 24), 1, ACT_RELU, IN_DIRECT, True, (1, 1, 1, 64, 4)),
+    ((96, 256), 96, (2, 2), (1, 1), (0, 0), (4, 6), 1, ACT_NONE, IN_UPSAMPLE2, False, (6, 1, 1, 16, 4)),
+    ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, False, (4, 1, 1, 16, 8)),
+    ((24,), 1, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, False, (1, 4, 1, 32, 4)),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=[f"bf16conv{i}" for i in range(len(BF16_CASES))])
+def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
+    """MR_COMPUTE_BF16: products of bf16-rounded weights and activations are exact in fp32, so against a float64
+    convolution of the rounded operands only the summation order differs."""
+    srcs_c, cout, k, stride, pad, (hs, ws), n, act, in_mode, use_res, sched = case
+    g = torch.Generator().manual_seed(11)
+    srcs = [torch.randn(n, c, hs, ws, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    weight = torch.randn(cout, cin, *k, generator=g) / math.sqrt(cin * k[0] * k[1])
+    bias = torch.randn(cout, generator=g)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    x = torch.cat(srcs, 1)
+    if in_mode == IN_UPSAMPLE2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    hin, win = x.shape[2], x.shape[3]
+    ho = (hin + 2 * pad[0] - k[0]) // stride[0] + 1
+    wo = (win + 2 * pad[1] - k[1]) // stride[1] + 1
+    if in_mode == IN_UPSAMPLE2:
+        ho, wo = hin, win
+        xr = F.pad(x, [0, 1, 0, 1])
+    else:
+        xr = F.pad(x, [pad[1], pad[1], pad[0], pad[0]])
+    ref = F.conv2d(rb(xr), rb(weight), bias.double(), stride=stride).float()[:, :, :ho, :wo]
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    p0, p1 = (0.1, 0.0) if act == ACT_LEAKY_RELU else (0.0025, 0.33)
+    ref = _act_ref(ref, act, p0, p1)
+    plan = engine.Plan.bare(DEV, schedule_override={"t": sched}, bf16=True)
+    out = plan.alloc("out", n, cout, ho, wo)
+    out.fill_(float("nan"))
+    plan.conv("main", "t", [s.to(DEV) for s in srcs], weight, bias, out, stride=stride, pad=pad, grid=(ho, wo),
+              act=act, p0=p0, p1=p1, in_mode=in_mode, residual=res.to(DEV) if use_res else None)
+    assert plan.conv_log[0]["bf16"]
+    _run(plan)
+    got = out.cpu()
+    assert not torch.isnan(got).any()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    # and it really is a different arithmetic from the fp32 path: the unrounded reference is ~1e-2 away
+    full = F.conv2d(xr.double(), weight.double(), bias.double(), stride=stride).float()[:, :, :ho, :wo]
+    if act == ACT_LEAKY_RELU and not use_res:
+        assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
+
+
 def _hip_cost_volume(batch, d):
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)

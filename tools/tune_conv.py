@@ -59,8 +59,8 @@ def time_op_streams(fn, streams, reps=5, warm=2):
     return e0.elapsed_time(e1) * 1e-3 / (reps * len(streams))
 
 
-def build_candidate(spec, sched, tensors):
-    plan = engine.Plan.bare(DEV, schedule_override={"t": sched})
+def build_candidate(spec, sched, tensors, bf16=False):
+    plan = engine.Plan.bare(DEV, schedule_override={"t": sched}, bf16=bf16)
     srcs, out, res, weight, bias, phase_w = tensors
     phases = None
     if spec["phases"] is not None:
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="time each candidate on this many concurrent streams")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--lds-cap", type=int, default=80 * 1024)
+    ap.add_argument("--bf16", action="store_true", help="tune the MR_COMPUTE_BF16 launches (hip_bf16=True plans)")
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     model = MonoRecModel(cv_depth_steps=args.depths)
     sd = synth.seeded_state_dict(model.state_dict())
     engine.TUNED.clear()
-    plan = engine.Plan(sd, args.batch, args.height, args.width, args.frames, args.depths, (0.33, 0.0025), "cpu")
+    plan = engine.Plan(sd, args.batch, args.height, args.width, args.frames, args.depths, (0.33, 0.0025), "cpu", bf16=args.bf16)
     table = {}
     if args.merge and os.path.exists(args.out):
         table = json.load(open(args.out))
@@ -109,7 +110,7 @@ def main():
         src_channels = [s[1] for s in spec["src_shapes"]]
         nph = 1 if spec["phases"] is None else len(spec["phases"])
         cands = engine.candidate_schedules(cout, src_channels, kh, kw, spec["stride"][0], spec["stride"][1],
-                                           spec["grid"][0], spec["grid"][1], c["batch"], nph, lds_cap=args.lds_cap)
+                                           spec["grid"][0], spec["grid"][1], c["batch"], nph, lds_cap=args.lds_cap, bf16=c.get("bf16", False))
         # prune: split-K only while the launch is short of ~8 workgroups per CU; drop tiny grids
         keep = []
         for cd in cands:
@@ -132,7 +133,7 @@ def main():
         for cd in keep:
             sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"], cd["waves"])
             try:
-                p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w))
+                p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w), c.get("bf16", False))
                 t = time_op(fn, reps=args.reps) if args.streams <= 1 else time_op_streams(fn, streams, reps=args.reps)
             except RuntimeError as e:
                 rows.append((sched, None, str(e)[:60]))

@@ -1,0 +1,96 @@
+"""The evaluation loop of the reference (`Evaluater.eval`, evaluater/evaluater.py:38-50,78-118) around the MI355X path
+(second half of SURVEY section 8 row f-1).
+
+The reference evaluates seven metric functions per batch, each re-deriving its masks from the full tensors and each
+ending in a host synchronisation (`acc_metrics[i] += metric(...)`, :43).  Here a batch costs one forward (kept in
+flight through `MonoRecModel.submit`) and one fused reduction launch; the per-sample sums stay on the device and are
+copied once, after the last batch.  The bookkeeping - a batch with a NaN metric counts as invalid and contributes
+zeros (:45-49), `metrics` = sum over valid batches / number of valid batches (:116), `metrics_correct` = running
+average weighted by batch size (:100-104) - is reproduced on the host in float64 like the numpy code it mirrors.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import metrics as _metrics
+
+
+def evaluation_log(per_batch_metrics, batch_sizes):
+    """per_batch_metrics: list of equal-length sequences (float, NaN allowed), batch_sizes: list of ints ->
+    {'metrics', 'metrics_correct', 'valid_batches'} with the reference's rules (evaluater.py:45-49,94-118)."""
+    n = len(per_batch_metrics[0]) if per_batch_metrics else 0
+    total, valid_total, running = np.zeros(n), np.zeros(n), np.zeros(n)
+    seen = 0
+    for vals, bsz in zip(per_batch_metrics, batch_sizes):
+        acc = np.zeros(n)
+        for i, v in enumerate(vals):
+            acc[i] += float(v)
+        if np.any(np.isnan(acc)):
+            acc, valid = np.zeros(n), np.zeros(n)
+        else:
+            valid = np.ones(n)
+        total += acc
+        valid_total += valid
+        running = acc.copy() if seen == 0 else running * (seen / (seen + bsz)) + acc * (bsz / (seen + bsz))
+        seen += bsz
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean = total / valid_total
+    return {"metrics": mean.tolist(), "metrics_correct": running.tolist(),
+            "valid_batches": float(valid_total[0]) if n else 0.0}
+
+
+class Evaluater:
+    """`Evaluater(model, roi=, max_distance=).eval(data_loader)` -> the reference's log dict (without the loss entries,
+    which are constant zero there, evaluater.py:85-86).  `data_loader` yields `(data_dict, target)` like the reference's
+    loaders; tensors may live on the host (they are moved) or already on the model's device."""
+
+    def __init__(self, model, roi=None, max_distance=None, metric_names=_metrics.SPARSE_METRICS, in_flight=2):
+        unknown = [m for m in metric_names if m not in _metrics.SPARSE_METRICS]
+        if unknown:
+            raise NotImplementedError(f"metrics outside the fused sparse set: {unknown}")
+        self.model, self.roi, self.max_distance = model, roi, max_distance
+        self.metric_names = tuple(metric_names)
+        self._cols = [_metrics.SPARSE_METRICS.index(m) for m in self.metric_names]
+        self.in_flight = max(1, in_flight)
+
+    @staticmethod
+    def _to(obj, device):
+        if torch.is_tensor(obj):
+            return obj.to(device, non_blocking=True)
+        if isinstance(obj, (list, tuple)):
+            return [Evaluater._to(o, device) for o in obj]
+        if isinstance(obj, dict):
+            return {k: Evaluater._to(v, device) for k, v in obj.items()}
+        return obj
+
+    def eval(self, data_loader):
+        device = next(self.model.parameters()).device
+        sums, sizes = [], []
+        pending = collections.deque()
+
+        def collect():
+            data, handle = pending.popleft()
+            out = handle.result()                                   # ordered behind the forward on the caller's stream
+            sums.append(_metrics.sparse_metric_sums_device({"result": out["result"], "target": data["target"]},
+                                                           self.roi, self.max_distance))
+            sizes.append(int(data["target"].shape[0]))
+
+        self.model.eval()
+        with torch.no_grad():
+            for data, target in data_loader:
+                data = self._to(data, device)
+                data["target"] = self._to(target, device)
+                pending.append((data, self.model.submit(data)))
+                if len(pending) >= self.in_flight:
+                    collect()
+            while pending:
+                collect()
+        if not sums:
+            return evaluation_log([], [])
+        host = [s.cpu() for s in sums] if len({tuple(s.shape) for s in sums}) > 1 else list(torch.stack(sums).cpu())
+        per_batch = []
+        for s in host:
+            vals = _metrics.metrics_from_sums(s)
+            per_batch.append([float(vals[c]) for c in self._cols])
+        return evaluation_log(per_batch, sizes)

@@ -16,15 +16,11 @@ from . import _lib
 _CACHE_KEY = "_monorec_amd_metric_sums"
 
 
-def sparse_metric_sums(data_dict, roi=None, max_distance=None):
-    """(B, 8) float64 CPU tensor of per-sample sums; cached on `data_dict` for the (result, target, roi, dist) at hand."""
+def sparse_metric_sums_device(data_dict, roi=None, max_distance=None):
+    """(B, 8) float64 DEVICE tensor of per-sample sums - one asynchronous launch, no host synchronisation."""
     pred, gt = data_dict["result"], data_dict["target"]
     if not pred.is_cuda:
         raise RuntimeError("monorec_amd.metrics needs result/target on a HIP device; there is no CPU path")
-    key = (pred.data_ptr(), pred._version, gt.data_ptr(), gt._version, None if roi is None else tuple(roi), max_distance)
-    cached = data_dict.get(_CACHE_KEY)
-    if cached is not None and cached[0] == key:
-        return cached[1]
     lib = _lib.load()
     pred = pred.contiguous().float()
     gt = gt.contiguous().float()
@@ -36,9 +32,27 @@ def sparse_metric_sums(data_dict, roi=None, max_distance=None):
     _lib.check(lib.mr_sparse_metric_sums_f32(pred.data_ptr(), gt.data_ptr(), b, h, w, roi_arr,
                                              float(max_distance) if max_distance else 0.0, sums.data_ptr(), stream),
                "mr_sparse_metric_sums_f32")
-    out = sums.cpu()
+    return sums
+
+
+def sparse_metric_sums(data_dict, roi=None, max_distance=None):
+    """(B, 8) float64 CPU tensor of per-sample sums; cached on `data_dict` for the (result, target, roi, dist) at hand."""
+    pred, gt = data_dict["result"], data_dict["target"]
+    if not pred.is_cuda:
+        raise RuntimeError("monorec_amd.metrics needs result/target on a HIP device; there is no CPU path")
+    key = (pred.data_ptr(), pred._version, gt.data_ptr(), gt._version, None if roi is None else tuple(roi), max_distance)
+    cached = data_dict.get(_CACHE_KEY)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    out = sparse_metric_sums_device(data_dict, roi, max_distance).cpu()
     data_dict[_CACHE_KEY] = (key, out)
     return out
+
+
+def metrics_from_sums(s):
+    """The seven metric values of one batch, in SPARSE_METRICS order, from its (B, 8) sums (CPU float64)."""
+    return [_batch_ratio(s, 1), _batch_ratio(s, 2), _per_sample_rms(s, 3), _per_sample_rms(s, 4),
+            _batch_ratio(s, 5), _batch_ratio(s, 6), _batch_ratio(s, 7)]
 
 
 def _check(pred_all_valid, use_cvmask):

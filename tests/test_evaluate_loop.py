@@ -1,0 +1,79 @@
+"""Evaluater loop mirror (evaluater/evaluater.py:38-50,78-118): host bookkeeping on CPU, the device loop on the GPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from monorec_amd import evaluate, synth
+from oracle import monorec_oracle as orc
+
+
+def _reference_loop(per_batch, sizes):
+    """evaluater.py:72-118 written out independently of monorec_amd.evaluate (numpy, like the reference)."""
+    n = len(per_batch[0])
+    total_metrics, total_valid, running, num = np.zeros(n), np.zeros(n), np.zeros(n), 0
+    for m, bs in zip(per_batch, sizes):
+        acc = np.zeros(n)
+        for i, v in enumerate(m):
+            acc[i] += v
+        if np.any(np.isnan(acc)):
+            acc, valid = np.zeros(n), np.zeros(n)
+        else:
+            valid = np.ones(n)
+        total_metrics += acc
+        total_valid += valid
+        if num == 0:
+            running += acc
+        else:
+            running = running * (num / (num + bs)) + acc * (bs / (num + bs))
+        num += bs
+    return (total_metrics / total_valid).tolist(), running.tolist(), total_valid[0]
+
+
+def test_evaluation_log_rules():
+    per_batch = [[0.5, 2.0], [float("nan"), 1.0], [0.25, 4.0], [1.0, 1.0]]
+    sizes = [2, 2, 1, 3]
+    log = evaluate.evaluation_log(per_batch, sizes)
+    m, r, v = _reference_loop(per_batch, sizes)
+    assert log["metrics"] == m and log["metrics_correct"] == r and log["valid_batches"] == v == 3
+    assert log["metrics"] == [(0.5 + 0.25 + 1.0) / 3, (2.0 + 4.0 + 1.0) / 3]      # the NaN batch is dropped entirely
+
+
+@pytest.mark.gpu
+def test_evaluater_matches_oracle_chain(hip_lib):
+    from monorec_amd import MonoRecModel
+    dev = "cuda:0"
+    model = MonoRecModel(cv_depth_steps=8)
+    sd = synth.seeded_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    batches = []
+    for i in range(5):
+        data = synth.make_batch(2, 64, 96, 2, seed=40 + i)
+        _, target = synth.make_depth_pair(2, 64, 96, seed=60 + i)
+        if i == 2:
+            target[1] = 0                      # one sample without ground truth -> NaN rmse -> whole batch invalid
+        batches.append((data, target))
+    log = evaluate.Evaluater(model, roi=None, max_distance=80).eval(batches)
+    per_batch = []
+    for data, target in batches:
+        with torch.no_grad():
+            res = model(synth.clone_batch(data, dev))["result"].cpu().clone()
+        vals = orc.sparse_metrics(res, target, None, 80)
+        per_batch.append([float(vals[k]) for k in evaluate._metrics.SPARSE_METRICS])
+    m, r, v = _reference_loop(per_batch, [2] * 5)
+    assert log["valid_batches"] == v == 4
+    for got, want in zip(log["metrics"] + log["metrics_correct"], m + r):
+        assert math.isclose(got, want, rel_tol=2e-5, abs_tol=1e-7), (got, want)
+    # a metric subset keeps the order given, roi is honoured
+    sub = evaluate.Evaluater(model, roi=[8, 56, 8, 88], max_distance=80,
+                             metric_names=("a1_sparse_metric", "abs_rel_sparse_metric")).eval(batches[:2])
+    want = []
+    for data, target in batches[:2]:
+        with torch.no_grad():
+            res = model(synth.clone_batch(data, dev))["result"].cpu().clone()
+        vals = orc.sparse_metrics(res, target, [8, 56, 8, 88], 80)
+        want.append([float(vals["a1_sparse_metric"]), float(vals["abs_rel_sparse_metric"])])
+    m2, _, _ = _reference_loop(want, [2, 2])
+    assert all(math.isclose(a, b, rel_tol=2e-5) for a, b in zip(sub["metrics"], m2))

@@ -216,7 +216,7 @@ class MonoRecModel(nn.Module):
         self.depth_cp_loc = depth_cp_loc
         self.freeze_module = freeze_module
         self.freeze_resnet = freeze_resnet
-        unsupported = dict(pretrain_mode=self.pretrain_mode != 0, use_stereo=bool(use_stereo), use_mono=not use_mono,
+        unsupported = dict(pretrain_mode=self.pretrain_mode != 0, use_mono=not (use_mono or use_stereo),
                            use_ssim=use_ssim not in (True, 1), sfcv_mult_mask=not sfcv_mult_mask,
                            simple_mask=bool(simple_mask), mask_use_cv=not mask_use_cv, mask_use_feats=not mask_use_feats,
                            cv_patch_size=cv_patch_size != 3, no_cv=bool(no_cv), augmentation=augmentation not in (None, "none"))
@@ -319,8 +319,15 @@ class MonoRecModel(nn.Module):
             raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
         keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
         kf_intrinsics, kf_pose = data_dict["keyframe_intrinsics"], data_dict["keyframe_pose"]
-        frames = list(data_dict["frames"])
-        poses, intrinsics = list(data_dict["poses"]), list(data_dict["intrinsics"])
+        frames, poses, intrinsics = [], [], []
+        if self.use_mono:                                     # monorec_model.py:160-163
+            frames += list(data_dict["frames"])
+            intrinsics += list(data_dict["intrinsics"])
+            poses += list(data_dict["poses"])
+        if self.use_stereo:                                   # :164-167: the stereo frame is one more source view
+            frames += [data_dict["stereoframe"]]
+            intrinsics += [data_dict["stereoframe_intrinsics"]]
+            poses += [data_dict["stereoframe_pose"]]
         if not keyframe.is_cuda:
             raise RuntimeError("monorec_amd.MonoRecModel needs its inputs on a HIP device (cuda:N on ROCm); "
                                "there is no CPU path")

@@ -184,6 +184,31 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **store)
         report["cases"][name] = {"config": [b, h, w, nf, d, seed, hard, full], "oracle_vs_reference_maxabs": diffs}
         print(name, "ok; oracle == reference on", len(diffs), "tensors")
+    # ---- use_stereo (row f-4): the stereo frame is one more source view (monorec_model.py:164-167) -----------------------
+    b3 = synth.make_batch(1, 64, 96, 3, seed=21)
+    stereo = synth.clone_batch(b3)
+    stereo["stereoframe"], stereo["stereoframe_intrinsics"], stereo["stereoframe_pose"] = \
+        stereo["frames"].pop(), stereo["intrinsics"].pop(), stereo["poses"].pop()
+    ref = Ref(cv_depth_steps=8, use_stereo=True).eval()
+    sd = synth.seeded_state_dict(ref.state_dict(), seed=0)
+    ref.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out_ref = ref(stereo)
+    out_orc = orc.forward(sd, b3, cv_depth_steps=8)
+    store, diffs = {}, {}
+    items_ref, items_orc = flatten_outputs(out_ref), flatten_outputs(out_orc)
+    for k in items_ref:
+        diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+        assert diffs[k] == 0.0, f"oracle deviates from the reference on small_stereo/{k}: {diffs[k]}"
+        for kk, vv in sample_summary(items_ref[k]).items():
+            store[f"{k}.{kk}"] = vv
+    for k in ("result", "cv_mask"):
+        store[f"{k}.full"] = items_ref[k].numpy()
+    store["meta"] = np.array([1, 64, 96, 3, 8, 21, 0, 1], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, "small_stereo.npz"), **store)
+    report["cases"]["small_stereo"] = {"config": "use_stereo=True: 2 mono frames + stereo frame", "oracle_vs_reference_maxabs": diffs}
+    print("small_stereo ok; oracle (3 source views) == reference (use_stereo) on", len(diffs), "tensors")
+
     # ---- the reference's own example sample (example/test_monorec.py: KITTI seq 07, image 169, sources 168/170,
     #      DVSO poses, annotated lidar depth) through the UNMODIFIED reference dataset class -------------------------
     cwd = os.getcwd()

@@ -171,6 +171,38 @@ def test_c5_shape_in_fp32(hip_lib):
     _check_against(out, ref_out, "c5-shape fp32")
 
 
+def test_use_stereo_adds_a_source_view(hip_lib):
+    """use_stereo=True (monorec_model.py:164-167): the stereo frame joins the source views; against the committed output of
+    the reference built with use_stereo=True and against the oracle fed with three source frames."""
+    g = Golden("small_stereo")
+    b3 = g.make_inputs()
+    m = MonoRecModel(cv_depth_steps=g.depths, use_stereo=True, hip_in_flight=1)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    data = _to_dev(b3)
+    data["stereoframe"], data["stereoframe_intrinsics"], data["stereoframe_pose"] = \
+        data["frames"].pop(), data["intrinsics"].pop(), data["poses"].pop()
+    with torch.no_grad():
+        out = m(data)
+    torch.cuda.synchronize()
+    assert len(out["single_frame_cvs"]) == 3
+    g.compare("result", out["result"], atol=RESULT_ATOL)
+    g.compare("cv_mask", out["cv_mask"], atol=1e-4)
+    g.compare("cost_volume", out["cost_volume"], atol=1e-5, max_outlier_frac=1e-4)
+    _check_against(out, orc.forward(sd, b3, cv_depth_steps=g.depths), "use_stereo")
+    # stereo only (use_mono=False): a single source view
+    m1 = MonoRecModel(cv_depth_steps=g.depths, use_stereo=True, use_mono=False, hip_in_flight=1)
+    m1.load_state_dict(sd)
+    m1 = m1.to(DEV).eval()
+    with torch.no_grad():
+        out1 = m1(dict(data))
+    one = {k: v for k, v in b3.items()}
+    one["frames"], one["intrinsics"], one["poses"] = b3["frames"][2:], b3["intrinsics"][2:], b3["poses"][2:]
+    assert len(out1["single_frame_cvs"]) == 1
+    _check_against(out1, orc.forward(sd, one, cv_depth_steps=g.depths), "stereo only")
+
+
 def test_bf16_mode_end_to_end(hip_lib):
     """hip_bf16=True (BASELINE configs[4] numerics): convolutions on the bf16 MFMA, cost volume and storage fp32.  Not within the
     1e-4 bar by construction; the test pins how far off it is and that the fp32 default is untouched."""

@@ -98,6 +98,26 @@ def committed_pmc_traffic():
         return None, None
 
 
+def committed_kernel_average():
+    """Average conv_mfma_kernel duration (us) in the committed `rocprofv3 --kernel-trace --stats` table of this command
+    (profiles/*_kernel_stats.csv).  The live figure is taken with HIP events around every launch and therefore also
+    contains the dispatch gap of a dependent launch (~3 us) and, for split-K layers, the finishing kernel."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")))
+    if not files:
+        return None, None
+    try:
+        tot, n = 0.0, 0
+        for r in list(csv.reader(open(files[-1])))[1:]:
+            if "conv_mfma_kernel" in r[0]:
+                tot += float(r[2])
+                n += int(r[1])
+        return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(sd, batch_cpu, depths, budget_s=25.0):
     """The CPU oracle (restatement of the reference's torch-CPU path, oracle/monorec_oracle.py) on this
     box's host cores: 1 warm-up + best of up to 5 forwards of the same keyframe batch."""
@@ -212,8 +232,10 @@ def main():
         conv_flops = 2.0 * sum(r["macs"] for r in conv_rows)
         achieved = conv_flops / conv_s / 1e12
         cv_row = next(r for r in rows if r["name"] == "cost_volume")
-        traffic, traffic_src = committed_pmc_traffic() if (args.batch, args.height, args.width, args.frames, args.depths) == (1, 256, 512, 2, 32) else (None, None)
         shape = (args.batch, args.height, args.width, args.frames, args.depths)
+        is_c2_fp32 = shape == (1, 256, 512, 2, 32) and not args.bf16        # the committed profiles are of this command
+        traffic, traffic_src = committed_pmc_traffic() if is_c2_fp32 else (None, None)
+        prof_avg, prof_src = committed_kernel_average() if is_c2_fp32 else (None, None)
         cfg_name = {(1, 256, 512, 2, 32): "c2 (BASELINE configs[1])", (8, 256, 512, 4, 64): "c3 (BASELINE configs[2])"}.get(shape, "custom")
         cv_bytes = 4.0 * args.batch * args.height * args.width * (3 + args.depths) * (1 + args.frames)
         result = {
@@ -240,6 +262,8 @@ def main():
                          "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / (BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS), "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
                          "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
+                         "avg_launch_us_note": "HIP events around each layer: kernel + dispatch gap (+ split-K finishing kernel)",
+                         "rocprof_avg_kernel_us": prof_avg, "rocprof_source": prof_src,
                          "algorithmic_gflop_per_step": conv_flops / 1e9, "conv_ms_per_step": conv_s * 1e3},
             "cost_volume_kernel": {"bound": "hbm", "us": cv_row["seconds"] * 1e6, "algorithmic_MB": cv_bytes / 1e6,
                                    "achieved_GBps": cv_bytes / cv_row["seconds"] / 1e9, "peak_GBps": 8000.0},

@@ -169,6 +169,15 @@ int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_
                        float alpha, const float* channel_weights /* 3 host floats */,
                        float* cost_volume, float* const* sfcv, void* stream);
 
+/* The same with the photometric term selected like CostVolumeModule's use_ssim (monorec_model.py:227-243):
+ * 1 = SSIM distance (what mr_cost_volume_f32 does), 0 = absolute difference, 2 = 0.85 SSIM + 0.15 absolute difference,
+ * 3 = absolute difference averaged over 3x3 (zero padded). */
+int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                            const float* kinv, const float* proj, const float* depths,
+                            int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                            float alpha, const float* channel_weights, int32_t use_ssim,
+                            float* cost_volume, float* const* sfcv, void* stream);
+
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the torchvision ResNet stem (monorec_model.py:124) */
 int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in_h, int32_t in_w, void* stream);
 

@@ -120,7 +120,9 @@ __device__ __forceinline__ bool mask_hit(const Sample& sp, int H, int W) {
     return m != 0.f;
 }
 
-template <int TX, int TY>
+// MODE = the photometric term of monorec_model.py:227-243 (use_ssim): 1 SSIM distance (default), 0 absolute difference,
+// 2 the 0.85 / 0.15 mix of both, 3 absolute difference averaged over 3x3 (zero padded, avg_pool2d).
+template <int TX, int TY, int MODE>
 __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
     constexpr int NT = TX * TY;
     constexpr int HX = TX + 4, HY = TY + 4;   // warped / keyframe tile with 2 px halo
@@ -260,24 +262,48 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                     if (s_in[r]) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
+                            float sv = 0.f;
+                            if (MODE == 1 || MODE == 2) {
+                                float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
 #pragma unroll
-                            for (int dy = 0; dy < 3; ++dy)
+                                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                                for (int dx = 0; dx < 3; ++dx) {
-                                    const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
-                                    const float x = wru[li], k = kf[li];
-                                    const float xx = x * x, xk = x * k;
-                                    if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
-                                    else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
-                                }
-                            const float mu_x = div9(sx1), mu_y = kmu[r][c];
-                            const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
-                            const float sig_x = div9(sx2) - mu_x_sq;
-                            const float sig_xy = div9(sxy) - mu_xy;
-                            const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
-                            const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
-                            const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
+                                    for (int dx = 0; dx < 3; ++dx) {
+                                        const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
+                                        const float x = wru[li], k = kf[li];
+                                        const float xx = x * x, xk = x * k;
+                                        if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
+                                        else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
+                                    }
+                                const float mu_x = div9(sx1), mu_y = kmu[r][c];
+                                const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
+                                const float sig_x = div9(sx2) - mu_x_sq;
+                                const float sig_xy = div9(sxy) - mu_xy;
+                                const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
+                                const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
+                                sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);               // layers.py:137
+                            }
+                            if (MODE == 0 || MODE == 2) {                                             // |warped - keyframe|, :228,239
+                                const int li = (c * HY + sly[r] + 1) * HX + slx[r] + 1;
+                                const float ad = fabsf(wru[li] - kf[li]);
+                                sv = MODE == 0 ? ad : 0.85f * sv + 0.15f * ad;
+                            }
+                            if (MODE == 3) {                                                          // avg_pool2d(|.|, 3, 1, padding=1), :241
+                                const int qy = ty0 - 1 + sly[r], qx = tx0 - 1 + slx[r];
+                                float acc = 0.f;
+                                bool first = true;
+#pragma unroll
+                                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                                    for (int dx = -1; dx <= 1; ++dx) {
+                                        if (qy + dy < 0 || qy + dy >= H || qx + dx < 0 || qx + dx >= W) continue;   // zero padding
+                                        const int li = (c * HY + sly[r] + 1 + dy) * HX + slx[r] + 1 + dx;
+                                        const float ad = fabsf(wru[li] - kf[li]);
+                                        acc = first ? ad : acc + ad;
+                                        first = false;
+                                    }
+                                sv = div9(acc);
+                            }
                             e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
                         }
                     }
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
 }
 
 template <int TX, int TY>
-int launch_cv(const CvArgs& a, hipStream_t stream) {
+int launch_cv(const CvArgs& a, int mode, hipStream_t stream) {
     CvArgs k = a;
     k.tiles_x = (a.W + TX - 1) / TX;
     const int tiles = k.tiles_x * ((a.H + TY - 1) / TY);
@@ -373,7 +399,13 @@ int launch_cv(const CvArgs& a, hipStream_t stream) {
     while ((long long)tiles * a.F * a.B * nchunk < 1024 && (a.D / (nchunk * 2)) >= 4 && (a.D % (nchunk * 4)) == 0) nchunk *= 2;
     k.nchunk = nchunk;
     k.dchunk = a.D / nchunk;
-    hipLaunchKernelGGL((cv_sad_kernel<TX, TY>), dim3(tiles, a.F * nchunk, a.B), dim3(TX * TY), 0, stream, k);
+    const dim3 grid(tiles, a.F * nchunk, a.B), block(TX * TY);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 0>), grid, block, 0, stream, k); break;
+        case 2: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 2>), grid, block, 0, stream, k); break;
+        case 3: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 3>), grid, block, 0, stream, k); break;
+        default: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 1>), grid, block, 0, stream, k); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long long total = (long long)a.B * a.H * a.W;
@@ -384,11 +416,12 @@ int launch_cv(const CvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
-                                  const float* kinv, const float* proj, const float* depths,
-                                  int32_t batch, int32_t num_depths, int32_t height, int32_t width,
-                                  float alpha, const float* channel_weights,
-                                  float* cost_volume, float* const* sfcv, void* stream) {
+extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                       const float* kinv, const float* proj, const float* depths,
+                                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                       float alpha, const float* channel_weights, int32_t use_ssim,
+                                       float* cost_volume, float* const* sfcv, void* stream) {
+    if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
     if (!keyframe || !frames || !kinv || !proj || !depths || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
     if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
@@ -406,5 +439,14 @@ extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* fra
     a.alpha = alpha;
     for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / 9.0f;
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
-    return launch_cv<32, 16>(a, (hipStream_t)stream);
+    return launch_cv<32, 16>(a, use_ssim, (hipStream_t)stream);
+}
+
+extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                  const float* kinv, const float* proj, const float* depths,
+                                  int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                  float alpha, const float* channel_weights,
+                                  float* cost_volume, float* const* sfcv, void* stream) {
+    return mr_cost_volume_mode_f32(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                                   channel_weights, 1, cost_volume, sfcv, stream);
 }

@@ -194,7 +194,7 @@ class Plan:
     """Buffers + launch list for one input shape. `state` is a CPU state dict with the reference keys."""
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
-                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False):
+                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -206,6 +206,7 @@ class Plan:
         self.alpha = float(alpha)
         self.cw = (ctypes.c_float * 3)(*[float(torch.tensor(c, dtype=torch.float32)) for c in channel_weights])
         self.schedule_override = schedule_override or {}
+        self.cv_mode = {False: 0, True: 1}.get(use_ssim, use_ssim) if not isinstance(use_ssim, bool) else int(use_ssim)
         self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
         self.buf = {}
@@ -425,9 +426,9 @@ class Plan:
         kinv, proj, depths = self.buf["kinv"], self.buf["proj"], self.buf["depths"]
 
         def run_cv(stream):
-            _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
-                                              depths.data_ptr(), B, D, H, W, self.alpha, self.cw,
-                                              cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_f32")
+            _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                                   depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode,
+                                                   cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
         self.add(st, "cost_volume", run_cv)
 
         # ---------------- MaskModule (monorec_model.py:345-385), frames batched as F*B ----------------

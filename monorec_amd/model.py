@@ -217,7 +217,7 @@ class MonoRecModel(nn.Module):
         self.freeze_module = freeze_module
         self.freeze_resnet = freeze_resnet
         unsupported = dict(pretrain_mode=self.pretrain_mode != 0, use_mono=not (use_mono or use_stereo),
-                           use_ssim=use_ssim not in (True, 1), sfcv_mult_mask=not sfcv_mult_mask,
+                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3), sfcv_mult_mask=not sfcv_mult_mask,
                            simple_mask=bool(simple_mask), mask_use_cv=not mask_use_cv, mask_use_feats=not mask_use_feats,
                            cv_patch_size=cv_patch_size != 3, no_cv=bool(no_cv), augmentation=augmentation not in (None, "none"))
         bad = [k for k, v in unsupported.items() if v]
@@ -292,7 +292,8 @@ class MonoRecModel(nn.Module):
             if self._packed_state is None or self._packed_state[0] != str(device):
                 self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
             plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
-                        alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16)
+                        alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
+                        use_ssim=self.use_ssim)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()

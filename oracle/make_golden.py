@@ -184,6 +184,31 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **store)
         report["cases"][name] = {"config": [b, h, w, nf, d, seed, hard, full], "oracle_vs_reference_maxabs": diffs}
         print(name, "ok; oracle == reference on", len(diffs), "tensors")
+    # ---- use_ssim variants of the photometric term (row f-4, monorec_model.py:227-243): cost volume only ------------------
+    for mode in (False, 2, 3):
+        name = f"cv_ssim{int(mode)}"
+        batch = synth.make_batch(2, 48, 80, 2, seed=31)
+        ref = Ref(cv_depth_steps=8, use_ssim=mode).eval()
+        dd = synth.clone_batch(batch)
+        dd["inv_depth_min"], dd["inv_depth_max"] = torch.tensor([0.33]), torch.tensor([0.0025])
+        dd["cv_depth_steps"] = torch.tensor([8], dtype=torch.int32)
+        with torch.no_grad():
+            dd = ref.cv_module(dd)
+        cv, sf = orc.cost_volume(batch, steps=8, use_ssim=mode)
+        items_ref = {"cost_volume": dd["cost_volume"], **{f"sfcv{i}": t for i, t in enumerate(dd["single_frame_cvs"])}}
+        items_orc = {"cost_volume": cv, **{f"sfcv{i}": t for i, t in enumerate(sf)}}
+        store, diffs = {}, {}
+        for k in items_ref:
+            diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+            assert diffs[k] == 0.0, f"oracle deviates from the reference on {name}/{k}: {diffs[k]}"
+            for kk, vv in sample_summary(items_ref[k]).items():
+                store[f"{k}.{kk}"] = vv
+        store["cost_volume.full"] = items_ref["cost_volume"].numpy()
+        store["meta"] = np.array([2, 48, 80, 2, 8, 31, 0, 0], dtype=np.int64)
+        np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **store)
+        report["cases"][name] = {"config": f"use_ssim={mode}", "oracle_vs_reference_maxabs": diffs}
+        print(name, "ok; oracle == reference on", len(diffs), "tensors")
+
     # ---- use_stereo (row f-4): the stereo frame is one more source view (monorec_model.py:164-167) -----------------------
     b3 = synth.make_batch(1, 64, 96, 3, seed=21)
     stereo = synth.clone_batch(b3)

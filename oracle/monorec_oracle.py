@@ -92,8 +92,9 @@ def ssim_distance(x, y):
 
 
 def cost_volume(batch, inv_depth_min=0.33, inv_depth_max=0.0025, steps=32, patch_size=3,
-                channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, stages=None):
-    """CostVolumeModule.forward (monorec_model.py:150-280), use_mono, use_ssim=True, sfcv_mult_mask=True.
+                channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, stages=None, use_ssim=True):
+    """CostVolumeModule.forward (monorec_model.py:150-280), use_mono, sfcv_mult_mask=True; use_ssim selects the photometric
+    term (:227-243): True SSIM distance, False absolute difference, 2 the 0.85/0.15 mix, 3 3x3-averaged absolute difference.
 
     Returns (cost_volume (B,D,H,W), [single_frame_cv (B,D,H,W)] * F).
     If `stages` is a dict it receives per-sample intermediates (grid, warped, sad, valid, weight)."""
@@ -128,8 +129,17 @@ def cost_volume(batch, inv_depth_min=0.33, inv_depth_max=0.0025, steps=32, patch
         warped = torch.stack(warped, 1)                       # (D,F,C,H,W)           :223
         valid = torch.stack(valid)                            # (F,1,H,W)             :225
         nb = steps * nf
-        diff = ssim_distance(warped.view(nb, c, h, w) + .5,
-                             keyframe[n].unsqueeze(0).expand(nb, -1, -1, -1) + .5)   # :231-232
+        if not use_ssim:                                                             # :227-228
+            diff = torch.abs(warped - keyframe[n])
+        elif use_ssim is True or use_ssim == 1:
+            diff = ssim_distance(warped.view(nb, c, h, w) + .5,
+                                 keyframe[n].unsqueeze(0).expand(nb, -1, -1, -1) + .5)   # :231-232
+        elif use_ssim == 2:                                                          # :234-239
+            diff = ssim_distance(warped.view(nb, c, h, w) + .5,
+                                 keyframe[n].unsqueeze(0).expand(nb, -1, -1, -1) + .5).view(steps, nf, c, h, w)
+            diff = 0.85 * diff + 0.15 * torch.abs(warped - keyframe[n])
+        else:                                                                        # :240-243
+            diff = F.avg_pool2d(torch.abs(warped - keyframe[n]).view(nb, c, h, w), kernel_size=3, stride=1, padding=1)
         diff = diff.view(steps, nf, c, h, w).permute(1, 2, 0, 3, 4)                  # :233,246
         sad = F.conv3d(diff, sad_kernel, padding=(0, patch_size // 2, patch_size // 2)).squeeze(1)   # :247
         sfcv = (1 - sad * 2) * valid                                                 # :251
@@ -295,10 +305,11 @@ def depth_module(sd, cost_volume_masked, keyframe, feats, prefix="depth_module")
 # ----------------------------------------------------------------------------------------
 # MonoRecModel.forward (monorec_model.py:672-729)
 # ----------------------------------------------------------------------------------------
-def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None):
+def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True):
     """Returns the reference's output dict entries for eval / pretrain_mode=0."""
     with torch.no_grad():
-        cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages)
+        cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages,
+                                use_ssim=use_ssim)
         feats = resnet_features(sd, batch["keyframe"] + .5)                         # :691
         cv_mask = mask_module(sd, sfcvs, feats)                                     # :694
         cv_masked = (1 - cv_mask) * cv                                              # :713

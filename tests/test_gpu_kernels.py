@@ -233,7 +233,7 @@ def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
         assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
 
 
-def _hip_cost_volume(batch, d):
+def _hip_cost_volume(batch, d, use_ssim=1):
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)
     b, _, h, w = kf.shape
@@ -247,8 +247,13 @@ def _hip_cost_volume(batch, d):
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
-    _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
-                                      b, d, h, w, 10.0, cw, cv.data_ptr(), sp, _stream()), "mr_cost_volume_f32")
+    if use_ssim == 1:
+        _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
+                                          b, d, h, w, 10.0, cw, cv.data_ptr(), sp, _stream()), "mr_cost_volume_f32")
+    else:
+        _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
+                                               b, d, h, w, 10.0, cw, int(use_ssim), cv.data_ptr(), sp, _stream()),
+                   "mr_cost_volume_mode_f32")
     torch.cuda.synchronize()
     return cv.cpu(), [s.cpu() for s in sf]
 
@@ -286,6 +291,27 @@ def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
         assert bad <= 1e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
     bad = ((cv - ocv).abs() > 2e-4).float().mean().item()
     assert bad <= 1e-4, (bad, (cv - ocv).abs().max().item())
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_cost_volume_use_ssim_variants(hip_lib, mode):
+    """use_ssim = False / 2 / 3 (monorec_model.py:227-243) against the reference's committed output and the oracle."""
+    g = Golden(f"cv_ssim{mode}")
+    batch = g.make_inputs()
+    cv, sf = _hip_cost_volume(batch, g.depths, use_ssim=mode)
+    # single-frame volumes: 1 - 2 sad, well conditioned.  Fused volume: sum(w sad) / sum(w) with w -> 0 wherever the cost
+    # is flat over depth, which the absolute-difference terms are on smooth texture - rounding noise of the 27-tap sum is
+    # amplified there (in the reference too), hence the looser bound with a small outlier budget.
+    for f in range(g.frames):
+        g.compare(f"sfcv{f}", sf[f], atol=2e-6, max_outlier_frac=1e-4)
+    g.compare("cost_volume", cv, atol=2e-5, max_outlier_frac=5e-3)
+    ocv, osf = orc.cost_volume(batch, steps=g.depths, use_ssim=(False if mode == 0 else mode))
+    assert ((cv - ocv).abs() > 1e-4).float().mean().item() <= 2e-4
+    for f in range(g.frames):
+        assert ((sf[f] - osf[f]).abs() > 1e-4).float().mean().item() <= 2e-4
+    # the variants really differ from the default term
+    dcv, _ = _hip_cost_volume(batch, g.depths)
+    assert (dcv - cv).abs().max().item() > 1e-2
 
 
 def test_cost_volume_properties_at_full_size(hip_lib):

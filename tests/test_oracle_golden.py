@@ -92,3 +92,12 @@ def test_oracle_sparse_metrics_match_reference_fixture():
         got = orc.sparse_metrics(pred, gt, roi, maxd)
         for k, want in case["metrics"].items():
             assert abs(float(got[k]) - want) <= 2e-6 * max(1.0, abs(want)), (name, k, float(got[k]), want)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_oracle_use_ssim_variants_match_reference_fixture(mode):
+    g = Golden(f"cv_ssim{mode}")
+    cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths, use_ssim=(False if mode == 0 else mode))
+    g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(sf):
+        g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)

@@ -486,7 +486,12 @@ class Plan:
 
         # ---------------- DepthModule (monorec_model.py:526-557) ----------------
         dm = "depth_module"
-        enc_spec = ((48, 7, 1), (64, 7, 2), (128, 5, 2), (192, 5, 2), (256, 3, 2))   # (channels, kernel, stride)
+        # (channels, kernel, stride); the widths come from the weights (depth_large_model widens stages 3, 4, :482-483)
+        enc_spec = tuple((int(sd[f"{dm}.enc.{i}.0.conv_y.weight"].shape[0]), k, s)
+                         for i, (k, s) in enumerate(((7, 1), (7, 2), (5, 2), (5, 2), (3, 2))))
+        dch = [int(sd[f"{dm}.dec.0.conv2d_t.weight"].shape[1]), int(sd[f"{dm}.dec.1.0.conv2d_t.weight"].shape[1]),
+               int(sd[f"{dm}.dec.2.0.conv2d_t.weight"].shape[1]), int(sd[f"{dm}.dec.3.conv2d_t.weight"].shape[1]),
+               int(sd[f"{dm}.dec.4.0.conv_y.weight"].shape[0]), int(sd[f"{dm}.dec.4.2.weight"].shape[0])]
         x_srcs = [cv, kf]                                                            # :531
         dfe = []
         hh, ww = H, W
@@ -510,27 +515,27 @@ class Plan:
                            p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)                # :556 + :717
             preds[scale_slot] = p
 
-        r0 = self.alloc("depth.dec0", B, 256, H // 8, W // 8)
+        r0 = self.alloc("depth.dec0", B, dch[0], H // 8, W // 8)
         self.refine(st, "depth.dec0", [dfe[4]], f"{dm}.dec.0", r0)
         head(0, r0, 3)
-        r1 = self.alloc("depth.dec1.t", B, 128, H // 4, W // 4)
+        r1 = self.alloc("depth.dec1.t", B, dch[1], H // 4, W // 4)
         self.refine(st, "depth.dec1.0", [dfe[3], feats[2], r0], f"{dm}.dec.1.0", r1)  # :545
-        m1 = self.alloc("depth.dec1.mid", B, 128, H // 4, W // 4)
-        x1 = self.alloc("depth.dec1", B, 128, H // 4, W // 4)
+        m1 = self.alloc("depth.dec1.mid", B, dch[1], H // 4, W // 4)
+        x1 = self.alloc("depth.dec1", B, dch[1], H // 4, W // 4)
         self.conv_relu2(st, "depth.dec1.1", [r1], f"{dm}.dec.1.1", m1, x1)
         head(1, x1, 2)
-        r2 = self.alloc("depth.dec2.t", B, 64, H // 2, W // 2)
+        r2 = self.alloc("depth.dec2.t", B, dch[2], H // 2, W // 2)
         self.refine(st, "depth.dec2.0", [dfe[2], feats[1], x1], f"{dm}.dec.2.0", r2)
-        m2 = self.alloc("depth.dec2.mid", B, 64, H // 2, W // 2)
-        x2 = self.alloc("depth.dec2", B, 64, H // 2, W // 2)
+        m2 = self.alloc("depth.dec2.mid", B, dch[2], H // 2, W // 2)
+        x2 = self.alloc("depth.dec2", B, dch[2], H // 2, W // 2)
         self.conv_relu2(st, "depth.dec2.1", [r2], f"{dm}.dec.2.1", m2, x2)
         head(2, x2, 1)
-        x3 = self.alloc("depth.dec3", B, 48, H, W)
+        x3 = self.alloc("depth.dec3", B, dch[3], H, W)
         self.refine(st, "depth.dec3", [dfe[1], feats[0], x2], f"{dm}.dec.3", x3)
-        m4 = self.alloc("depth.dec4.mid", B, 32, H, W)
-        x4a = self.alloc("depth.dec4.a", B, 32, H, W)
+        m4 = self.alloc("depth.dec4.mid", B, dch[4], H, W)
+        x4a = self.alloc("depth.dec4.a", B, dch[4], H, W)
         self.conv_relu2(st, "depth.dec4.0", [dfe[0], x3], f"{dm}.dec.4.0", m4, x4a)   # :543
-        x4 = self.alloc("depth.dec4", B, 24, H, W)
+        x4 = self.alloc("depth.dec4", B, dch[5], H, W)
         self.same_conv(st, "depth.dec4.2", [x4a], f"{dm}.dec.4.2.weight", f"{dm}.dec.4.2.bias", x4)
         head(3, x4, 0)
         self.feats = feats

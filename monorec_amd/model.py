@@ -125,13 +125,11 @@ class DepthModule(_ParamsOnly):
 
     def __init__(self, depth_steps=32, feature_channels=(64, 64, 128, 256, 512), large_model=False):
         super().__init__()
-        if large_model:
-            raise NotImplementedError("depth_large_model=True is outside the MI355X hot-path scope (SURVEY.md f-4)")
         self.depth_steps = depth_steps
         self.feat_chns = feature_channels
         fc = tuple(int(c) for c in feature_channels)
-        ec = (48, 64, 128, 192, 256)
-        dc = (256, 128, 64, 48, 32, 24)
+        ec = (48, 64, 128, 256, 512) if large_model else (48, 64, 128, 192, 256)          # monorec_model.py:482
+        dc = (512, 256, 128, 64, 32, 24) if large_model else (256, 128, 64, 48, 32, 24)  # :483
         ks = (7, 7, 5, 5, 3)
 
         def cr2(cin, cout, k, s=1):

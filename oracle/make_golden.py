@@ -209,6 +209,27 @@ def main():
         report["cases"][name] = {"config": f"use_ssim={mode}", "oracle_vs_reference_maxabs": diffs}
         print(name, "ok; oracle == reference on", len(diffs), "tensors")
 
+    # ---- depth_large_model (row f-4, monorec_model.py:482-483): wider DepthModule stages --------------------------------
+    batch = synth.make_batch(1, 64, 96, 2, seed=23)
+    ref = Ref(cv_depth_steps=8, depth_large_model=True).eval()
+    sd = synth.seeded_state_dict(ref.state_dict(), seed=0)
+    ref.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out_ref = ref(synth.clone_batch(batch))
+    out_orc = orc.forward(sd, batch, cv_depth_steps=8)
+    store, diffs = {}, {}
+    items_ref, items_orc = flatten_outputs(out_ref), flatten_outputs(out_orc)
+    for k in items_ref:
+        diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+        assert diffs[k] == 0.0, f"oracle deviates from the reference on small_large_depth/{k}: {diffs[k]}"
+        for kk, vv in sample_summary(items_ref[k]).items():
+            store[f"{k}.{kk}"] = vv
+    store["result.full"] = items_ref["result"].numpy()
+    store["meta"] = np.array([1, 64, 96, 2, 8, 23, 0, 1], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, "small_large_depth.npz"), **store)
+    report["cases"]["small_large_depth"] = {"config": "depth_large_model=True", "oracle_vs_reference_maxabs": diffs}
+    print("small_large_depth ok; oracle == reference (depth_large_model) on", len(diffs), "tensors")
+
     # ---- use_stereo (row f-4): the stereo frame is one more source view (monorec_model.py:164-167) -----------------------
     b3 = synth.make_batch(1, 64, 96, 3, seed=21)
     stereo = synth.clone_batch(b3)

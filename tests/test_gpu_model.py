@@ -203,6 +203,23 @@ def test_use_stereo_adds_a_source_view(hip_lib):
     _check_against(out1, orc.forward(sd, one, cv_depth_steps=g.depths), "stereo only")
 
 
+def test_depth_large_model(hip_lib):
+    """depth_large_model=True (monorec_model.py:482-483): the plan takes the DepthModule widths from the weights."""
+    g = Golden("small_large_depth")
+    batch = g.make_inputs()
+    m = MonoRecModel(cv_depth_steps=g.depths, depth_large_model=True, hip_in_flight=1)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(_to_dev(batch))
+    torch.cuda.synchronize()
+    g.compare("result", out["result"], atol=RESULT_ATOL)
+    for i in range(4):
+        g.compare(f"pred{i}", out["predicted_inverse_depths"][i], atol=RESULT_ATOL)
+    _check_against(out, orc.forward(sd, batch, cv_depth_steps=g.depths), "depth_large_model")
+
+
 def test_bf16_mode_end_to_end(hip_lib):
     """hip_bf16=True (BASELINE configs[4] numerics): convolutions on the bf16 MFMA, cost volume and storage fp32.  Not within the
     1e-4 bar by construction; the test pins how far off it is and that the fp32 default is untouched."""

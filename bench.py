@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches; kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch timing table (JSON) here")
+    ap.add_argument("--no-primer", action="store_true",
+                    help="skip the throw-away primer process (see prime_device)")
+    ap.add_argument("--primer", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -136,6 +139,29 @@ def cpu_baseline(sd, batch_cpu, depths, budget_s=25.0):
             "sample": f"{n} timed forwards (best) + 1 warm-up of the same {b}-keyframe batch, torch CPU fp32"}, ref
 
 
+def prime_device(args, dev_index):
+    """The first process that runs this workload on a freshly booted GPU box pipelines ~6 % slower than every later
+    one - measured: 375 vs 400 keyframes/s with identical per-kernel times, whatever the spin-up length (3-40 s), the
+    allocator setting, eager or hipGraph launches, 1 or 2 keyframes in flight; a 20-step run of the same command in a
+    separate process beforehand removes it.  So the benchmark first runs itself once, briefly, in a throw-away child
+    (untimed, output discarded) - the steady state of a serving process is what `value` should report."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env["MR_BENCH_DEVICE"] = str(dev_index)
+    cmd = [sys.executable, os.path.abspath(__file__), "--primer", "--no-cpu-baseline", "--steps", "20", "--warmup", "2",
+           "--spinup-seconds", "0.5", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
+           "--frames", str(args.frames), "--depths", str(args.depths), "--in-flight", str(args.in_flight)]
+    if args.bf16:
+        cmd.append("--bf16")
+    if args.graph:
+        cmd.append("--graph")
+    try:
+        return subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300).returncode == 0
+    except Exception:
+        return False
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,6 +174,11 @@ def main():
     # flow can be exercised on a 1-GPU box; normally one rank per GPU over RCCL ("nccl" backend on ROCm).
     one_device = os.environ.get("MR_BENCH_ONE_DEVICE") == "1"
     dev_index = 0 if one_device else local_rank
+    if args.primer:
+        dev_index = int(os.environ.get("MR_BENCH_DEVICE", "0"))
+    primed = False
+    if not args.primer and not args.no_primer and not (one_device and rank > 0):
+        primed = prime_device(args, dev_index)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -223,6 +254,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_keyframes = float(sum(g[0].item() for g in gathered))
+    if args.primer:
+        return
 
     if rank == 0:
         plan_key = next(iter(model._plans))
@@ -246,6 +279,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "untimed_spinup_steps": n_spin,
+            "primer_process": primed,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="time each candidate on this many concurrent streams")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--lds-cap", type=int, default=80 * 1024)
+    ap.add_argument("--finalists", type=int, default=4, help="candidates re-timed in the second pass")
+    ap.add_argument("--final-reps", type=int, default=20, help="launches per round of the second pass (0 = skip it)")
     ap.add_argument("--bf16", action="store_true", help="tune the MR_COMPUTE_BF16 launches (hip_bf16=True plans)")
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
@@ -142,6 +144,19 @@ def main():
             if best is None or t < best[0]:
                 best = (t, sched)
             del p, fn
+        # second pass: the leaders of the (noisy, few-repetition) sweep again, interleaved and with many repetitions
+        finalists = [r for r in sorted((r for r in rows if r[1]), key=lambda r: r[1])[:args.finalists]]
+        if len(finalists) > 1 and args.final_reps > 0:
+            built = []
+            for sched, _, _ in finalists:
+                p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w), c.get("bf16", False))
+                built.append((sched, p, fn, []))
+            for _ in range(3):
+                for sched, p, fn, ts in built:
+                    ts.append(time_op(fn, reps=args.final_reps, warm=1))
+            scored = sorted((sorted(ts)[1], sched) for sched, p, fn, ts in built)      # median of three rounds
+            best = scored[0]
+            del built
         table[c["sig"]] = list(best[1])
         tf = 2 * c["macs"] / best[0] / 1e12
         report.append(dict(name=c["name"], sig=c["sig"], best=best[1], us=best[0] * 1e6, tflops=tf,

@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): where do HIP / local-CPU oracle / build-container fixture disagree on sfcv?"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from golden_util import Golden
 from test_gpu_kernels import _hip_cost_volume

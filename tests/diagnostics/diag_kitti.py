@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): HIP model vs local-CPU oracle vs committed reference outputs on the KITTI example sample."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from golden_util import Golden
 from monorec_amd import synth

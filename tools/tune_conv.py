@@ -80,10 +80,10 @@ def main():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--merge", action="store_true", help="keep entries already in the table for other shapes")
-    ap.add_argument("--max-cands", type=int, default=90)
+    ap.add_argument("--max-cands", type=int, default=2000)
     ap.add_argument("--streams", type=int, default=1, help="time each candidate on this many concurrent streams")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--lds-cap", type=int, default=80 * 1024)
+    ap.add_argument("--lds-cap", type=int, default=160 * 1024)
     ap.add_argument("--finalists", type=int, default=4, help="candidates re-timed in the second pass")
     ap.add_argument("--final-reps", type=int, default=20, help="launches per round of the second pass (0 = skip it)")
     ap.add_argument("--bf16", action="store_true", help="tune the MR_COMPUTE_BF16 launches (hip_bf16=True plans)")

@@ -100,7 +100,7 @@ typedef struct mr_conv_desc {
     /* schedule */
     int32_t cout_blocks_per_wg;      /* MB: 16-channel output blocks per workgroup, one of 1,2,3,4,6 */
     int32_t pixel_blocks_per_wave;   /* NB: 16-pixel row segments per wave, one of 1,2,4            */
-    int32_t chunk_channels;          /* CK: input channels staged per LDS chunk, one of 8,16,32,64  */
+    int32_t chunk_channels;          /* CK: input channels staged per LDS chunk: 8,16,32,64,128    */
     int32_t split_k;                 /* >= 1; > 1 needs `workspace`                               */
     float* workspace;                /* split_k * phases * batch * ceil16(out_channels) * out_h * out_w floats */
     /* optional output phases (the 4 parities of ConvTranspose2d(k=4,s=2), model/layers.py:389):
@@ -118,7 +118,7 @@ typedef struct mr_conv_desc {
      * MR_COMPUTE_BF16: v_mfma_f32_16x16x16_bf16 - packed_weights / phase_weights from mr_conv_pack_weights_bf16, the
      * activations (still fp32 in memory) are rounded to bf16 (nearest even) as the B fragment is formed, fp32 accumulate:
      * the numerics of "bf16 weights and activations, fp32 accumulate" (BASELINE configs[4]).  chunk_channels in
-     * {16, 32, 64}; LDS-DMA staged inputs only (in_mode DIRECT / UPSAMPLE2, no in_transform). */
+     * {16, 32, 64, 128}; LDS-DMA staged inputs only (in_mode DIRECT / UPSAMPLE2, no in_transform). */
     int32_t compute_dtype;
 } mr_conv_desc;
 

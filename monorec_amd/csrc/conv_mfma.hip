@@ -604,7 +604,7 @@ struct Derived {
 };
 
 bool valid_mb(int mb) { return mb == 1 || mb == 2 || mb == 3 || mb == 4 || mb == 6; }
-bool valid_ck(int ck) { return ck == 8 || ck == 16 || ck == 32 || ck == 64; }
+bool valid_ck(int ck) { return ck == 8 || ck == 16 || ck == 32 || ck == 64 || ck == 128; }
 
 int derive(const mr_conv_desc* d, Derived* out) {
     if (!d || d->num_src < 1 || d->num_src > MR_MAX_SOURCES) return MR_ERR_BAD_ARGUMENT;

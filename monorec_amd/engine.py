@@ -147,7 +147,7 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                 if mb > cb and mb != 1:
                     continue
                 groups = math.ceil(cb / mb)
-                for ck in ((16, 32, 64) if bf16 else (8, 16, 32, 64)):
+                for ck in ((16, 32, 64, 128) if bf16 else (8, 16, 32, 64, 128)):
                     if ck > 16 and ck // 2 >= max(cpads):
                         continue
                     nchunks = sum(math.ceil(c / ck) for c in cpads)

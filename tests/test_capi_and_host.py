@@ -213,7 +213,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
     assert abs(plan.conv_macs() / 1e9 - 61.07) < 0.01
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
-    assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64)
+    assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log)
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 4        # the four Refine transposed convolutions
     assert len(plan.stages["encoder"]) == 22 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"

@@ -123,16 +123,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MR_HIP_LIBRARY") or LIB_PATH      # MR_HIP_LIBRARY: e.g. the timeline-instrumented diagnostic build
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build the gfx950 kernels first (python -m monorec_amd.build or "
+            f"{path} not found: build the gfx950 kernels first (python -m monorec_amd.build or "
             "__graft_entry__.build()). monorec_amd has no CPU/PyTorch fallback for its hot path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in ABI.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.mr_abi_version() != 2:

@@ -64,5 +64,27 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+TIMELINE_LIB_PATH = os.path.join(HERE, "libmonorec_hip_timeline.so")
+
+
+def build_timeline(verbose=False):
+    """Diagnostic variant for tools/wg_timeline.py: conv_mfma.hip with -DMR_CONV_TIMELINE (per-workgroup timestamps;
+    ~3 % slower even when the stamps are off, hence not in the product library).  Select it with MR_HIP_LIBRARY."""
+    build(verbose=verbose)
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    o = os.path.join(objdir, "conv_mfma_timeline.o")
+    src = os.path.join(CSRC, "conv_mfma.hip")
+    if _stale(o, [src, os.path.join(CSRC, "conv_layout.h")]):
+        subprocess.run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-DMR_CONV_TIMELINE", "-c", src, "-o", o], check=True)
+    objs = [o] + [os.path.join(objdir, s.replace(".hip", ".o")) for s, _ in SOURCES if s != "conv_mfma.hip"]
+    if _stale(TIMELINE_LIB_PATH, objs):
+        subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", TIMELINE_LIB_PATH] + objs, check=True)
+    return TIMELINE_LIB_PATH
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--timeline" in sys.argv:
+        print(build_timeline(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -173,12 +173,25 @@ __device__ __forceinline__ void dma_global_x1(unsigned lds_byte_addr, const floa
                  "global_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
 }
-// MR_CONV_DBG bit 16 (tools/wg_timeline.py): thread 0 of every workgroup drops 100 MHz timestamps into the workspace
+// Ablation / timeline switches exist only in the diagnostic library (python -m monorec_amd.build --timeline, -DMR_CONV_TIMELINE):
+// in the product kernel MR_DBG(bit) is a compile-time 0 - carried as run-time tests they cost ~3 % keyframes/s.
+#ifdef MR_CONV_TIMELINE
+#define MR_DBG(bit) (a.dbg & (bit))
+#else
+#define MR_DBG(bit) 0
+#endif
+
+// MR_CONV_DBG bit 16 (tools/wg_timeline.py, library built with -DMR_CONV_TIMELINE): thread 0 of every workgroup drops
+// 100 MHz timestamps into the workspace
 __device__ __forceinline__ void dbg_stamp(const ConvKArgs& a, int k) {
+#ifndef MR_CONV_TIMELINE      // the stamps cost ~3 % keyframes/s even when switched off (SGPR pressure): opt-in at compile time
+    (void)a; (void)k;
+#else
     if ((a.dbg & 16) && threadIdx.x == 0) {
         const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
         ((unsigned long long*)a.ws)[wg * 12 + k] = (k == 9 || k == 10) ? clock64() : wall_clock64();
     }
+#endif
 }
 
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -221,14 +234,14 @@ __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCurso
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
     const int wfloats = T * ck * MB * (a.bf16 ? 8 : 16);
     const float* wsrc = wgrp + c.woff;
-    const int n1k = (a.dbg & 4) ? 0 : wfloats >> 8;   // 1 KiB pieces (64 lanes x 16 B)
+    const int n1k = MR_DBG(4) ? 0 : wfloats >> 8;   // 1 KiB pieces (64 lanes x 16 B)
     for (int kb = wave; kb < n1k; kb += nwave) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
-    const int nfrag = (a.dbg & 4) ? 0 : wfloats >> 6; // tail: 256 B pieces (64 lanes x 4 B)
+    const int nfrag = MR_DBG(4) ? 0 : wfloats >> 6; // tail: 256 B pieces (64 lanes x 4 B)
     for (int fr = (n1k << 2) + wave; fr < nfrag; fr += nwave) dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane);
 
     const int creal = a.src_c[c.s] - c.c0;                            // real (unpadded) channels left
     const int sbase_bytes = (b * a.src_c[c.s] + c.c0) * HsWs * 4;     // byte offset of channel c0 of sample b
-    if (a.dbg & 2) return;
+    if (MR_DBG(2)) return;
     if (DMA_IN && a.dma_x4) {
         // one buffer_load_dwordx4 ... lds = 64 lanes x 16 B = up to 256 consecutive floats of one channel plane;
         // wave w streams channels w, w+4, ... of the chunk
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
             issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
         }
         if (stamp) dbg_stamp(a, 5);
-        if (!(a.dbg & 1)) {
+        if (!MR_DBG(1)) {
             if (BF16) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
             else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
         }
@@ -497,10 +510,10 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     // ---- epilogue: D fragment lane l holds pixel (l&15), couts (l>>4)*4 + r ---------------------
     const int CB16 = a.CB * 16;
     dbg_stamp(a, 2);
-    if (a.dbg & 16) {                                  // stamp 3 = after this thread's stores were accepted
+    if (MR_DBG(16)) {                                  // stamp 3 = after this thread's stores were accepted
         if (a.ksplit > 1) return;                      // (the workspace is the stamp buffer here)
     }
-    if (a.dbg & 8) { if (acc[0][0][0] != 123.456f) return; }
+    if (MR_DBG(8)) { if (acc[0][0][0] != 123.456f) return; }
     const int lq4 = (lane >> 4) * 4;
     if (a.ksplit > 1) {                                // raw partial sums; splitk_epilogue_kernel finishes them
         const long long plane = (long long)a.Ho * a.Wo;
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
             }
         }
     }
-    if (a.dbg & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(a, 3); }
+    if (MR_DBG(16)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(a, 3); }
 }
 
 __device__ __forceinline__ void mr_store_out(const ConvKArgs& a, int ph, int b, int cout, int oy, int ox, float v) {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Ablation timing of single conv launches (env MR_CONV_DBG bits: 1 no sweep, 2 no input DMA, 4 no weight DMA, 8 no stores)."""
+"""Ablation timing of single conv launches (env MR_CONV_DBG bits: 1 no sweep, 2 no input DMA, 4 no weight DMA, 8 no stores;
+needs the diagnostic library: python -m monorec_amd.build --timeline, selected here through MR_HIP_LIBRARY)."""
 import os, sys, json, subprocess, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -28,7 +29,8 @@ else:
     names = "mask.enc0.0,mask.dec3.1,resnet.l1b0.conv1,depth.enc2.1.conv_y,resnet.l4b0.conv2,depth.dec2.0"
     table = {}
     for dbg in (0, 1, 2, 4, 8, 3, 7, 15):
-        env = dict(os.environ, MR_CONV_DBG=str(dbg))
+        from monorec_amd import build as _build
+        env = dict(os.environ, MR_CONV_DBG=str(dbg), MR_HIP_LIBRARY=_build.build_timeline())   # the switches live in the diagnostic library
         out = subprocess.run([sys.executable, __file__, "child", names], env=env, capture_output=True, text=True).stdout
         line = [l for l in out.splitlines() if l.startswith("RESULT ")]
         table[dbg] = json.loads(line[0][7:]) if line else None

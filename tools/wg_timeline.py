@@ -7,6 +7,10 @@ import os
 import sys
 
 os.environ["MR_CONV_DBG"] = os.environ.get("MR_TL_DBG", "16")
+ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT_)
+from monorec_amd import build as _build  # noqa: E402
+os.environ["MR_HIP_LIBRARY"] = _build.build_timeline()      # stamps are compiled in only in this diagnostic library
 import numpy as np
 import torch
 

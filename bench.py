@@ -63,7 +63,7 @@ def time_layers(model, batch_dev, plan_key, reps=5):
     """Per-launch device time with HIP events on the stream the kernels are launched on."""
     plan = model._plans[plan_key]
     stream = torch.cuda.current_stream()
-    ops = plan.stages["encoder"] + plan.stages["cv"] + plan.stages["main"]
+    ops = plan.stages["encoder"] + plan.stages["encoder_tail"] + plan.stages["cv"] + plan.stages["main"]
     acc = [0.0] * len(ops)
     for _ in range(reps):
         evs = []

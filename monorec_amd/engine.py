@@ -4,7 +4,8 @@ The plan owns every activation buffer (allocated once, HBM resident), the repack
 ordered list of C-ABI launches (include/monorec_hip.h).  It is the host-side replacement of the ATen
 call sequence inside `MonoRecModel.forward` (reference model/monorec/monorec_model.py:672-729):
 
-    stage "encoder" : ResnetEncoder.forward (:118-129)                 - independent of the poses
+    stage "encoder" : ResnetEncoder.forward (:118-129) up to layer3    - independent of the poses
+    stage "encoder_tail" : ResNet layer4 (output image_features[4] only; nothing downstream reads it)
     stage "cv"      : CostVolumeModule (:193-271) -> MaskModule encoder (:357-365)  - independent of the image features
     stage "main"    : MaskModule decoder (:370-383) -> (1-mask)*cv (:713) -> DepthModule (:526-557) -> affine (:717)
 "encoder" and "cv" have no data dependence on each other, so MonoRecModel runs them on two HIP streams at the
@@ -211,7 +212,7 @@ class Plan:
         self.sd = state
         self.buf = {}
         self.keep = []          # packed weights / biases (device tensors kept alive)
-        self.stages = {"encoder": [], "cv": [], "main": []}
+        self.stages = {"encoder": [], "encoder_tail": [], "cv": [], "main": []}
         self.conv_log = []      # (name, macs, mb, nb, split_k, wgs) for bench / tuning
         self._ws_floats = {}      # stage -> floats: stages may run concurrently on different streams,
         self._pending_ws = []     # so every stage gets its own split-K workspace
@@ -394,6 +395,8 @@ class Plan:
         feats = [f0]
         x, cin, hh, ww = pool, 64, H // 4, W // 4
         for li, cout in enumerate((64, 128, 256, 512), start=1):
+            if li == 4:
+                st = "encoder_tail"      # layer4 only feeds image_features[4]: nothing downstream waits for it
             for bi in range(2):
                 pre = f"{enc}.layer{li}.{bi}"
                 stride = 2 if (li > 1 and bi == 0) else 1

@@ -371,6 +371,11 @@ class MonoRecModel(nn.Module):
             self._run_stage(key, plan, "encoder", enc)
             enc_done = torch.cuda.Event()
             enc_done.record(enc)
+            # ResNet layer4 is output-only (image_features[4]): it keeps running on the encoder stream while the mask /
+            # depth stages proceed, and only the completion event of the keyframe waits for it
+            self._run_stage(key, plan, "encoder_tail", enc)
+            tail_done = torch.cuda.Event()
+            tail_done.record(enc)
 
             # 3. host 4x4 algebra while the encoder runs, then upload
             mats_done.synchronize()
@@ -384,6 +389,7 @@ class MonoRecModel(nn.Module):
             self._run_stage(key, plan, "cv", main)
             main.wait_event(enc_done)
             self._run_stage(key, plan, "main", main)
+            main.wait_event(tail_done)
             done = torch.cuda.Event()
             done.record(main)
         data_dict["cv_module_time"] = keyframe.new_tensor([time.time() - start_time])

@@ -216,7 +216,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log)
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 4        # the four Refine transposed convolutions
-    assert len(plan.stages["encoder"]) == 22 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
+    assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
 
 def test_bf16_weight_packing_layout(hip_lib):

@@ -17,13 +17,13 @@ for graph in (True, False):
     key, plan = next(iter(m._plans.items()))
     # stage graphs alone
     if graph:
-        for st in ("encoder", "cv", "main"):
+        for st in ("encoder", "encoder_tail", "cv", "main"):
             g = m._graphs[(key, st)]
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): g.replay()
             torch.cuda.synchronize(); print(f"  graph '{st}' replay alone: {1e3*(time.perf_counter()-t0)/20:.3f} ms")
     s = torch.cuda.current_stream()
-    for st in ("encoder", "cv", "main"):
+    for st in ("encoder", "encoder_tail", "cv", "main"):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): plan.run_stage(st, s.cuda_stream)
         t1 = time.perf_counter(); torch.cuda.synchronize()

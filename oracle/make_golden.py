@@ -412,6 +412,20 @@ def main():
         store[name + ".cfg"] = np.array([h, w, c, oh, ow], dtype=np.int64)
         print("preprocess", name, "ok; oracle == Pillow", Image.__version__ if hasattr(Image, "__version__") else "")
     np.savez_compressed(os.path.join(GOLDEN, "preprocess_cases.npz"), **store)
+    # ---- drop-in runner: the names evaluate.py / create_pointcloud.py look up resolve to the MI355X implementations ------
+    from monorec_amd import dropin
+    rebound = dropin.install()
+    import model.model as module_arch                                     # noqa: reference module, now rebound
+    import model.metric as module_metric                                  # noqa
+    cfg = json.load(open(os.path.join(ref_shims.REFERENCE_ROOT, "configs", "evaluate", "eval_monorec.json")))
+    arch = cfg["models"][0]
+    kw = dict(arch["args"], checkpoint_location=None)
+    built = getattr(module_arch, arch["type"])(**kw)                       # utils/parse_config.py:72-89
+    assert type(built).__module__ == "monorec_amd.model"
+    assert all(getattr(module_metric, m).__module__ == "monorec_amd.metrics" for m in cfg["metrics"])   # evaluate.py:24
+    report["dropin_rebinds"] = [f"{a}.{b}" for a, b in rebound]
+    print("dropin: eval_monorec.json model + its", len(cfg["metrics"]), "metrics resolve to monorec_amd")
+
     with open(os.path.join(GOLDEN, "PINNING.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print("wrote", GOLDEN)

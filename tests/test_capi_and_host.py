@@ -249,3 +249,35 @@ def test_bf16_weight_packing_layout(hip_lib):
                                     assert blk[lane, j] == exp, (grp, sc, c0, tap, c16, m, lane, j)
             cin_off += sc
     assert o == u16.size
+
+
+def test_dropin_rebinds_the_names_the_reference_scripts_look_up(tmp_path):
+    """python -m monorec_amd.dropin <script>: a miniature checkout with the reference's import structure (model/model.py re-export,
+    model/metric.py star imports, utils/__init__.py star import) - the script itself is untouched."""
+    import subprocess
+    import sys
+    root = tmp_path
+    (root / "model" / "monorec").mkdir(parents=True)
+    (root / "model" / "metric_functions").mkdir()
+    (root / "utils").mkdir()
+    (root / "model" / "__init__.py").write_text("")
+    (root / "model" / "monorec" / "__init__.py").write_text("")
+    (root / "model" / "metric_functions" / "__init__.py").write_text("")
+    (root / "model" / "monorec" / "monorec_model.py").write_text("class MonoRecModel:\n    origin = 'reference'\n")
+    (root / "model" / "model.py").write_text("from .monorec.monorec_model import MonoRecModel\n")
+    (root / "model" / "metric_functions" / "sparse_metrics.py").write_text(
+        "def abs_rel_sparse_metric(*a, **k):\n    return 'reference'\ndef other_metric(*a, **k):\n    return 'reference'\n")
+    (root / "model" / "metric.py").write_text("from .metric_functions.sparse_metrics import *\n")
+    (root / "utils" / "ply_utils.py").write_text("class PLYSaver:\n    origin = 'reference'\n")
+    (root / "utils" / "__init__.py").write_text("from .ply_utils import *\n")
+    (root / "evaluate_like.py").write_text(
+        "import sys\nimport model.metric as module_metric\nimport model.model as module_arch\nfrom utils import PLYSaver\n"
+        "cls = getattr(module_arch, 'MonoRecModel')\n"
+        "print(cls.__module__, getattr(module_metric, 'abs_rel_sparse_metric').__module__, module_metric.other_metric(),\n"
+        "      PLYSaver.__module__, sys.argv[1:])\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "monorec_amd.dropin", "evaluate_like.py", "--config", "x.json"], cwd=root,
+                         env=dict(os.environ, PYTHONPATH=repo), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["monorec_amd.model", "monorec_amd.metrics", "reference", "monorec_amd.pointcloud",
+                                  "['--config',", "'x.json']"]

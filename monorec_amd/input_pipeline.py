@@ -86,18 +86,38 @@ class ImagePreprocessor:
         up = lambda a: torch.from_numpy(a).to(self.device)
         self.hb, self.hk, self.vb, self.vk = up(hb), up(hk), up(vb), up(vk)
         self._box_c = (ctypes.c_int32 * 4)(*self.box)
+        self._staging = {}          # channels -> ring of (pinned host buffer, device buffer, copy-done event)
+        self._ring_pos = 0
 
     def __call__(self, image, out=None):
         """image: uint8 (H, W, 3) or (H, W), numpy / CPU tensor (uploaded) or device tensor -> float32 (3, h, w) on the device."""
+        if torch.is_tensor(image) and not image.is_cuda:
+            image = image.numpy()
         if isinstance(image, np.ndarray):
-            image = torch.from_numpy(np.ascontiguousarray(image))
-        if image.dtype != torch.uint8 or image.dim() not in (2, 3):
-            raise ValueError("expected a uint8 (H, W[, 3]) image")
-        channels = 1 if image.dim() == 2 else image.shape[2]
+            if image.dtype != np.uint8 or image.ndim not in (2, 3):
+                raise ValueError("expected a uint8 (H, W[, 3]) image")
+            channels = 1 if image.ndim == 2 else image.shape[2]
+        else:
+            if image.dtype != torch.uint8 or image.dim() not in (2, 3):
+                raise ValueError("expected a uint8 (H, W[, 3]) image")
+            channels = 1 if image.dim() == 2 else image.shape[2]
         if (image.shape[0], image.shape[1]) != (self.orig_h, self.orig_w) or channels not in (1, 3):
             raise ValueError(f"image of shape {tuple(image.shape)} does not match this preprocessor ({self.orig_h}x{self.orig_w})")
-        if not image.is_cuda:
-            image = image.contiguous().pin_memory().to(self.device, non_blocking=True)
+        if isinstance(image, np.ndarray):
+            # host image: through a small ring of pinned staging buffers (allocated once), asynchronous upload
+            ring = self._staging.get(channels)
+            if ring is None:
+                shape = (self.orig_h, self.orig_w) if channels == 1 else (self.orig_h, self.orig_w, channels)
+                ring = [(torch.empty(shape, dtype=torch.uint8).pin_memory(), torch.empty(shape, dtype=torch.uint8, device=self.device),
+                         torch.cuda.Event()) for _ in range(4)]
+                self._staging[channels] = ring
+            host, devbuf, ev = ring[self._ring_pos % len(ring)]
+            self._ring_pos += 1
+            ev.synchronize()                                   # the upload that last used this slot has finished
+            host.numpy()[...] = image
+            devbuf.copy_(host, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            image = devbuf
         image = image.contiguous()
         if out is None:
             out = torch.empty(3, self.out_h, self.out_w, dtype=torch.float32, device=self.device)

@@ -35,6 +35,7 @@ struct CvArgs {
     const float* kinv;    // B x 9
     const float* proj;    // B x F x 12
     const float* depths;  // D
+    const float* pix_depths;  // B x D x H x W per-pixel hypotheses (data_dict['cv_depths'], monorec_model.py:181-182) or null
     float* cv;
     int F, B, D, H, W;
     int tiles_x, nchunk, dchunk;
@@ -122,7 +123,7 @@ __device__ __forceinline__ bool mask_hit(const Sample& sp, int H, int W) {
 
 // MODE = the photometric term of monorec_model.py:227-243 (use_ssim): 1 SSIM distance (default), 0 absolute difference,
 // 2 the 0.85 / 0.15 mix of both, 3 absolute difference averaged over 3x3 (zero padded, avg_pool2d).
-template <int TX, int TY, int MODE>
+template <int TX, int TY, int MODE, bool PIXD>
 __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
     constexpr int NT = TX * TY;
     constexpr int HX = TX + 4, HY = TY + 4;   // warped / keyframe tile with 2 px halo
@@ -223,10 +224,11 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
         // ---- (a) warp own pixel + one halo position, DPI depth planes ---------------------------
 #pragma unroll
         for (int u = 0; u < DPI; ++u) {
-            const float depth = a.depths[d + u];
+            const float depth = PIXD ? 0.f : a.depths[d + u];
+            const float* pd = PIXD ? a.pix_depths + ((long long)b * D + d + u) * HWp : nullptr;
             float* wru = wr + u * 3 * HY * HX;
             if (own_in) {
-                const Sample sp = project(ro[0], ro[1], ro[2], depth, P, H, W);
+                const Sample sp = project(ro[0], ro[1], ro[2], PIXD ? pd[opy * W + opx] : depth, P, H, W);
                 hit_all = hit_all && mask_hit(sp, H, W);                   // monorec_model.py:218-219
                 const Taps tp = tap_offsets(sp, H, W);
 #pragma unroll
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                     wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img, c * HWp * 4, tp, sp) + 0.5f;
             }
             if (has_halo) {
-                const Sample sp = project(rh[0], rh[1], rh[2], depth, P, H, W);
+                const Sample sp = project(rh[0], rh[1], rh[2], PIXD ? pd[hpy * W + hpx] : depth, P, H, W);
                 const Taps tp = tap_offsets(sp, H, W);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -400,11 +402,20 @@ int launch_cv(const CvArgs& a, int mode, hipStream_t stream) {
     k.nchunk = nchunk;
     k.dchunk = a.D / nchunk;
     const dim3 grid(tiles, a.F * nchunk, a.B), block(TX * TY);
-    switch (mode) {
-        case 0: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 0>), grid, block, 0, stream, k); break;
-        case 2: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 2>), grid, block, 0, stream, k); break;
-        case 3: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 3>), grid, block, 0, stream, k); break;
-        default: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 1>), grid, block, 0, stream, k); break;
+    if (a.pix_depths) {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 0, true>), grid, block, 0, stream, k); break;
+            case 2: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 2, true>), grid, block, 0, stream, k); break;
+            case 3: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 3, true>), grid, block, 0, stream, k); break;
+            default: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 1, true>), grid, block, 0, stream, k); break;
+        }
+    } else {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 0, false>), grid, block, 0, stream, k); break;
+            case 2: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 2, false>), grid, block, 0, stream, k); break;
+            case 3: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 3, false>), grid, block, 0, stream, k); break;
+            default: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 1, false>), grid, block, 0, stream, k); break;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -420,9 +431,10 @@ extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const
                                        const float* kinv, const float* proj, const float* depths,
                                        int32_t batch, int32_t num_depths, int32_t height, int32_t width,
                                        float alpha, const float* channel_weights, int32_t use_ssim,
+                                       const float* pixel_depths,
                                        float* cost_volume, float* const* sfcv, void* stream) {
     if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
-    if (!keyframe || !frames || !kinv || !proj || !depths || !cost_volume || !sfcv || !channel_weights)
+    if (!keyframe || !frames || !kinv || !proj || (!depths && !pixel_depths) || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
     if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
     if (num_depths < 2 || (num_depths & 1)) return MR_ERR_UNSUPPORTED;   // two planes per iteration
@@ -433,7 +445,7 @@ extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const
         a.sfcv[f] = f < num_frames ? sfcv[f] : nullptr;
         if (f < num_frames && (!a.frames[f] || !a.sfcv[f])) return MR_ERR_BAD_ARGUMENT;
     }
-    a.kinv = kinv; a.proj = proj; a.depths = depths; a.cv = cost_volume;
+    a.kinv = kinv; a.proj = proj; a.depths = depths; a.pix_depths = pixel_depths; a.cv = cost_volume;
     a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
     a.tiles_x = 0; a.nchunk = 1; a.dchunk = num_depths;
     a.alpha = alpha;
@@ -448,5 +460,5 @@ extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* fra
                                   float alpha, const float* channel_weights,
                                   float* cost_volume, float* const* sfcv, void* stream) {
     return mr_cost_volume_mode_f32(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
-                                   channel_weights, 1, cost_volume, sfcv, stream);
+                                   channel_weights, 1, nullptr, cost_volume, sfcv, stream);
 }

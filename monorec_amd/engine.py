@@ -208,6 +208,7 @@ class Plan:
         self.cw = (ctypes.c_float * 3)(*[float(torch.tensor(c, dtype=torch.float32)) for c in channel_weights])
         self.schedule_override = schedule_override or {}
         self.cv_mode = {False: 0, True: 1}.get(use_ssim, use_ssim) if not isinstance(use_ssim, bool) else int(use_ssim)
+        self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
         self.buf = {}
@@ -429,8 +430,9 @@ class Plan:
         kinv, proj, depths = self.buf["kinv"], self.buf["proj"], self.buf["depths"]
 
         def run_cv(stream):
+            pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
             _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
-                                                   depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode,
+                                                   depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                    cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
         self.add(st, "cost_volume", run_cv)
 

@@ -331,8 +331,9 @@ class MonoRecModel(nn.Module):
             raise RuntimeError("monorec_amd.MonoRecModel needs its inputs on a HIP device (cuda:N on ROCm); "
                                "there is no CPU path")
         _lib.load()
-        if "cv_depths" in data_dict:
-            raise NotImplementedError("per-pixel cv_depths override is not supported (SURVEY.md f-4)")
+        cv_depths = data_dict.get("cv_depths")                # per-pixel depth hypotheses (monorec_model.py:181-182)
+        if cv_depths is not None and self._hip_graph:
+            raise NotImplementedError("cv_depths with hip_graph=True: the captured launch has no per-pixel depth pointer")
         b, c, h, w = keyframe.shape
         nf = len(frames)
         device = keyframe.device
@@ -385,6 +386,13 @@ class MonoRecModel(nn.Module):
             plan.host_geom[b * 9:].copy_(proj.reshape(-1))
             plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
 
+            plan.pix_depths_on = cv_depths is not None
+            if cv_depths is not None:
+                if tuple(cv_depths.shape) != (b, self.cv_depth_steps, h, w):
+                    raise ValueError(f"cv_depths must be (B, cv_depth_steps, H, W), got {tuple(cv_depths.shape)}")
+                if "pix_depths" not in plan.buf:
+                    plan.alloc("pix_depths", b, self.cv_depth_steps, h, w)
+                plan.buf["pix_depths"].copy_(cv_depths)
             # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
             self._run_stage(key, plan, "cv", main)
             main.wait_event(enc_done)

@@ -187,3 +187,13 @@ def make_u8_image(height, width, channels=3, seed=11):
     img[:, :, :, width // 4: width // 4 + 3] = 0.0
     a = (img.clamp(0, 1) * 255).round().to(torch.uint8)[0].permute(1, 2, 0).contiguous().numpy()
     return a[:, :, 0].copy() if channels == 1 else a
+
+
+def make_pixel_depths(batch, depths, height, width, seed=34):
+    """Seeded per-pixel depth hypotheses (B, D, H, W) for the `cv_depths` input: the model's uniform inverse-depth ladder,
+    smoothly perturbed per pixel by up to +-20 %."""
+    gen = torch.Generator().manual_seed(seed)
+    base = 1 / torch.linspace(0.0025, 0.33, depths)
+    low = torch.rand(batch, depths, max(height // 8, 2), max(width // 8, 2), generator=gen)
+    pert = F.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)
+    return (base.view(1, depths, 1, 1) * (0.8 + 0.4 * pert)).contiguous()

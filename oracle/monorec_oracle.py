@@ -92,7 +92,7 @@ def ssim_distance(x, y):
 
 
 def cost_volume(batch, inv_depth_min=0.33, inv_depth_max=0.0025, steps=32, patch_size=3,
-                channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, stages=None, use_ssim=True):
+                channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, stages=None, use_ssim=True, cv_depths=None):
     """CostVolumeModule.forward (monorec_model.py:150-280), use_mono, sfcv_mult_mask=True; use_ssim selects the photometric
     term (:227-243): True SSIM distance, False absolute difference, 2 the 0.85/0.15 mix, 3 3x3-averaged absolute difference.
 
@@ -113,7 +113,10 @@ def cost_volume(batch, inv_depth_min=0.33, inv_depth_max=0.0025, steps=32, patch
     for n in range(b):                                                               # :193
         inv_k = torch.inverse(batch["keyframe_intrinsics"][n]).unsqueeze(0)          # :198
         rays = inv_k[:, :3, :3] @ coord                                              # :199
-        pts = depths.view(steps, 1, 1) * rays                                        # :200
+        if cv_depths is not None:                                                    # per-pixel hypotheses, :181-182
+            pts = cv_depths[n].reshape(steps, 1, -1) * rays
+        else:
+            pts = depths.view(steps, 1, 1) * rays                                    # :200
         pts = torch.cat([pts, ones.expand(steps, -1, -1)], 1)                        # :201
         warped, valid = [], []
         grids = []
@@ -305,11 +308,11 @@ def depth_module(sd, cost_volume_masked, keyframe, feats, prefix="depth_module")
 # ----------------------------------------------------------------------------------------
 # MonoRecModel.forward (monorec_model.py:672-729)
 # ----------------------------------------------------------------------------------------
-def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True):
+def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True, cv_depths=None):
     """Returns the reference's output dict entries for eval / pretrain_mode=0."""
     with torch.no_grad():
         cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages,
-                                use_ssim=use_ssim)
+                                use_ssim=use_ssim, cv_depths=cv_depths)
         feats = resnet_features(sd, batch["keyframe"] + .5)                         # :691
         cv_mask = mask_module(sd, sfcvs, feats)                                     # :694
         cv_masked = (1 - cv_mask) * cv                                              # :713

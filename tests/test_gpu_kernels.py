@@ -233,7 +233,7 @@ def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
         assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
 
 
-def _hip_cost_volume(batch, d, use_ssim=1):
+def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None):
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)
     b, _, h, w = kf.shape
@@ -247,12 +247,13 @@ def _hip_cost_volume(batch, d, use_ssim=1):
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
-    if use_ssim == 1:
+    if use_ssim == 1 and cv_depths is None:
         _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
                                           b, d, h, w, 10.0, cw, cv.data_ptr(), sp, _stream()), "mr_cost_volume_f32")
     else:
         _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
-                                               b, d, h, w, 10.0, cw, int(use_ssim), cv.data_ptr(), sp, _stream()),
+                                               b, d, h, w, 10.0, cw, int(use_ssim),
+                                               None if cv_depths is None else cv_depths.data_ptr(), cv.data_ptr(), sp, _stream()),
                    "mr_cost_volume_mode_f32")
     torch.cuda.synchronize()
     return cv.cpu(), [s.cpu() for s in sf]
@@ -312,6 +313,21 @@ def test_cost_volume_use_ssim_variants(hip_lib, mode):
     # the variants really differ from the default term
     dcv, _ = _hip_cost_volume(batch, g.depths)
     assert (dcv - cv).abs().max().item() > 1e-2
+
+
+def test_cost_volume_per_pixel_depths(hip_lib):
+    """data_dict["cv_depths"] (monorec_model.py:181-182): per-pixel depth hypotheses instead of the shared ladder."""
+    g = Golden("cv_pixel_depths")
+    batch = g.make_inputs()
+    pix = synth.make_pixel_depths(g.batch, g.depths, g.h, g.w, seed=34)
+    cv, sf = _hip_cost_volume(batch, g.depths, cv_depths=pix.to(DEV))
+    for f in range(g.frames):
+        g.compare(f"sfcv{f}", sf[f], atol=2e-6, max_outlier_frac=1e-4)
+    g.compare("cost_volume", cv, atol=1e-5, max_outlier_frac=1e-4)
+    ocv, _ = orc.cost_volume(batch, steps=g.depths, cv_depths=pix)
+    assert ((cv - ocv).abs() > 1e-4).float().mean().item() <= 2e-4
+    ucv, _ = _hip_cost_volume(batch, g.depths)
+    assert (ucv - cv).abs().max().item() > 1e-2           # really different from the shared ladder
 
 
 def test_cost_volume_properties_at_full_size(hip_lib):

@@ -203,6 +203,23 @@ def test_use_stereo_adds_a_source_view(hip_lib):
     _check_against(out1, orc.forward(sd, one, cv_depth_steps=g.depths), "stereo only")
 
 
+def test_cv_depths_through_the_model(hip_lib):
+    """The optional `cv_depths` entry of the input dict reaches the cost-volume kernel (and is not sticky)."""
+    model, sd = _model(8, graph=False)
+    batch = synth.make_batch(1, 64, 96, 2, seed=4)
+    pix = synth.make_pixel_depths(1, 8, 64, 96, seed=35)
+    data = _to_dev(batch)
+    data["cv_depths"] = pix.to(DEV)
+    with torch.no_grad():
+        out = model(data)
+    torch.cuda.synchronize()
+    _check_against(out, orc.forward(sd, batch, cv_depth_steps=8, cv_depths=pix), "cv_depths")     # before the buffers are reused
+    with torch.no_grad():
+        plain = model(_to_dev(batch))["result"].clone()
+    ref_plain = orc.forward(sd, batch, cv_depth_steps=8)
+    assert (plain.cpu() - ref_plain["result"]).abs().max().item() <= RESULT_ATOL
+
+
 def test_depth_large_model(hip_lib):
     """depth_large_model=True (monorec_model.py:482-483): the plan takes the DepthModule widths from the weights."""
     g = Golden("small_large_depth")

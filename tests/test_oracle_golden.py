@@ -101,3 +101,12 @@ def test_oracle_use_ssim_variants_match_reference_fixture(mode):
     g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
     for i, t in enumerate(sf):
         g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
+
+
+def test_oracle_per_pixel_depths_match_reference_fixture():
+    g = Golden("cv_pixel_depths")
+    pix = synth.make_pixel_depths(g.batch, g.depths, g.h, g.w, seed=34)
+    cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths, cv_depths=pix)
+    g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(sf):
+        g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)

@@ -281,3 +281,35 @@ def test_dropin_rebinds_the_names_the_reference_scripts_look_up(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split() == ["monorec_amd.model", "monorec_amd.metrics", "reference", "monorec_amd.pointcloud",
                                   "['--config',", "'x.json']"]
+
+
+def test_python_lds_model_bounds_the_library(hip_lib):
+    """engine.candidate_schedules filters by engine.lds_bytes (a Python mirror of derive() in conv_mfma.hip): for every candidate it
+    keeps, the library must accept the launch and need no more LDS than the mirror predicted."""
+    import itertools
+    import random
+    rnd = random.Random(5)
+    shapes = [(64, [64], 3, 3, 1, 1, 64, 128), (128, [64], 3, 3, 2, 2, 32, 64), (96, [96, 128, 96], 3, 3, 1, 1, 32, 64),
+              (48, [35], 7, 1, 1, 1, 256, 512), (64, [48], 1, 7, 1, 2, 128, 256), (1, [24], 3, 3, 1, 1, 256, 512),
+              (512, [512], 3, 3, 1, 1, 8, 16), (256, [128], 1, 1, 2, 2, 16, 32), (24, [32], 3, 3, 1, 1, 50, 70)]
+    checked = 0
+    for (cout, srcs, kh, kw, sh, sw, oh, ow), bf16 in itertools.product(shapes, (False, True)):
+        cands = engine.candidate_schedules(cout, srcs, kh, kw, sh, sw, oh, ow, 1, lds_cap=160 * 1024, bf16=bf16)
+        for cd in rnd.sample(cands, min(len(cands), 25)):
+            d = _lib.ConvDesc()
+            d.num_src = len(srcs)
+            for i, c in enumerate(srcs):
+                d.src[i], d.src_channels[i] = 16, c
+            d.batch, d.src_h, d.src_w = 1, oh * sh, ((ow * sw) + 3) // 4 * 4
+            d.kh, d.kw, d.stride_h, d.stride_w, d.pad_top, d.pad_left = kh, kw, sh, sw, kh // 2, kw // 2
+            d.out_h, d.out_w, d.dst, d.out_channels, d.dst_total_channels = oh, ow, 16, cout, cout
+            d.dst_plane_h, d.dst_plane_w, d.out_step_h, d.out_step_w = oh, ow, 1, 1
+            d.packed_weights = 16
+            d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = cd["mb"], cd["nb"], cd["split_k"], cd["ck"]
+            d.waves_per_wg, d.compute_dtype = cd["waves"], 1 if bf16 else 0
+            got = int(hip_lib.mr_conv2d_lds_bytes(ctypes.byref(d)))
+            if got == -2 and cd["waves"] == 8:            # 8-wave tiles need the dwordx4 path: legitimately refused for some geometries
+                continue
+            assert 0 < got <= cd["lds"] <= 160 * 1024, (cout, srcs, kh, kw, cd, got)
+            checked += 1
+    assert checked > 200

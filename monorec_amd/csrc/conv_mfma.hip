@@ -4,20 +4,20 @@
 // (reference: model/layers.py:241-252,289-356,380-400; model/monorec/monorec_model.py:118-129,
 // 345-385,526-557).  See conv_layout.h for the GEMM view and the packed weight stream.
 //
-// Workgroup = 256 threads = 4 waves.  It owns a TH x (TWB*16) tile of one output plane and MB
-// consecutive 16-channel output blocks.  Per K chunk (<= CK input channels of one concat source):
-//   * the haloed input tile is staged into LDS - each thread owns fixed tile positions and issues the
-//     loads of 16 channels back to back (one memory latency per batch, not per element); zero padding,
-//     nearest-upsample, 2x2 max-pool and the ResNet input normalisation are applied here, so those ops
-//     never touch HBM;
-//   * the chunk's A fragments (one contiguous block of the packed stream) are DMA'd global->LDS with
-//     global_load_lds_dwordx4 (no VGPR round trip);
-//   * after one barrier every wave sweeps taps x channel-quads reading A (lane-linear) and B
-//     (plane stride = 16 mod 32, conflict free) from LDS and issues MB*NB v_mfma_f32_16x16x4_f32 per
-//     k-step - the sweep contains no global memory access at all.
-// Latency of the staging phase is hidden by co-resident workgroups (LDS footprint is kept small enough
-// for >= 3 per CU).  fp32 MFMA is an exact fmaf chain, so results differ from the oneDNN CPU reference
-// only by summation order.
+// Workgroup = WV (4 or 8) waves.  It owns a TH x (TWB*16) tile of one output plane (WV*NB blocks of 16 pixels) and MB
+// consecutive 16-channel output blocks.  K is walked in chunks of <= CK input channels of one concat source through two
+// LDS buffers (one when a workgroup only ever sees one chunk); per chunk:
+//   * the haloed input tile goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 16-byte groups of a 4-aligned
+//     tile row; dword DMA for the nearest-upsample read): out-of-range SRD offsets make the hardware write zeros, so
+//     padding, padded channels and the halo need no branch and no VGPR.  A second instantiation stages through
+//     registers instead (2x2 max-pool / ResNet input normalisation while loading);
+//   * the chunk's A fragments (one contiguous block of the packed stream) follow with global_load_lds_dwordx4;
+//   * after one barrier every wave sweeps taps x channel-quads reading A (lane-linear) and B (plane stride = 16 mod 32,
+//     conflict free) from LDS and issues MB*NB v_mfma_f32_16x16x4_f32 per k-step (or, MR_COMPUTE_BF16, one
+//     v_mfma_f32_16x16x16_bf16 per 16 channels with the B fragment rounded to bf16 on the way) - the sweep contains no
+//     global memory access at all, and the next chunk streams into the other buffer meanwhile.
+// The schedule (MB, NB, split_k, CK, WV) per layer shape is measured, not modelled (tools/tune_conv.py).  fp32 MFMA is an
+// exact fmaf chain, so results differ from the oneDNN CPU reference only by summation order.
 //
 // Epilogue: bias (eval-BatchNorm folded by the host), residual add, activation, scatter with an
 // output step/offset into a channel slice of the destination.  The four output parities of

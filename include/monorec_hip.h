@@ -173,12 +173,14 @@ int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_
  * 1 = SSIM distance (what mr_cost_volume_f32 does), 0 = absolute difference, 2 = 0.85 SSIM + 0.15 absolute difference,
  * 3 = absolute difference averaged over 3x3 (zero padded); and, when pixel_depths != NULL, per-pixel depth hypotheses
  * (batch, num_depths, H, W) instead of the num_depths shared ones - data_dict["cv_depths"], monorec_model.py:181-182
- * (`depths` may then be NULL). */
+ * (`depths` may then be NULL); and sfcv_mult_mask = 0 masks the single-frame volumes per depth plane by
+ * (any channel of the warped pixel != 0) | (warped pixel == keyframe pixel) instead of by the all-depth validity
+ * (monorec_model.py:252-253; needs num_depths >= num_frames), 1 = default. */
 int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
                             const float* kinv, const float* proj, const float* depths,
                             int32_t batch, int32_t num_depths, int32_t height, int32_t width,
                             float alpha, const float* channel_weights, int32_t use_ssim,
-                            const float* pixel_depths,
+                            const float* pixel_depths, int32_t sfcv_mult_mask,
                             float* cost_volume, float* const* sfcv, void* stream);
 
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the torchvision ResNet stem (monorec_model.py:124) */

@@ -77,7 +77,7 @@ ABI = {
     "mr_cost_volume_mode_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                                               ctypes.c_float, _c_float_p, ctypes.c_int32, ctypes.c_void_p,
+                                               ctypes.c_float, _c_float_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "mr_maxpool3x3s2_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_void_p]),

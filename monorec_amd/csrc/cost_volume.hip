@@ -123,8 +123,13 @@ __device__ __forceinline__ bool mask_hit(const Sample& sp, int H, int W) {
 
 // MODE = the photometric term of monorec_model.py:227-243 (use_ssim): 1 SSIM distance (default), 0 absolute difference,
 // 2 the 0.85 / 0.15 mix of both, 3 absolute difference averaged over 3x3 (zero padded, avg_pool2d).
-template <int TX, int TY, int MODE, bool PIXD>
+// OPT bit 0: per-pixel depth hypotheses (cv_depths).  OPT bit 1: sfcv_mult_mask=False (monorec_model.py:252-253) - the single-frame
+// volumes are masked per depth plane by (any channel of the warped pixel != 0) | (warped pixel == keyframe pixel) instead of by
+// the all-depth validity; that flag rides in the sign bit of every raw sad plane and the validity moves into the (not yet
+// written) cost-volume buffer, plane f of sample b, cleared with an atomic AND.
+template <int TX, int TY, int MODE, int OPT>
 __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
+    constexpr bool PIXD = OPT & 1, PFLAG = (OPT & 2) != 0;
     constexpr int NT = TX * TY;
     constexpr int HX = TX + 4, HY = TY + 4;   // warped / keyframe tile with 2 px halo
     constexpr int SX = TX + 2, SY = TY + 2;   // SSIM tile with 1 px halo
@@ -219,6 +224,12 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
     const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000);
     float* sad_out = a.sfcv[f] + (long long)b * D * HWp + opy * W + opx;
     bool hit_all = true;       // all depth planes of this chunk sample the border mask != 0
+    float kraw[3] = {0.f, 0.f, 0.f};
+    if (PFLAG && own_in) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) kraw[c] = kimg[c * HWp + opy * W + opx];
+    }
+    bool pflag[DPI];
 
     for (int d = d_lo; d < d_hi; d += DPI) {
         // ---- (a) warp own pixel + one halo position, DPI depth planes ---------------------------
@@ -231,9 +242,14 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                 const Sample sp = project(ro[0], ro[1], ro[2], PIXD ? pd[opy * W + opx] : depth, P, H, W);
                 hit_all = hit_all && mask_hit(sp, H, W);                   // monorec_model.py:218-219
                 const Taps tp = tap_offsets(sp, H, W);
+                bool any_nz = false, all_eq = true;
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    wru[(c * HY + oly + 2) * HX + olx + 2] = bilinear(img, c * HWp * 4, tp, sp) + 0.5f;
+                for (int c = 0; c < 3; ++c) {
+                    const float wv = bilinear(img, c * HWp * 4, tp, sp);
+                    if (PFLAG) { any_nz = any_nz || wv != 0.f; all_eq = all_eq && wv == kraw[c]; }
+                    wru[(c * HY + oly + 2) * HX + olx + 2] = wv + 0.5f;
+                }
+                pflag[u] = any_nz || all_eq;                                     // :253
             }
             if (has_halo) {
                 const Sample sp = project(rh[0], rh[1], rh[2], PIXD ? pd[hpy * W + hpx] : depth, P, H, W);
@@ -327,14 +343,18 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                         const float v = esu[(oly + dy) * SX + olx + dx];
                         s = (dy == 0 && dx == 0) ? v : s + v;
                     }
-                if (d + u == d_hi - 1 && !hit_all) s = -s;      // sad >= 0: the sign bit is free (-0.0 keeps it)
+                if (PFLAG) { if (!pflag[u]) s = -s; }           // per-plane flag in the sign bit
+                else if (d + u == d_hi - 1 && !hit_all) s = -s; // sad >= 0: the sign bit is free (-0.0 keeps it)
                 sad_out[(long long)(d + u) * HWp] = s;
             }
         }
     }
+    if (PFLAG && own_in && !hit_all)
+        atomicAnd((unsigned int*)a.cv + ((long long)b * D + f) * HWp + opy * W + opx, 0u);
 }
 
 // Per-pixel frame fusion (monorec_model.py:251-269) over the raw sad values kernel A left in the sfcv buffers.
+template <bool PFLAG>
 __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
     const int HWp = a.H * a.W;
     const int D = a.D;
@@ -351,10 +371,11 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
             if (f < a.F) {
                 const float* sf = a.sfcv[f] + (long long)b * D * HWp + p;
                 bool valid = border;
+                if (PFLAG) valid = valid && ((const unsigned int*)a.cv)[((long long)b * D + f) * HWp + p] != 0u;
                 float smin = INFINITY;
                 for (int d = 0; d < D; ++d) {
                     const float v = sf[(long long)d * HWp];
-                    valid = valid && !(__float_as_uint(v) & 0x80000000u);
+                    if (!PFLAG) valid = valid && !(__float_as_uint(v) & 0x80000000u);
                     smin = fminf(smin, fabsf(v));
                 }
                 float se = 0.f;
@@ -378,8 +399,10 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
             for (int f = 0; f < MR_MAX_FRAMES; ++f) {
                 if (f < a.F) {
                     float* sf = a.sfcv[f] + (long long)b * D * HWp + p + (long long)d * HWp;
-                    const float s = fabsf(*sf);
-                    *sf = (1.0f - s * 2.0f) * vmask[f];                          // :251
+                    const float raw = *sf;
+                    const float s = fabsf(raw);
+                    const float keep = PFLAG ? ((__float_as_uint(raw) & 0x80000000u) ? 0.f : 1.f) : vmask[f];
+                    *sf = (1.0f - s * 2.0f) * keep;                              // :251 / :253
                     const float t = s * wgt[f];                                  // :262
                     num = f == 0 ? t : num + t;
                 }
@@ -391,8 +414,23 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
     }
 }
 
+template <int TX, int TY, int MODE, int OPT>
+void launch_sad(const CvArgs& k, dim3 grid, hipStream_t stream) {
+    hipLaunchKernelGGL((cv_sad_kernel<TX, TY, MODE, OPT>), grid, dim3(TX * TY), 0, stream, k);
+}
+
+template <int TX, int TY, int MODE>
+void launch_sad_opt(const CvArgs& k, int opt, dim3 grid, hipStream_t stream) {
+    switch (opt) {
+        case 1: launch_sad<TX, TY, MODE, 1>(k, grid, stream); break;
+        case 2: launch_sad<TX, TY, MODE, 2>(k, grid, stream); break;
+        case 3: launch_sad<TX, TY, MODE, 3>(k, grid, stream); break;
+        default: launch_sad<TX, TY, MODE, 0>(k, grid, stream); break;
+    }
+}
+
 template <int TX, int TY>
-int launch_cv(const CvArgs& a, int mode, hipStream_t stream) {
+int launch_cv(const CvArgs& a, int mode, bool plane_flags, hipStream_t stream) {
     CvArgs k = a;
     k.tiles_x = (a.W + TX - 1) / TX;
     const int tiles = k.tiles_x * ((a.H + TY - 1) / TY);
@@ -401,27 +439,24 @@ int launch_cv(const CvArgs& a, int mode, hipStream_t stream) {
     while ((long long)tiles * a.F * a.B * nchunk < 1024 && (a.D / (nchunk * 2)) >= 4 && (a.D % (nchunk * 4)) == 0) nchunk *= 2;
     k.nchunk = nchunk;
     k.dchunk = a.D / nchunk;
-    const dim3 grid(tiles, a.F * nchunk, a.B), block(TX * TY);
-    if (a.pix_depths) {
-        switch (mode) {
-            case 0: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 0, true>), grid, block, 0, stream, k); break;
-            case 2: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 2, true>), grid, block, 0, stream, k); break;
-            case 3: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 3, true>), grid, block, 0, stream, k); break;
-            default: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 1, true>), grid, block, 0, stream, k); break;
-        }
-    } else {
-        switch (mode) {
-            case 0: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 0, false>), grid, block, 0, stream, k); break;
-            case 2: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 2, false>), grid, block, 0, stream, k); break;
-            case 3: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 3, false>), grid, block, 0, stream, k); break;
-            default: hipLaunchKernelGGL((cv_sad_kernel<TX, TY, 1, false>), grid, block, 0, stream, k); break;
-        }
+    const dim3 grid(tiles, a.F * nchunk, a.B);
+    const int opt = (a.pix_depths ? 1 : 0) | (plane_flags ? 2 : 0);
+    if (plane_flags) {     // validity words (plane f of every sample of the cost-volume buffer) start as all ones
+        hipError_t e = hipMemsetAsync(a.cv, 0xff, (size_t)a.B * a.D * a.H * a.W * sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    switch (mode) {
+        case 0: launch_sad_opt<TX, TY, 0>(k, opt, grid, stream); break;
+        case 2: launch_sad_opt<TX, TY, 2>(k, opt, grid, stream); break;
+        case 3: launch_sad_opt<TX, TY, 3>(k, opt, grid, stream); break;
+        default: launch_sad_opt<TX, TY, 1>(k, opt, grid, stream); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long long total = (long long)a.B * a.H * a.W;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(cv_fuse_kernel, dim3(blocks), dim3(256), 0, stream, k);
+    if (plane_flags) hipLaunchKernelGGL(cv_fuse_kernel<true>, dim3(blocks), dim3(256), 0, stream, k);
+    else hipLaunchKernelGGL(cv_fuse_kernel<false>, dim3(blocks), dim3(256), 0, stream, k);
     return (int)hipGetLastError();
 }
 
@@ -431,9 +466,10 @@ extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const
                                        const float* kinv, const float* proj, const float* depths,
                                        int32_t batch, int32_t num_depths, int32_t height, int32_t width,
                                        float alpha, const float* channel_weights, int32_t use_ssim,
-                                       const float* pixel_depths,
+                                       const float* pixel_depths, int32_t sfcv_mult_mask,
                                        float* cost_volume, float* const* sfcv, void* stream) {
     if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
+    if (!sfcv_mult_mask && num_depths < num_frames) return MR_ERR_UNSUPPORTED;      // validity words live in planes 0..F-1
     if (!keyframe || !frames || !kinv || !proj || (!depths && !pixel_depths) || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
     if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
@@ -451,7 +487,7 @@ extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const
     a.alpha = alpha;
     for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / 9.0f;
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
-    return launch_cv<32, 16>(a, use_ssim, (hipStream_t)stream);
+    return launch_cv<32, 16>(a, use_ssim, !sfcv_mult_mask, (hipStream_t)stream);
 }
 
 extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
@@ -460,5 +496,5 @@ extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* fra
                                   float alpha, const float* channel_weights,
                                   float* cost_volume, float* const* sfcv, void* stream) {
     return mr_cost_volume_mode_f32(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
-                                   channel_weights, 1, nullptr, cost_volume, sfcv, stream);
+                                   channel_weights, 1, nullptr, 1, cost_volume, sfcv, stream);
 }

@@ -195,7 +195,7 @@ class Plan:
     """Buffers + launch list for one input shape. `state` is a CPU state dict with the reference keys."""
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
-                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True):
+                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -208,6 +208,7 @@ class Plan:
         self.cw = (ctypes.c_float * 3)(*[float(torch.tensor(c, dtype=torch.float32)) for c in channel_weights])
         self.schedule_override = schedule_override or {}
         self.cv_mode = {False: 0, True: 1}.get(use_ssim, use_ssim) if not isinstance(use_ssim, bool) else int(use_ssim)
+        self.sfcv_mult_mask = bool(sfcv_mult_mask)
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
@@ -433,6 +434,7 @@ class Plan:
             pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
             _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                    depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
+                                                   1 if self.sfcv_mult_mask else 0,
                                                    cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
         self.add(st, "cost_volume", run_cv)
 

@@ -215,7 +215,7 @@ class MonoRecModel(nn.Module):
         self.freeze_module = freeze_module
         self.freeze_resnet = freeze_resnet
         unsupported = dict(pretrain_mode=self.pretrain_mode != 0, use_mono=not (use_mono or use_stereo),
-                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3), sfcv_mult_mask=not sfcv_mult_mask,
+                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3),
                            simple_mask=bool(simple_mask), mask_use_cv=not mask_use_cv, mask_use_feats=not mask_use_feats,
                            cv_patch_size=cv_patch_size != 3, no_cv=bool(no_cv), augmentation=augmentation not in (None, "none"))
         bad = [k for k, v in unsupported.items() if v]
@@ -291,7 +291,7 @@ class MonoRecModel(nn.Module):
                 self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
             plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
-                        use_ssim=self.use_ssim)
+                        use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()

@@ -234,6 +234,31 @@ def main():
     report["cases"]["cv_pixel_depths"] = {"config": "data_dict['cv_depths'] per pixel", "oracle_vs_reference_maxabs": diffs}
     print("cv_pixel_depths ok; oracle == reference on", len(diffs), "tensors")
 
+    # ---- sfcv_mult_mask=False (row f-4, monorec_model.py:252-253): cost volume only --------------------------------------
+    batch = synth.make_batch(2, 48, 80, 2, seed=37, hard_pose=False)
+    ref = Ref(cv_depth_steps=8, sfcv_mult_mask=False).eval()
+    dd = synth.clone_batch(batch)
+    dd["inv_depth_min"], dd["inv_depth_max"] = torch.tensor([0.33]), torch.tensor([0.0025])
+    dd["cv_depth_steps"] = torch.tensor([8], dtype=torch.int32)
+    with torch.no_grad():
+        dd = ref.cv_module(dd)
+    cv, sf = orc.cost_volume(batch, steps=8, sfcv_mult_mask=False)
+    items_ref = {"cost_volume": dd["cost_volume"], **{f"sfcv{i}": t for i, t in enumerate(dd["single_frame_cvs"])}}
+    items_orc = {"cost_volume": cv, **{f"sfcv{i}": t for i, t in enumerate(sf)}}
+    store, diffs = {}, {}
+    for k in items_ref:
+        diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+        assert diffs[k] == 0.0, f"oracle deviates from the reference on cv_no_mult_mask/{k}: {diffs[k]}"
+        for kk, vv in sample_summary(items_ref[k]).items():
+            store[f"{k}.{kk}"] = vv
+        store[f"{k}.full"] = items_ref[k].numpy()
+    store["meta"] = np.array([2, 48, 80, 2, 8, 37, 0, 0], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, "cv_no_mult_mask.npz"), **store)
+    report["cases"]["cv_no_mult_mask"] = {"config": "sfcv_mult_mask=False", "oracle_vs_reference_maxabs": diffs}
+    masked_default = orc.cost_volume(batch, steps=8)[1]
+    print("cv_no_mult_mask ok; oracle == reference on", len(diffs), "tensors; entries differing from the default masking:",
+          int((masked_default[0] != sf[0]).sum()))
+
     # ---- depth_large_model (row f-4, monorec_model.py:482-483): wider DepthModule stages --------------------------------
     batch = synth.make_batch(1, 64, 96, 2, seed=23)
     ref = Ref(cv_depth_steps=8, depth_large_model=True).eval()

@@ -92,7 +92,8 @@ def ssim_distance(x, y):
 
 
 def cost_volume(batch, inv_depth_min=0.33, inv_depth_max=0.0025, steps=32, patch_size=3,
-                channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, stages=None, use_ssim=True, cv_depths=None):
+                channel_weights=(5 / 32, 16 / 32, 11 / 32), alpha=10, stages=None, use_ssim=True, cv_depths=None,
+                sfcv_mult_mask=True):
     """CostVolumeModule.forward (monorec_model.py:150-280), use_mono, sfcv_mult_mask=True; use_ssim selects the photometric
     term (:227-243): True SSIM distance, False absolute difference, 2 the 0.85/0.15 mix, 3 3x3-averaged absolute difference.
 
@@ -145,7 +146,10 @@ def cost_volume(batch, inv_depth_min=0.33, inv_depth_max=0.0025, steps=32, patch
             diff = F.avg_pool2d(torch.abs(warped - keyframe[n]).view(nb, c, h, w), kernel_size=3, stride=1, padding=1)
         diff = diff.view(steps, nf, c, h, w).permute(1, 2, 0, 3, 4)                  # :233,246
         sad = F.conv3d(diff, sad_kernel, padding=(0, patch_size // 2, patch_size // 2)).squeeze(1)   # :247
-        sfcv = (1 - sad * 2) * valid                                                 # :251
+        if sfcv_mult_mask:
+            sfcv = (1 - sad * 2) * valid                                             # :251
+        else:                                                                        # :253
+            sfcv = (1 - sad * 2) * (torch.any(warped != 0, dim=2) | torch.all(warped == keyframe[n], dim=2)).permute(1, 0, 2, 3)
         for f in range(nf):
             sfcvs[f].append(sfcv[f])
         e = torch.exp(-alpha * torch.pow(sad - torch.min(sad, dim=1, keepdim=True)[0], 2))     # :257
@@ -308,11 +312,12 @@ def depth_module(sd, cost_volume_masked, keyframe, feats, prefix="depth_module")
 # ----------------------------------------------------------------------------------------
 # MonoRecModel.forward (monorec_model.py:672-729)
 # ----------------------------------------------------------------------------------------
-def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True, cv_depths=None):
+def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True, cv_depths=None,
+            sfcv_mult_mask=True):
     """Returns the reference's output dict entries for eval / pretrain_mode=0."""
     with torch.no_grad():
         cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages,
-                                use_ssim=use_ssim, cv_depths=cv_depths)
+                                use_ssim=use_ssim, cv_depths=cv_depths, sfcv_mult_mask=sfcv_mult_mask)
         feats = resnet_features(sd, batch["keyframe"] + .5)                         # :691
         cv_mask = mask_module(sd, sfcvs, feats)                                     # :694
         cv_masked = (1 - cv_mask) * cv                                              # :713

@@ -178,7 +178,7 @@ def test_public_attributes_are_json_serialisable():
 
 
 @pytest.mark.parametrize("kw", [dict(use_mono=False), dict(pretrain_mode=1), dict(simple_mask=True), dict(use_ssim=4),
-                                dict(sfcv_mult_mask=False), dict(no_cv=True), dict(cv_patch_size=5)])
+                                dict(mask_use_cv=False), dict(no_cv=True), dict(cv_patch_size=5)])
 def test_unsupported_options_raise(kw):
     with pytest.raises(NotImplementedError):
         MonoRecModel(**kw)

@@ -233,7 +233,7 @@ def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
         assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
 
 
-def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None):
+def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True):
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)
     b, _, h, w = kf.shape
@@ -247,13 +247,14 @@ def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None):
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
-    if use_ssim == 1 and cv_depths is None:
+    if use_ssim == 1 and cv_depths is None and mult_mask:
         _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
                                           b, d, h, w, 10.0, cw, cv.data_ptr(), sp, _stream()), "mr_cost_volume_f32")
     else:
         _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
                                                b, d, h, w, 10.0, cw, int(use_ssim),
-                                               None if cv_depths is None else cv_depths.data_ptr(), cv.data_ptr(), sp, _stream()),
+                                               None if cv_depths is None else cv_depths.data_ptr(), 1 if mult_mask else 0,
+                                               cv.data_ptr(), sp, _stream()),
                    "mr_cost_volume_mode_f32")
     torch.cuda.synchronize()
     return cv.cpu(), [s.cpu() for s in sf]
@@ -328,6 +329,18 @@ def test_cost_volume_per_pixel_depths(hip_lib):
     assert ((cv - ocv).abs() > 1e-4).float().mean().item() <= 2e-4
     ucv, _ = _hip_cost_volume(batch, g.depths)
     assert (ucv - cv).abs().max().item() > 1e-2           # really different from the shared ladder
+
+
+def test_cost_volume_without_mult_mask(hip_lib):
+    """sfcv_mult_mask=False (monorec_model.py:252-253): single-frame volumes masked per depth plane by the warped pixel itself."""
+    g = Golden("cv_no_mult_mask")
+    batch = g.make_inputs()
+    cv, sf = _hip_cost_volume(batch, g.depths, mult_mask=False)
+    for f in range(g.frames):
+        g.compare(f"sfcv{f}", sf[f], atol=2e-6, max_outlier_frac=2e-4)
+    g.compare("cost_volume", cv, atol=1e-5, max_outlier_frac=1e-4)          # the fused volume does not depend on the option
+    dcv, dsf = _hip_cost_volume(batch, g.depths)
+    assert torch.equal(dcv, cv) and not torch.equal(dsf[0], sf[0])
 
 
 def test_cost_volume_properties_at_full_size(hip_lib):

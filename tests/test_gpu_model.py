@@ -220,6 +220,19 @@ def test_cv_depths_through_the_model(hip_lib):
     assert (plain.cpu() - ref_plain["result"]).abs().max().item() <= RESULT_ATOL
 
 
+def test_sfcv_without_mult_mask_through_the_model(hip_lib):
+    """sfcv_mult_mask=False (monorec_model.py:252-253) reaches the kernel; the MaskModule consumes the differently masked volumes."""
+    batch = synth.make_batch(1, 64, 96, 2, seed=37, hard_pose=False)
+    m = MonoRecModel(cv_depth_steps=8, sfcv_mult_mask=False, hip_in_flight=1)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(_to_dev(batch))
+    torch.cuda.synchronize()
+    _check_against(out, orc.forward(sd, batch, cv_depth_steps=8, sfcv_mult_mask=False), "sfcv_mult_mask=False")
+
+
 def test_depth_large_model(hip_lib):
     """depth_large_model=True (monorec_model.py:482-483): the plan takes the DepthModule widths from the weights."""
     g = Golden("small_large_depth")

@@ -110,3 +110,11 @@ def test_oracle_per_pixel_depths_match_reference_fixture():
     g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
     for i, t in enumerate(sf):
         g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
+
+
+def test_oracle_without_mult_mask_matches_reference_fixture():
+    g = Golden("cv_no_mult_mask")
+    cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths, sfcv_mult_mask=False)
+    g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(sf):
+        g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)

@@ -195,7 +195,8 @@ class Plan:
     """Buffers + launch list for one input shape. `state` is a CPU state dict with the reference keys."""
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
-                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True):
+                 alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
+                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -209,6 +210,8 @@ class Plan:
         self.schedule_override = schedule_override or {}
         self.cv_mode = {False: 0, True: 1}.get(use_ssim, use_ssim) if not isinstance(use_ssim, bool) else int(use_ssim)
         self.sfcv_mult_mask = bool(sfcv_mult_mask)
+        self.pretrain_mode, self.no_cv = int(pretrain_mode), bool(no_cv)                  # monorec_model.py:680-727 (eval branches)
+        self.mask_use_cv, self.mask_use_feats = bool(mask_use_cv), bool(mask_use_feats)   # :352-355
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
@@ -436,18 +439,28 @@ class Plan:
                                                    depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                    1 if self.sfcv_mult_mask else 0,
                                                    cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
-        self.add(st, "cost_volume", run_cv)
+        if self.no_cv:                     # :682-686: zero volumes, never written (the in-place mask multiply keeps 0)
+            sfcv.zero_()
+            cv.zero_()
+        else:
+            self.add(st, "cost_volume", run_cv)
+        with_mask = self.pretrain_mode in (0, 2)
+        with_depth = self.pretrain_mode != 2
 
         # ---------------- MaskModule (monorec_model.py:345-385), frames batched as F*B ----------------
         am = "att_module"
         enc_ch = (D, 48, 64, 96, 96)
+        FM = F                             # frames the mask encoder runs on
         x = sfcv.view(F * B, D, H, W)
+        if not self.mask_use_cv:           # :352-353 `sfcv * 0`: every frame is the same zero input, so one pass stands for all
+            x = self.alloc("mask.zero_input", B, D, H, W).zero_()
+            FM = 1
         cvf = []
-        for i in range(5):
+        for i in range(5 if with_mask else 0):
             hi, wi = H >> i, W >> i
             i0, i1 = (0, 1) if i == 0 else (1, 2)       # index 0 of stages 1-4 is the MaxPool
-            a = self.alloc(f"mask.enc{i}.a", F * B, enc_ch[i], hi, wi)
-            xo = self.alloc(f"mask.enc{i}.x", F * B, enc_ch[i], hi, wi)
+            a = self.alloc(f"mask.enc{i}.a", FM * B, enc_ch[i], hi, wi)
+            xo = self.alloc(f"mask.enc{i}.x", FM * B, enc_ch[i], hi, wi)
             self.same_conv(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a)
             self.same_conv(st, f"mask.enc{i}.1", [a], f"{am}.enc.{i}.{i1}.conv.weight", f"{am}.enc.{i}.{i1}.conv.bias", xo)
             m = self.alloc(f"mask.cvf{i}", B, enc_ch[i], hi, wi)
@@ -455,41 +468,50 @@ class Plan:
             if i < 4:
                 # nn.MaxPool2d(2) of the next stage (its own HBM-bound pass: the conv then stages by LDS-DMA) and the
                 # maximum over the frames, both from one read of this stage's output
-                xp = self.alloc(f"mask.enc{i + 1}.pool", F * B, enc_ch[i], hi // 2, wi // 2)
+                xp = self.alloc(f"mask.enc{i + 1}.pool", FM * B, enc_ch[i], hi // 2, wi // 2)
 
                 def run_pool_max(stream, src=xo, dst=xp, mx=m, planes=B * enc_ch[i], hh_=hi, ww_=wi):
-                    _lib.check(lib.mr_pool2x2_framemax_f32(src.data_ptr(), dst.data_ptr(), mx.data_ptr(), F, planes, hh_, ww_,
+                    _lib.check(lib.mr_pool2x2_framemax_f32(src.data_ptr(), dst.data_ptr(), mx.data_ptr(), FM, planes, hh_, ww_,
                                                            stream), "mr_pool2x2_framemax_f32")
                 self.add(st, f"mask.poolmax{i}", run_pool_max)
                 x = xp
             else:
                 def run_max(stream, src=xo, dst=m, count=B * enc_ch[i] * hi * wi):
-                    _lib.check(lib.mr_max_over_frames_f32(src.data_ptr(), dst.data_ptr(), F, count, stream),
+                    _lib.check(lib.mr_max_over_frames_f32(src.data_ptr(), dst.data_ptr(), FM, count, stream),
                                "mr_max_over_frames_f32")
                 self.add(st, f"mask.max{i}", run_max)
         st = "main"
-        x_srcs = [cvf[4], feats[3]]                                                  # :372
-        for i in range(4):
+        mfeats = feats if self.mask_use_feats else [self.alloc(f"mask.zero_feat{i}", *feats[i].shape).zero_() for i in range(4)]   # :354-355
+        x_srcs = [cvf[4], mfeats[3]] if with_mask else None                          # :372
+        for i in range(4 if with_mask else 0):
             hi, wi = H >> (3 - i), W >> (3 - i)
             up_ch = sd[f"{am}.dec.{i}.0.conv.weight"].shape[0]
             dec_ch = {i: sd[f"{am}.dec.{i}.1.conv.weight"].shape[0]}
             u = self.alloc(f"mask.dec{i}.up", B, up_ch, hi, wi)
             self.same_conv(st, f"mask.dec{i}.0", x_srcs, f"{am}.dec.{i}.0.conv.weight", f"{am}.dec.{i}.0.conv.bias", u,
                            act=ACT_NONE, in_mode=IN_UPSAMPLE2)                        # Upconv, layers.py:353-356
-            cat = [cvf[3 - i], u] if i == 3 else [cvf[3 - i], feats[2 - i], u]       # :374-380
+            cat = [cvf[3 - i], u] if i == 3 else [cvf[3 - i], mfeats[2 - i], u]      # :374-380
             a = self.alloc(f"mask.dec{i}.a", B, dec_ch[i], hi, wi)
             xo = self.alloc(f"mask.dec{i}.x", B, dec_ch[i], hi, wi)
             self.same_conv(st, f"mask.dec{i}.1", cat, f"{am}.dec.{i}.1.conv.weight", f"{am}.dec.{i}.1.conv.bias", a)
             self.same_conv(st, f"mask.dec{i}.2", [a], f"{am}.dec.{i}.2.conv.weight", f"{am}.dec.{i}.2.conv.bias", xo)
             x_srcs = [xo]
         cv_mask = self.alloc("cv_mask", B, 1, H, W)
-        self.same_conv(st, "mask.classifier", x_srcs, f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
-                       act=ACT_SIGMOID)
+        if with_mask:
+            self.same_conv(st, "mask.classifier", x_srcs, f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
+                           act=ACT_SIGMOID)
+        else:
+            cv_mask.zero_()                # pretrain_mode 1, eval (:708); pretrain_mode 3: the model copies data_dict["mvobj_mask"] in (:711)
+        self.feats = feats
+        self.preds = None
+        if not with_depth:                 # pretrain_mode 2 (:693, :712, :723-724): mask only
+            return
 
         def run_mask(stream):                                                        # :713 (in place)
             _lib.check(lib.mr_apply_mask_f32(cv.data_ptr(), cv_mask.data_ptr(), cv.data_ptr(), B, D, H * W, stream),
                        "mr_apply_mask_f32")
-        self.add(st, "apply_mask", run_mask)
+        if self.pretrain_mode != 1:        # (1 - 0) * cv == cv exactly
+            self.add(st, "apply_mask", run_mask)
 
         # ---------------- DepthModule (monorec_model.py:526-557) ----------------
         dm = "depth_module"
@@ -545,7 +567,6 @@ class Plan:
         x4 = self.alloc("depth.dec4", B, dch[5], H, W)
         self.same_conv(st, "depth.dec4.2", [x4a], f"{dm}.dec.4.2.weight", f"{dm}.dec.4.2.bias", x4)
         head(3, x4, 0)
-        self.feats = feats
         self.preds = preds
 
     # ------------------------------------------------------------------ execution

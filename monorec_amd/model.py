@@ -214,10 +214,11 @@ class MonoRecModel(nn.Module):
         self.depth_cp_loc = depth_cp_loc
         self.freeze_module = freeze_module
         self.freeze_resnet = freeze_resnet
-        unsupported = dict(pretrain_mode=self.pretrain_mode != 0, use_mono=not (use_mono or use_stereo),
-                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3),
-                           simple_mask=bool(simple_mask), mask_use_cv=not mask_use_cv, mask_use_feats=not mask_use_feats,
-                           cv_patch_size=cv_patch_size != 3, no_cv=bool(no_cv), augmentation=augmentation not in (None, "none"))
+        # simple_mask: SimpleMaskModule.forward reads data_dict["predicted_inverse_depths"] before the DepthModule has run
+        # (monorec_model.py:449) - it only works inside the training-time refinement passes, which are out of scope here
+        unsupported = dict(pretrain_mode=self.pretrain_mode not in (0, 1, 2, 3), use_mono=not (use_mono or use_stereo or no_cv),
+                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3), simple_mask=bool(simple_mask),
+                           cv_patch_size=cv_patch_size != 3, augmentation=augmentation not in (None, "none"))
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(
@@ -239,10 +240,12 @@ class MonoRecModel(nn.Module):
                 p.requires_grad_(False)
         self.cv_module = CostVolumeModule(use_mono=use_mono, use_stereo=use_stereo, use_ssim=use_ssim,
                                           sfcv_mult_mask=self.sfcv_mult_mask, patch_size=cv_patch_size)
-        self.att_module = MaskModule(self.cv_depth_steps, self._feature_extractor.num_ch_enc,
-                                     use_cv=mask_use_cv, use_features=mask_use_feats)
-        self.depth_module = DepthModule(self.cv_depth_steps, feature_channels=self._feature_extractor.num_ch_enc,
-                                        large_model=self.depth_large_model)
+        if self.pretrain_mode not in (1, 3):                                       # :622-626
+            self.att_module = MaskModule(self.cv_depth_steps, self._feature_extractor.num_ch_enc,
+                                         use_cv=mask_use_cv, use_features=mask_use_feats)
+        if self.pretrain_mode != 2:                                                # :627-628
+            self.depth_module = DepthModule(self.cv_depth_steps, feature_channels=self._feature_extractor.num_ch_enc,
+                                            large_model=self.depth_large_model)
         self.augmenter = None
 
         def load(cp_list, sub=None, prefix=None):
@@ -257,8 +260,10 @@ class MonoRecModel(nn.Module):
                     sub.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix)}, strict=False)
 
         load(self.checkpoint_location)                                             # monorec_model.py:630-637
-        load(self.mask_cp_loc, self.att_module, "att_module")                      # :639-647
-        load(self.depth_cp_loc, self.depth_module, "depth_module")                 # :649-657
+        if self.mask_cp_loc is not None:
+            load(self.mask_cp_loc, self.att_module, "att_module")                  # :639-647
+        if self.depth_cp_loc is not None:
+            load(self.depth_cp_loc, self.depth_module, "depth_module")             # :649-657
         for module_name in self.freeze_module:                                     # :659-663
             module = getattr(self, module_name + "_module")
             module.eval()
@@ -291,7 +296,8 @@ class MonoRecModel(nn.Module):
                 self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
             plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
-                        use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask)
+                        use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
+                        no_cv=self.no_cv, mask_use_cv=self.mask_use_cv, mask_use_feats=self.mask_use_feats)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
@@ -319,11 +325,13 @@ class MonoRecModel(nn.Module):
         keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
         kf_intrinsics, kf_pose = data_dict["keyframe_intrinsics"], data_dict["keyframe_pose"]
         frames, poses, intrinsics = [], [], []
-        if self.use_mono:                                     # monorec_model.py:160-163
+        if self.no_cv:                                        # :682-686: one zero volume per entry of data_dict["poses"]
+            frames, intrinsics, poses = list(data_dict["frames"]), list(data_dict["intrinsics"]), list(data_dict["poses"])
+        elif self.use_mono:                                   # monorec_model.py:160-163
             frames += list(data_dict["frames"])
             intrinsics += list(data_dict["intrinsics"])
             poses += list(data_dict["poses"])
-        if self.use_stereo:                                   # :164-167: the stereo frame is one more source view
+        if self.use_stereo and not self.no_cv:                # :164-167: the stereo frame is one more source view
             frames += [data_dict["stereoframe"]]
             intrinsics += [data_dict["stereoframe_intrinsics"]]
             poses += [data_dict["stereoframe_pose"]]
@@ -394,6 +402,8 @@ class MonoRecModel(nn.Module):
                     plan.alloc("pix_depths", b, self.cv_depth_steps, h, w)
                 plan.buf["pix_depths"].copy_(cv_depths)
             # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
+            if self.pretrain_mode == 3:                       # :711 cv_mask = data_dict["mvobj_mask"].clone()
+                plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
             self._run_stage(key, plan, "cv", main)
             main.wait_event(enc_done)
             self._run_stage(key, plan, "main", main)
@@ -406,9 +416,12 @@ class MonoRecModel(nn.Module):
         data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
         data_dict["image_features"] = list(plan.feats)
         data_dict["cv_mask"] = plan.buf["cv_mask"]
-        data_dict["predicted_inverse_depths"] = list(plan.preds)
-        data_dict["result"] = data_dict["predicted_inverse_depths"][0]
-        data_dict["mask"] = data_dict["cv_mask"]
+        if self.pretrain_mode == 2:                           # :723-724: mask only
+            data_dict["result"] = data_dict["cv_mask"]
+        else:
+            data_dict["predicted_inverse_depths"] = list(plan.preds)
+            data_dict["result"] = data_dict["predicted_inverse_depths"][0]
+            data_dict["mask"] = data_dict["cv_mask"]
         return _Pending(data_dict, done, device)
 
     def _run_stage(self, key, plan, stage, stream):

@@ -14,6 +14,7 @@ order) that cost_volume.hip relies on, and the reference's state-dict key/shape 
 """
 import json
 import os
+import warnings
 import sys
 
 import numpy as np
@@ -258,6 +259,46 @@ def main():
     masked_default = orc.cost_volume(batch, steps=8)[1]
     print("cv_no_mult_mask ok; oracle == reference on", len(diffs), "tensors; entries differing from the default masking:",
           int((masked_default[0] != sf[0]).sum()))
+
+    # ---- model-level options of row f-4: pretrain_mode 1/2/3 in eval mode (monorec_model.py:693-727; the validation passes of
+    #      configs/train/monorec/monorec_depth.json and monorec_mask.json run exactly this), no_cv (:680-686),
+    #      mask_use_cv / mask_use_feats = False (:352-355).  One batch, one fixture file, keys "<case>.<tensor>".
+    batch = synth.make_batch(1, 64, 96, 2, seed=41)
+    g = torch.Generator().manual_seed(41)
+    mvobj = (torch.rand(1, 1, 64, 96, generator=g) < 0.2).float()
+    option_cases = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
+                    "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False)}
+    store = {}
+    for case, kw in option_cases.items():
+        ref = Ref(cv_depth_steps=8, **kw).eval()
+        sd = synth.seeded_state_dict(ref.state_dict(), seed=0)
+        ref.load_state_dict(sd, strict=True)
+        dd = synth.clone_batch(batch)
+        dd["mvobj_mask"] = mvobj.clone()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")            # no_cv: torch.tensor(tensor) copy-construct warning in the reference
+            with torch.no_grad():
+                out_ref = ref(dd)
+        ob = dict(batch)
+        ob["mvobj_mask"] = mvobj
+        out_orc = orc.forward(sd, ob, cv_depth_steps=8, **kw)
+        assert ("predicted_inverse_depths" in out_ref) == ("predicted_inverse_depths" in out_orc), case
+        assert ("mask" in out_ref) == ("mask" in out_orc), case
+        keys = ["result", "cv_mask", "cost_volume"] + [f"sfcv{i}" for i in range(len(out_ref["single_frame_cvs"]))]
+        get = lambda o, k: o["single_frame_cvs"][int(k[4:])] if k.startswith("sfcv") else o[k]
+        diffs = {}
+        for k in keys:
+            diffs[k] = float((get(out_ref, k) - get(out_orc, k)).abs().max())
+            assert diffs[k] == 0.0, f"oracle deviates from the reference on small_options/{case}/{k}: {diffs[k]}"
+            for kk, vv in sample_summary(get(out_ref, k)).items():
+                store[f"{case}.{k}.{kk}"] = vv
+        for k in ("result", "cv_mask"):
+            store[f"{case}.{k}.full"] = get(out_ref, k).numpy()
+        report["cases"][f"small_options.{case}"] = {"config": str(kw), "oracle_vs_reference_maxabs": diffs}
+    store["input.mvobj_mask"] = mvobj.numpy()
+    store["meta"] = np.array([1, 64, 96, 2, 8, 41, 0, 1], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, "small_options.npz"), **store)
+    print("small_options ok; oracle == reference for", ", ".join(option_cases))
 
     # ---- depth_large_model (row f-4, monorec_model.py:482-483): wider DepthModule stages --------------------------------
     batch = synth.make_batch(1, 64, 96, 2, seed=23)

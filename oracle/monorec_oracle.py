@@ -247,8 +247,12 @@ def resnet_features(sd, image, prefix="_feature_extractor.encoder"):
 # ----------------------------------------------------------------------------------------
 # MaskModule (monorec_model.py:345-385)
 # ----------------------------------------------------------------------------------------
-def mask_module(sd, sfcvs, feats, prefix="att_module"):
+def mask_module(sd, sfcvs, feats, prefix="att_module", use_cv=True, use_features=True):
     cv_feats = []
+    if not use_cv:
+        sfcvs = [c * 0 for c in sfcvs]                                              # :352-353
+    if not use_features:
+        feats = [f * 0 for f in feats]                                              # :354-355
     for cv in sfcvs:                                                                # :357
         x = cv
         for i in range(5):
@@ -313,27 +317,34 @@ def depth_module(sd, cost_volume_masked, keyframe, feats, prefix="depth_module")
 # MonoRecModel.forward (monorec_model.py:672-729)
 # ----------------------------------------------------------------------------------------
 def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True, cv_depths=None,
-            sfcv_mult_mask=True):
-    """Returns the reference's output dict entries for eval / pretrain_mode=0."""
+            sfcv_mult_mask=True, pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True):
+    """Returns the reference's output dict entries for eval mode (monorec_model.py:672-729); `pretrain_mode` as in :693-727."""
     with torch.no_grad():
-        cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages,
-                                use_ssim=use_ssim, cv_depths=cv_depths, sfcv_mult_mask=sfcv_mult_mask)
-        feats = resnet_features(sd, batch["keyframe"] + .5)                         # :691
-        cv_mask = mask_module(sd, sfcvs, feats)                                     # :694
+        kf = batch["keyframe"]
+        if not no_cv:                                                               # :680-686
+            cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages,
+                                    use_ssim=use_ssim, cv_depths=cv_depths, sfcv_mult_mask=sfcv_mult_mask)
+        else:
+            cv = kf.new_zeros(kf.shape[0], cv_depth_steps, kf.shape[2], kf.shape[3])
+            sfcvs = [cv.clone() for _ in batch["poses"]]
+        feats = resnet_features(sd, kf + .5)                                        # :691
+        if pretrain_mode in (0, 2):
+            cv_mask = mask_module(sd, sfcvs, feats, use_cv=mask_use_cv, use_features=mask_use_feats)   # :694
+        elif pretrain_mode == 1:
+            cv_mask = kf.new_zeros(kf.shape[0], 1, kf.shape[2], kf.shape[3])        # :708 (eval branch)
+        else:
+            cv_mask = batch["mvobj_mask"].clone()                                   # :711
+        out = {"cost_volume_unmasked": cv, "single_frame_cvs": sfcvs, "image_features": feats, "cv_mask": cv_mask}
+        if pretrain_mode == 2:                                                      # :723-724
+            out["cost_volume"] = cv
+            out["result"] = cv_mask
+            return out
         cv_masked = (1 - cv_mask) * cv                                              # :713
-        preds = depth_module(sd, cv_masked, batch["keyframe"], feats)               # :715
+        preds = depth_module(sd, cv_masked, kf, feats)                              # :715
         lo, hi = inv_depth_min_max[1], inv_depth_min_max[0]
         preds = [(1 - p) * lo + p * hi for p in preds]                              # :717-718
-    return {
-        "cost_volume_unmasked": cv,
-        "cost_volume": cv_masked,
-        "single_frame_cvs": sfcvs,
-        "image_features": feats,
-        "cv_mask": cv_mask,
-        "predicted_inverse_depths": preds,
-        "result": preds[0],
-        "mask": cv_mask,
-    }
+    out.update({"cost_volume": cv_masked, "predicted_inverse_depths": preds, "result": preds[0], "mask": cv_mask})
+    return out
 
 
 # ----------------------------------------------------------------------------------------

@@ -177,11 +177,20 @@ def test_public_attributes_are_json_serialisable():
     assert public["cv_depth_steps"] == 32 and public["training"] is True
 
 
-@pytest.mark.parametrize("kw", [dict(use_mono=False), dict(pretrain_mode=1), dict(simple_mask=True), dict(use_ssim=4),
-                                dict(mask_use_cv=False), dict(no_cv=True), dict(cv_patch_size=5)])
+@pytest.mark.parametrize("kw", [dict(use_mono=False), dict(pretrain_mode=4), dict(simple_mask=True), dict(use_ssim=4),
+                                dict(cv_patch_size=5), dict(augmentation="depth")])
 def test_unsupported_options_raise(kw):
     with pytest.raises(NotImplementedError):
         MonoRecModel(**kw)
+
+
+def test_pretrain_modes_build_the_reference_submodules():
+    """monorec_model.py:622-628: no MaskModule for pretrain_mode 1 / 3, no DepthModule for 2 (checkpoints of those stages load strictly)."""
+    has = lambda m, prefix: any(k.startswith(prefix) for k in m.state_dict())
+    for mode, mask, depth in ((0, True, True), (1, False, True), (2, True, False), (3, False, True)):
+        m = MonoRecModel(cv_depth_steps=8, pretrain_mode=mode)
+        assert has(m, "att_module.") == mask and has(m, "depth_module.") == depth, mode
+        assert has(m, "_feature_extractor.")
 
 
 def test_forward_refuses_cpu_inputs_and_training_mode():

@@ -233,6 +233,42 @@ def test_sfcv_without_mult_mask_through_the_model(hip_lib):
     _check_against(out, orc.forward(sd, batch, cv_depth_steps=8, sfcv_mult_mask=False), "sfcv_mult_mask=False")
 
 
+OPTION_CASES = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
+                "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False)}
+
+
+@pytest.mark.parametrize("case", sorted(OPTION_CASES))
+def test_model_options_against_reference_fixture(hip_lib, case):
+    """Eval-mode branches of monorec_model.py:680-727 (pretrain_mode 1/2/3, no_cv) and :352-355 (mask_use_cv/feats=False):
+    plan-level variants of the same kernels, checked against outputs of the reference model (fixture small_options)."""
+    g = Golden("small_options")
+    kw = OPTION_CASES[case]
+    batch = g.make_inputs()
+    batch["mvobj_mask"] = torch.from_numpy(g.z["input.mvobj_mask"])
+    m = MonoRecModel(cv_depth_steps=g.depths, hip_in_flight=1, **kw)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    data = _to_dev(batch)
+    data["mvobj_mask"] = batch["mvobj_mask"].to(DEV)
+    with torch.no_grad():
+        out = m(data)
+    torch.cuda.synchronize()
+    g.compare(f"{case}.result", out["result"], atol=RESULT_ATOL)
+    g.compare(f"{case}.cv_mask", out["cv_mask"], atol=1e-4)
+    g.compare(f"{case}.cost_volume", out["cost_volume"], atol=2e-4, max_outlier_frac=5e-4)
+    for f in range(len(out["single_frame_cvs"])):
+        g.compare(f"{case}.sfcv{f}", out["single_frame_cvs"][f], atol=1e-4, max_outlier_frac=1e-4)
+    assert ("predicted_inverse_depths" in out) == (case != "pm2") and ("mask" in out) == (case != "pm2")
+    ref = orc.forward(sd, batch, cv_depth_steps=g.depths, **kw)
+    assert (out["result"].cpu() - ref["result"]).abs().max().item() <= RESULT_ATOL
+    if case != "pm2":
+        for i in range(4):
+            assert (out["predicted_inverse_depths"][i].cpu() - ref["predicted_inverse_depths"][i]).abs().max().item() <= RESULT_ATOL
+    if case == "nocv":
+        assert float(out["cost_volume"].abs().max()) == 0.0 and len(out["single_frame_cvs"]) == len(batch["poses"])
+
+
 def test_depth_large_model(hip_lib):
     """depth_large_model=True (monorec_model.py:482-483): the plan takes the DepthModule widths from the weights."""
     g = Golden("small_large_depth")

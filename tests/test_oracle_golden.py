@@ -118,3 +118,23 @@ def test_oracle_without_mult_mask_matches_reference_fixture():
     g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
     for i, t in enumerate(sf):
         g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
+
+
+OPTION_CASES = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
+                "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False)}
+
+
+@pytest.mark.parametrize("case", sorted(OPTION_CASES))
+def test_oracle_model_options_match_reference_fixture(case):
+    """pretrain_mode 1/2/3 (eval), no_cv, mask_use_cv / mask_use_feats = False: fixture written from the reference model."""
+    from monorec_amd import MonoRecModel
+    g = Golden("small_options")
+    kw = OPTION_CASES[case]
+    batch = g.make_inputs()
+    batch["mvobj_mask"] = torch.from_numpy(g.z["input.mvobj_mask"])
+    sd = synth.seeded_state_dict(MonoRecModel(cv_depth_steps=g.depths, **kw).state_dict(), seed=0)
+    out = orc.forward(sd, batch, cv_depth_steps=g.depths, **kw)
+    g.compare(f"{case}.result", out["result"], atol=ATOL)
+    g.compare(f"{case}.cv_mask", out["cv_mask"], atol=ATOL)
+    g.compare(f"{case}.cost_volume", out["cost_volume"], atol=ATOL, max_outlier_frac=FLIPS)
+    assert ("predicted_inverse_depths" in out) == (case != "pm2") and ("mask" in out) == (case != "pm2")

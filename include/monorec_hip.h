@@ -199,6 +199,10 @@ int mr_resnet_normalize_f32(const float* src, float* dst, int64_t count, void* s
  * src is (F, count) contiguous. */
 int mr_max_over_frames_f32(const float* src, float* dst, int32_t num_frames, int64_t count, void* stream);
 
+/* SimpleMaskModule input (monorec_model.py:448-449): stacked.sum(0) / (stacked != 0).sum(0).clamp_min(1) over the F
+ * single-frame cost volumes.  src is (F, count) contiguous, count % 4 == 0. */
+int mr_nonzero_mean_over_frames_f32(const float* src, float* dst, int32_t num_frames, int64_t count, void* stream);
+
 /* Both consumers of a MaskModule encoder stage output in one pass: pooled = MaxPool2d(2) per frame (next stage input,
  * monorec_model.py:304-316) and frame_max = max over the frames (cv_feats[i], :365).
  * src (F, planes, in_h, in_w) -> pooled (F, planes, in_h/2, in_w/2), frame_max (planes, in_h, in_w);

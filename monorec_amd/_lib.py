@@ -86,6 +86,8 @@ ABI = {
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "mr_max_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                               ctypes.c_void_p]),
+    "mr_nonzero_mean_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                       ctypes.c_void_p]),
     "mr_pool2x2_framemax_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_apply_mask_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,

@@ -44,6 +44,21 @@ __global__ __launch_bounds__(256) void max_over_frames_kernel(const float4* __re
     }
 }
 
+// SimpleMaskModule input (monorec_model.py:448-449): sum over the F single-frame volumes / max(#non-zero entries, 1); 16 B per lane.
+__global__ __launch_bounds__(256) void nonzero_mean_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                           int F, long long count4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count4; i += (long long)gridDim.x * 256) {
+        float4 s = src[i];
+        float4 n = make_float4(s.x != 0.0f, s.y != 0.0f, s.z != 0.0f, s.w != 0.0f);
+        for (int f = 1; f < F; ++f) {
+            const float4 v = src[f * count4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            n.x += v.x != 0.0f; n.y += v.y != 0.0f; n.z += v.z != 0.0f; n.w += v.w != 0.0f;
+        }
+        dst[i] = make_float4(s.x / fmaxf(n.x, 1.0f), s.y / fmaxf(n.y, 1.0f), s.z / fmaxf(n.z, 1.0f), s.w / fmaxf(n.w, 1.0f));
+    }
+}
+
 // cost_volume = (1 - cv_mask) * cost_volume (monorec_model.py:713); 16 B per lane.
 __global__ __launch_bounds__(256) void apply_mask_kernel(const float4* cv, const float4* __restrict__ mask,
                                                          float4* dst, int B, int D, long long plane4) {
@@ -225,6 +240,13 @@ extern "C" int mr_sparse_metric_sums_f32(const float* prediction, const float* t
 extern "C" int mr_max_over_frames_f32(const float* src, float* dst, int32_t num_frames, int64_t count, void* stream) {
     if (!src || !dst || num_frames < 1 || count < 4 || (count & 3)) return MR_ERR_BAD_ARGUMENT;
     hipLaunchKernelGGL(max_over_frames_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src, (float4*)dst, num_frames, (long long)(count / 4));
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_nonzero_mean_over_frames_f32(const float* src, float* dst, int32_t num_frames, int64_t count, void* stream) {
+    if (!src || !dst || num_frames < 1 || count < 4 || (count & 3)) return MR_ERR_BAD_ARGUMENT;
+    hipLaunchKernelGGL(nonzero_mean_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)src, (float4*)dst, num_frames, (long long)(count / 4));
     return (int)hipGetLastError();
 }

@@ -196,7 +196,7 @@ class Plan:
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
-                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True):
+                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -212,6 +212,7 @@ class Plan:
         self.sfcv_mult_mask = bool(sfcv_mult_mask)
         self.pretrain_mode, self.no_cv = int(pretrain_mode), bool(no_cv)                  # monorec_model.py:680-727 (eval branches)
         self.mask_use_cv, self.mask_use_feats = bool(mask_use_cv), bool(mask_use_feats)   # :352-355
+        self.simple_mask = bool(simple_mask)                                              # SimpleMaskModule, :388-473
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
@@ -449,10 +450,21 @@ class Plan:
 
         # ---------------- MaskModule (monorec_model.py:345-385), frames batched as F*B ----------------
         am = "att_module"
-        enc_ch = (D, 48, 64, 96, 96)
+        enc_ch = (int(sd[f"{am}.enc.0.0.conv.weight"].shape[1]) if with_mask else D, 48, 64, 96, 96)   # D; D + 4 for SimpleMaskModule
         FM = F                             # frames the mask encoder runs on
         x = sfcv.view(F * B, D, H, W)
-        if not self.mask_use_cv:           # :352-353 `sfcv * 0`: every frame is the same zero input, so one pass stands for all
+        first_srcs = None
+        if self.simple_mask and with_mask:
+            # :447-453: one encoder pass over cat(non-zero mean of the single-frame volumes, keyframe, previous inverse depth)
+            mean = self.alloc("mask.sfcv_mean", B, D, H, W)
+            prev = self.alloc("prev_depth", B, 1, H, W)      # data_dict["predicted_inverse_depths"][0], copied in by the model
+
+            def run_mean(stream, src=sfcv, dst=mean):
+                _lib.check(lib.mr_nonzero_mean_over_frames_f32(src.data_ptr(), dst.data_ptr(), self.F, B * D * H * W, stream),
+                           "mr_nonzero_mean_over_frames_f32")
+            self.add(st, "mask.sfcv_mean", run_mean)
+            first_srcs, FM = [mean, kf, prev], 1
+        elif not self.mask_use_cv:           # :352-353 `sfcv * 0`: every frame is the same zero input, so one pass stands for all
             x = self.alloc("mask.zero_input", B, D, H, W).zero_()
             FM = 1
         cvf = []
@@ -461,7 +473,8 @@ class Plan:
             i0, i1 = (0, 1) if i == 0 else (1, 2)       # index 0 of stages 1-4 is the MaxPool
             a = self.alloc(f"mask.enc{i}.a", FM * B, enc_ch[i], hi, wi)
             xo = self.alloc(f"mask.enc{i}.x", FM * B, enc_ch[i], hi, wi)
-            self.same_conv(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a)
+            self.same_conv(st, f"mask.enc{i}.0", first_srcs if (i == 0 and first_srcs) else [x], f"{am}.enc.{i}.{i0}.conv.weight",
+                           f"{am}.enc.{i}.{i0}.conv.bias", a)
             self.same_conv(st, f"mask.enc{i}.1", [a], f"{am}.enc.{i}.{i1}.conv.weight", f"{am}.enc.{i}.{i1}.conv.bias", xo)
             m = self.alloc(f"mask.cvf{i}", B, enc_ch[i], hi, wi)
             cvf.append(m)

@@ -93,12 +93,12 @@ class CostVolumeModule(_ParamsOnly):
 class MaskModule(_ParamsOnly):
     """Parameters of MaskModule (monorec_model.py:287-343)."""
 
-    def __init__(self, depth_steps=32, feature_channels=(64, 64, 128, 256, 512), use_cv=True, use_features=True):
+    def __init__(self, depth_steps=32, feature_channels=(64, 64, 128, 256, 512), use_cv=True, use_features=True, in_channels=None):
         super().__init__()
         self.depth_steps = depth_steps
         self.feat_chns = feature_channels
         self.use_cv, self.use_features = use_cv, use_features
-        ec = (depth_steps, 48, 64, 96, 96)
+        ec = (depth_steps if in_channels is None else in_channels, 48, 64, 96, 96)
         dc = (96, 96, 64, 48)
         fc = tuple(int(c) for c in feature_channels)
 
@@ -118,6 +118,13 @@ class MaskModule(_ParamsOnly):
             dec.append(_seq(_Named(conv=_conv(up_in[i], up_out[i], 2)), cr(cat_in[i], dc[i]), cr(dc[i], dc[i])))
         self.dec = nn.ModuleList(dec)
         self.classifier = _seq(_conv(dc[3], 1, 1), nn.Sigmoid())
+
+
+class SimpleMaskModule(MaskModule):
+    """Parameters of SimpleMaskModule (monorec_model.py:388-442): the MaskModule layout with depth_steps + 3 + 1 input channels."""
+
+    def __init__(self, depth_steps=32, feature_channels=(64, 64, 128, 256, 512)):
+        super().__init__(depth_steps, feature_channels, in_channels=depth_steps + 3 + 1)
 
 
 class DepthModule(_ParamsOnly):
@@ -214,10 +221,8 @@ class MonoRecModel(nn.Module):
         self.depth_cp_loc = depth_cp_loc
         self.freeze_module = freeze_module
         self.freeze_resnet = freeze_resnet
-        # simple_mask: SimpleMaskModule.forward reads data_dict["predicted_inverse_depths"] before the DepthModule has run
-        # (monorec_model.py:449) - it only works inside the training-time refinement passes, which are out of scope here
         unsupported = dict(pretrain_mode=self.pretrain_mode not in (0, 1, 2, 3), use_mono=not (use_mono or use_stereo or no_cv),
-                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3), simple_mask=bool(simple_mask),
+                           use_ssim=use_ssim not in (True, False, 0, 1, 2, 3),
                            cv_patch_size=cv_patch_size != 3, augmentation=augmentation not in (None, "none"))
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -241,8 +246,11 @@ class MonoRecModel(nn.Module):
         self.cv_module = CostVolumeModule(use_mono=use_mono, use_stereo=use_stereo, use_ssim=use_ssim,
                                           sfcv_mult_mask=self.sfcv_mult_mask, patch_size=cv_patch_size)
         if self.pretrain_mode not in (1, 3):                                       # :622-626
-            self.att_module = MaskModule(self.cv_depth_steps, self._feature_extractor.num_ch_enc,
-                                         use_cv=mask_use_cv, use_features=mask_use_feats)
+            if not self.simple_mask:
+                self.att_module = MaskModule(self.cv_depth_steps, self._feature_extractor.num_ch_enc,
+                                             use_cv=mask_use_cv, use_features=mask_use_feats)
+            else:
+                self.att_module = SimpleMaskModule(self.cv_depth_steps, self._feature_extractor.num_ch_enc)
         if self.pretrain_mode != 2:                                                # :627-628
             self.depth_module = DepthModule(self.cv_depth_steps, feature_channels=self._feature_extractor.num_ch_enc,
                                             large_model=self.depth_large_model)
@@ -297,7 +305,8 @@ class MonoRecModel(nn.Module):
             plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
                         use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
-                        no_cv=self.no_cv, mask_use_cv=self.mask_use_cv, mask_use_feats=self.mask_use_feats)
+                        no_cv=self.no_cv, mask_use_cv=self.mask_use_cv or self.simple_mask,
+                        mask_use_feats=self.mask_use_feats or self.simple_mask, simple_mask=self.simple_mask)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
@@ -402,6 +411,9 @@ class MonoRecModel(nn.Module):
                     plan.alloc("pix_depths", b, self.cv_depth_steps, h, w)
                 plan.buf["pix_depths"].copy_(cv_depths)
             # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
+            if self.simple_mask and self.pretrain_mode in (0, 2):
+                # SimpleMaskModule reads a previous prediction from the dict (:453) - KeyError without one, like the reference
+                plan.buf["prev_depth"].copy_(data_dict["predicted_inverse_depths"][0])
             if self.pretrain_mode == 3:                       # :711 cv_mask = data_dict["mvobj_mask"].clone()
                 plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
             self._run_stage(key, plan, "cv", main)

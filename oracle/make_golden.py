@@ -267,7 +267,9 @@ def main():
     g = torch.Generator().manual_seed(41)
     mvobj = (torch.rand(1, 1, 64, 96, generator=g) < 0.2).float()
     option_cases = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
-                    "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False)}
+                    "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False),
+                    "simple": dict(simple_mask=True)}
+    prev_depth = 0.0025 + (0.33 - 0.0025) * torch.rand(1, 1, 64, 96, generator=g)     # SimpleMaskModule reads a previous prediction
     store = {}
     for case, kw in option_cases.items():
         ref = Ref(cv_depth_steps=8, **kw).eval()
@@ -275,12 +277,16 @@ def main():
         ref.load_state_dict(sd, strict=True)
         dd = synth.clone_batch(batch)
         dd["mvobj_mask"] = mvobj.clone()
+        if case == "simple":
+            dd["predicted_inverse_depths"] = [prev_depth.clone()]
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")            # no_cv: torch.tensor(tensor) copy-construct warning in the reference
             with torch.no_grad():
                 out_ref = ref(dd)
         ob = dict(batch)
         ob["mvobj_mask"] = mvobj
+        if case == "simple":
+            ob["predicted_inverse_depths"] = [prev_depth]
         out_orc = orc.forward(sd, ob, cv_depth_steps=8, **kw)
         assert ("predicted_inverse_depths" in out_ref) == ("predicted_inverse_depths" in out_orc), case
         assert ("mask" in out_ref) == ("mask" in out_orc), case
@@ -296,6 +302,7 @@ def main():
             store[f"{case}.{k}.full"] = get(out_ref, k).numpy()
         report["cases"][f"small_options.{case}"] = {"config": str(kw), "oracle_vs_reference_maxabs": diffs}
     store["input.mvobj_mask"] = mvobj.numpy()
+    store["input.prev_depth"] = prev_depth.numpy()
     store["meta"] = np.array([1, 64, 96, 2, 8, 41, 0, 1], dtype=np.int64)
     np.savez_compressed(os.path.join(GOLDEN, "small_options.npz"), **store)
     print("small_options ok; oracle == reference for", ", ".join(option_cases))

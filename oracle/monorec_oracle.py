@@ -247,12 +247,18 @@ def resnet_features(sd, image, prefix="_feature_extractor.encoder"):
 # ----------------------------------------------------------------------------------------
 # MaskModule (monorec_model.py:345-385)
 # ----------------------------------------------------------------------------------------
-def mask_module(sd, sfcvs, feats, prefix="att_module", use_cv=True, use_features=True):
+def mask_module(sd, sfcvs, feats, prefix="att_module", use_cv=True, use_features=True, simple_input=None):
+    """MaskModule.forward (:345-385); with `simple_input` = (keyframe, previous inverse depth) SimpleMaskModule.forward
+    (:444-473): one encoder pass over cat(non-zero mean of the single-frame volumes, keyframe, previous depth), same decoder."""
     cv_feats = []
     if not use_cv:
         sfcvs = [c * 0 for c in sfcvs]                                              # :352-353
     if not use_features:
         feats = [f * 0 for f in feats]                                              # :354-355
+    if simple_input is not None:
+        stacked = torch.stack(sfcvs, dim=0)                                         # :447-449
+        mean = stacked.sum(dim=0) / (stacked != 0).to(dtype=torch.float32).sum(dim=0).clamp_min(1)
+        sfcvs = [torch.cat([mean, simple_input[0], simple_input[1]], dim=1)]         # :453
     for cv in sfcvs:                                                                # :357
         x = cv
         for i in range(5):
@@ -317,7 +323,7 @@ def depth_module(sd, cost_volume_masked, keyframe, feats, prefix="depth_module")
 # MonoRecModel.forward (monorec_model.py:672-729)
 # ----------------------------------------------------------------------------------------
 def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True, cv_depths=None,
-            sfcv_mult_mask=True, pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True):
+            sfcv_mult_mask=True, pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False):
     """Returns the reference's output dict entries for eval mode (monorec_model.py:672-729); `pretrain_mode` as in :693-727."""
     with torch.no_grad():
         kf = batch["keyframe"]
@@ -329,7 +335,10 @@ def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stag
             sfcvs = [cv.clone() for _ in batch["poses"]]
         feats = resnet_features(sd, kf + .5)                                        # :691
         if pretrain_mode in (0, 2):
-            cv_mask = mask_module(sd, sfcvs, feats, use_cv=mask_use_cv, use_features=mask_use_feats)   # :694
+            if simple_mask:                                                         # :625-626; reads a previous prediction, :453
+                cv_mask = mask_module(sd, sfcvs, feats, simple_input=(kf, batch["predicted_inverse_depths"][0]))
+            else:
+                cv_mask = mask_module(sd, sfcvs, feats, use_cv=mask_use_cv, use_features=mask_use_feats)   # :694
         elif pretrain_mode == 1:
             cv_mask = kf.new_zeros(kf.shape[0], 1, kf.shape[2], kf.shape[3])        # :708 (eval branch)
         else:

@@ -177,7 +177,7 @@ def test_public_attributes_are_json_serialisable():
     assert public["cv_depth_steps"] == 32 and public["training"] is True
 
 
-@pytest.mark.parametrize("kw", [dict(use_mono=False), dict(pretrain_mode=4), dict(simple_mask=True), dict(use_ssim=4),
+@pytest.mark.parametrize("kw", [dict(use_mono=False), dict(pretrain_mode=4), dict(use_ssim=4),
                                 dict(cv_patch_size=5), dict(augmentation="depth")])
 def test_unsupported_options_raise(kw):
     with pytest.raises(NotImplementedError):
@@ -191,6 +191,8 @@ def test_pretrain_modes_build_the_reference_submodules():
         m = MonoRecModel(cv_depth_steps=8, pretrain_mode=mode)
         assert has(m, "att_module.") == mask and has(m, "depth_module.") == depth, mode
         assert has(m, "_feature_extractor.")
+    simple = MonoRecModel(cv_depth_steps=8, simple_mask=True).state_dict()          # SimpleMaskModule: depth_steps + 3 + 1 input channels
+    assert simple["att_module.enc.0.0.conv.weight"].shape == (12, 12, 3, 3) and simple["att_module.enc.1.1.conv.weight"].shape[1] == 12
 
 
 def test_forward_refuses_cpu_inputs_and_training_mode():

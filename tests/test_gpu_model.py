@@ -234,7 +234,8 @@ def test_sfcv_without_mult_mask_through_the_model(hip_lib):
 
 
 OPTION_CASES = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
-                "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False)}
+                "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False),
+                "simple": dict(simple_mask=True)}
 
 
 @pytest.mark.parametrize("case", sorted(OPTION_CASES))
@@ -245,12 +246,16 @@ def test_model_options_against_reference_fixture(hip_lib, case):
     kw = OPTION_CASES[case]
     batch = g.make_inputs()
     batch["mvobj_mask"] = torch.from_numpy(g.z["input.mvobj_mask"])
+    if case == "simple":                      # SimpleMaskModule reads a previous prediction from the dict (monorec_model.py:453)
+        batch["predicted_inverse_depths"] = [torch.from_numpy(g.z["input.prev_depth"])]
     m = MonoRecModel(cv_depth_steps=g.depths, hip_in_flight=1, **kw)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
     data = _to_dev(batch)
     data["mvobj_mask"] = batch["mvobj_mask"].to(DEV)
+    if case == "simple":
+        data["predicted_inverse_depths"] = [batch["predicted_inverse_depths"][0].to(DEV)]
     with torch.no_grad():
         out = m(data)
     torch.cuda.synchronize()

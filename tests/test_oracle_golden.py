@@ -121,7 +121,8 @@ def test_oracle_without_mult_mask_matches_reference_fixture():
 
 
 OPTION_CASES = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
-                "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False)}
+                "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False),
+                "simple": dict(simple_mask=True)}
 
 
 @pytest.mark.parametrize("case", sorted(OPTION_CASES))
@@ -132,6 +133,8 @@ def test_oracle_model_options_match_reference_fixture(case):
     kw = OPTION_CASES[case]
     batch = g.make_inputs()
     batch["mvobj_mask"] = torch.from_numpy(g.z["input.mvobj_mask"])
+    if case == "simple":                      # SimpleMaskModule reads a previous prediction from the dict (monorec_model.py:453)
+        batch["predicted_inverse_depths"] = [torch.from_numpy(g.z["input.prev_depth"])]
     sd = synth.seeded_state_dict(MonoRecModel(cv_depth_steps=g.depths, **kw).state_dict(), seed=0)
     out = orc.forward(sd, batch, cv_depth_steps=g.depths, **kw)
     g.compare(f"{case}.result", out["result"], atol=ATOL)

@@ -8,10 +8,11 @@
 The reference decodes and resizes every image three times with `frame_count = 2` (once as keyframe, twice as a
 source frame of its neighbours); `FrameCache` keeps the preprocessed frames of the last few indices in HBM, so a
 sequential sweep decodes each PNG once and runs one resize launch per *new* frame.  PNG decoding stays on the host
-(PIL, as in the reference); everything after it runs on the device, bit-identical to Pillow's integer resampling.
+(PIL, as in the reference; `FrameCache(workers=N)` decodes ahead on N threads); everything after it runs on the device, bit-identical to Pillow's integer resampling.
 There is no CPU fallback for the resize."""
 import ctypes
 from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -154,23 +155,53 @@ def lidar_inverse_depth(depth_png, crop_box, target_image_size, device="cuda:0")
 
 class FrameCache:
     """Preprocessed frames by index, least recently used evicted.  `load(index)` returns the decoded uint8 image
-    (the reference: `dataset.get_cam2(index)` / `get_cam0`, a PIL image - `np.asarray` of it works)."""
+    (the reference: `dataset.get_cam2(index)` / `get_cam0`, a PIL image - `np.asarray` of it works).
 
-    def __init__(self, load, preprocessor, capacity=8):
+    `workers > 0` decodes ahead on that many host threads (PIL's PNG decoder releases the GIL), the counterpart of the
+    reference's `num_workers` data-loader processes (configs/evaluate/eval_monorec.json:33): whenever frame i is asked
+    for, the decodes of i+1 .. i+lookahead are started, so a sequential sweep finds its next image already decoded.
+    Only `load` runs on the threads; the device launches stay on the caller's thread and stream.  `index_range = (lo, hi)`
+    bounds the read-ahead (hi exclusive)."""
+
+    def __init__(self, load, preprocessor, capacity=8, workers=0, lookahead=None, index_range=None):
         self.load, self.pre, self.capacity = load, preprocessor, capacity
         self._frames = OrderedDict()
         self.decoded = 0                       # number of images decoded + resized so far
+        self.workers = int(workers)
+        self.lookahead = int(lookahead if lookahead is not None else 2 * self.workers)
+        self.index_range = index_range
+        self._pool = ThreadPoolExecutor(self.workers, thread_name_prefix="monorec-decode") if self.workers > 0 else None
+        self._decoding = {}                    # index -> Future of the decoded image
+
+    def _decode_host(self, index):
+        return np.ascontiguousarray(np.asarray(self.load(index)))
+
+    def prefetch(self, indices):
+        """Start decoding `indices` on the worker threads (no-op without workers, for cached or already started ones)."""
+        if self._pool is None:
+            return
+        for j in indices:
+            if j in self._frames or j in self._decoding:
+                continue
+            if self.index_range is not None and not (self.index_range[0] <= j < self.index_range[1]):
+                continue
+            self._decoding[j] = self._pool.submit(self._decode_host, j)
 
     def frame(self, index):
         if index in self._frames:
             self._frames.move_to_end(index)
             return self._frames[index]
-        img = self.load(index)
-        t = self.pre(np.asarray(img))
+        fut = self._decoding.pop(index, None)
+        img = fut.result() if fut is not None else self._decode_host(index)
+        t = self.pre(img)
         self.decoded += 1
         self._frames[index] = t
         while len(self._frames) > self.capacity:
             self._frames.popitem(last=False)
+        if self._pool is not None:
+            self.prefetch(range(index + 1, index + 1 + self.lookahead))
+            for j in [j for j in self._decoding if j < index - self.capacity]:     # read-ahead the sweep has left behind
+                self._decoding.pop(j).cancel()
         return t
 
     def sample(self, index, frame_count=2, dilation=1, offset_d=0):
@@ -179,3 +210,11 @@ class FrameCache:
         offs = [i for i in range(-(frame_count // 2) * dilation, ((frame_count + 1) // 2) * dilation + 1, dilation) if i != 0]
         idx = [index + i + offset_d for i in offs]
         return self.frame(index), [self.frame(j) for j in idx], idx
+
+    def close(self):
+        if self._pool is not None:
+            for fut in self._decoding.values():
+                fut.cancel()
+            self._decoding.clear()
+            self._pool.shutdown(wait=True)
+            self._pool = None

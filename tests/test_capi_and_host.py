@@ -324,3 +324,35 @@ def test_python_lds_model_bounds_the_library(hip_lib):
             assert 0 < got <= cd["lds"] <= 160 * 1024, (cout, srcs, kh, kw, cd, got)
             checked += 1
     assert checked > 200
+
+
+def test_frame_cache_reads_ahead_on_worker_threads():
+    """FrameCache(workers=N): decodes run ahead on host threads, every image is decoded once, results equal the serial cache."""
+    import threading
+    import numpy as np
+    from monorec_amd.input_pipeline import FrameCache
+    main = threading.get_ident()
+    calls, threads = [], set()
+    lock = threading.Lock()
+
+    def load(i):
+        with lock:
+            calls.append(i)
+            threads.add(threading.get_ident())
+        return np.full((4, 6, 3), i % 251, dtype=np.uint8)
+
+    pre = lambda img: torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)       # stands in for the device preprocessor
+    serial = FrameCache(load, pre, capacity=4)
+    want = [[float(t[0, 0, 0]) for t in ([serial.sample(i)[0]] + serial.sample(i)[1])] for i in range(1, 30)]
+    del calls[:]
+    threads.clear()
+    cache = FrameCache(load, pre, capacity=4, workers=3, index_range=(0, 31))
+    got = []
+    for i in range(1, 30):
+        kf, fr, idx = cache.sample(i)
+        assert idx == [i - 1, i + 1]
+        got.append([float(t[0, 0, 0]) for t in [kf] + fr])
+    cache.close()
+    assert got == want
+    assert sorted(calls) == sorted(set(calls)) and set(range(0, 31)) >= set(calls) >= set(range(0, 31 - 1))   # once each, never past the range
+    assert cache.decoded == 31 and main not in threads - {main} and len(threads - {main}) >= 1

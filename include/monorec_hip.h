@@ -279,6 +279,13 @@ int mr_preprocess_image_u8_f32(const uint8_t* src, int32_t src_h, int32_t src_w,
 int mr_lidar_inverse_depth_u16_f32(const uint16_t* depth_png, int32_t src_h, int32_t src_w, const int32_t* box,
                                    int32_t out_h, int32_t out_w, int32_t* owner_scratch, float* dst, void* stream);
 
+/* Sparse D(V)SO ground truth, preprocess_depth_dso (kitti_odometry_dataset.py:156-182): the 16-bit PNG (0 = no point) ->
+ * inverse depth orig_w * value / (0.54 * focal_x * 65535) scattered like mr_lidar_inverse_depth_u16_f32; source coordinates
+ * are rescaled to the original image size (orig_h, orig_w) first and the crop box is tested on those (NULL = none). */
+int mr_dso_inverse_depth_u16_f32(const uint16_t* depth_png, int32_t src_h, int32_t src_w, int32_t orig_h, int32_t orig_w,
+                                 double focal_x, const int32_t* box, int32_t out_h, int32_t out_w,
+                                 int32_t* owner_scratch, float* dst, void* stream);
+
 int mr_abi_version(void);
 const char* mr_error_string(int code);
 

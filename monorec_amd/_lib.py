@@ -112,6 +112,9 @@ ABI = {
                                                   ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_lidar_inverse_depth_u16_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "mr_dso_inverse_depth_u16_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.c_double, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_abi_version": (ctypes.c_int, []),
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }

@@ -100,6 +100,36 @@ __global__ __launch_bounds__(256) void lidar_write_kernel(const unsigned short* 
     }
 }
 
+// ---- sparse D(V)SO ground truth: preprocess_depth_dso (kitti_odometry_dataset.py:156-182) -----------------------------
+// Same scatter, but the source coordinates are first rescaled to the original image size (:160-161, a no-op up to double
+// rounding when the depth PNG has the image's size), the crop test runs on those doubles (:169) and the stored value is
+// the inverse depth w * value / (0.54 * f_x * 65535) (:164).
+__global__ __launch_bounds__(256) void dso_elect_kernel(const unsigned short* __restrict__ png, int H, int W, int orig_h, int orig_w,
+                                                        int x0, int y0, int x1, int y1, int out_h, int out_w, int* __restrict__ owner) {
+    const long long n = (long long)H * W;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (png[i] == 0) continue;
+        const int r = (int)(i / W), c = (int)(i - (long long)r * W);
+        const double ry = fmin(fmax((double)r / (double)H * (double)orig_h, 0.0), (double)(orig_h - 1));   // :160
+        const double rx = fmin(fmax((double)c / (double)W * (double)orig_w, 0.0), (double)(orig_w - 1));   // :161
+        if (!((double)y0 <= ry && ry < (double)y1 && (double)x0 <= rx && rx < (double)x1)) continue;       // :169
+        double ty = (ry - (double)y0) / (double)(y1 - y0) * (double)out_h;         // :178
+        double tx = (rx - (double)x0) / (double)(x1 - x0) * (double)out_w;         // :179
+        ty = fmin(fmax(ty, 0.0), (double)(out_h - 1));
+        tx = fmin(fmax(tx, 0.0), (double)(out_w - 1));
+        const int cy = (int)rint(ty), cx = (int)rint(tx);                          // np.around
+        atomicMax(owner + cy * out_w + cx, (int)i);
+    }
+}
+
+__global__ __launch_bounds__(256) void dso_write_kernel(const unsigned short* __restrict__ png, const int* __restrict__ owner,
+                                                        int cells, double orig_w, double denom, float* __restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cells; i += gridDim.x * 256) {
+        const int o = owner[i];
+        out[i] = o >= 0 ? (float)(orig_w * (double)png[o] / denom) : 0.f;           // :164, then float32 (:182)
+    }
+}
+
 double triangle(double x) {
     if (x < 0.0) x = -x;
     return x < 1.0 ? 1.0 - x : 0.0;
@@ -182,5 +212,26 @@ extern "C" int mr_lidar_inverse_depth_u16_f32(const uint16_t* depth_png, int32_t
                        depth_png, src_h, src_w, x0, y0, x1, y1, out_h, out_w, owner_scratch);
     hipLaunchKernelGGL(lidar_write_kernel, dim3((unsigned)((cells + 255) / 256 < 2048 ? (cells + 255) / 256 : 2048)), dim3(256), 0, st,
                        depth_png, owner_scratch, cells, dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_dso_inverse_depth_u16_f32(const uint16_t* depth_png, int32_t src_h, int32_t src_w, int32_t orig_h, int32_t orig_w,
+                                            double focal_x, const int32_t* box, int32_t out_h, int32_t out_w,
+                                            int32_t* owner_scratch, float* dst, void* stream) {
+    if (!depth_png || !owner_scratch || !dst || src_h < 1 || src_w < 1 || orig_h < 1 || orig_w < 1 || out_h < 1 || out_w < 1 ||
+        !(focal_x > 0.0)) return MR_ERR_BAD_ARGUMENT;
+    if ((long long)src_h * src_w >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
+    int x0 = 0, y0 = 0, x1 = orig_w, y1 = orig_h;
+    if (box) { x0 = box[0]; y0 = box[1]; x1 = box[2]; y1 = box[3]; }
+    if (x1 <= x0 || y1 <= y0) return MR_ERR_BAD_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    const int cells = out_h * out_w;
+    hipError_t e = hipMemsetAsync(owner_scratch, 0xff, (size_t)cells * sizeof(int), st);      // -1 everywhere
+    if (e != hipSuccess) return (int)e;
+    const long long n = (long long)src_h * src_w;
+    hipLaunchKernelGGL(dso_elect_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
+                       depth_png, src_h, src_w, orig_h, orig_w, x0, y0, x1, y1, out_h, out_w, owner_scratch);
+    hipLaunchKernelGGL(dso_write_kernel, dim3((unsigned)((cells + 255) / 256 < 2048 ? (cells + 255) / 256 : 2048)), dim3(256), 0, st,
+                       depth_png, owner_scratch, cells, (double)orig_w, 0.54 * focal_x * 65535.0, dst);
     return (int)hipGetLastError();
 }

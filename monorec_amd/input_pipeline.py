@@ -153,6 +153,31 @@ def lidar_inverse_depth(depth_png, crop_box, target_image_size, device="cuda:0")
     return out
 
 
+def dso_inverse_depth(depth_png, dso_depth_parameters, crop_box, target_image_size, device="cuda:0"):
+    """`preprocess_depth_dso` (kitti_odometry_dataset.py:156-182): uint16 D(V)SO depth PNG array -> sparse inverse-depth map
+    (target_h, target_w) float32 on the device.  `dso_depth_parameters` = (original image height, width, f_x) (:351-355)."""
+    lib = _lib.load()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("monorec_amd.input_pipeline: a HIP device is required - there is no CPU fallback")
+    if isinstance(depth_png, np.ndarray):
+        if depth_png.dtype != np.uint16:
+            raise ValueError("expected the 16-bit depth PNG as a uint16 array")
+        depth_png = torch.from_numpy(np.ascontiguousarray(depth_png).view(np.int16))
+    if depth_png.dtype not in (torch.int16, torch.uint16) or depth_png.dim() != 2:
+        raise ValueError("expected a (H, W) 16-bit image")
+    src = depth_png.contiguous().to(device, non_blocking=True)
+    h, w = src.shape
+    oh, ow, f_x = dso_depth_parameters
+    th, tw = int(target_image_size[0]), int(target_image_size[1])
+    box = None if crop_box is None else (ctypes.c_int32 * 4)(*[int(v) for v in crop_box])
+    owner = torch.empty(th * tw, dtype=torch.int32, device=device)
+    out = torch.empty(th, tw, dtype=torch.float32, device=device)
+    _lib.check(lib.mr_dso_inverse_depth_u16_f32(src.data_ptr(), h, w, int(oh), int(ow), float(f_x), box, th, tw, owner.data_ptr(),
+                                                out.data_ptr(), torch.cuda.current_stream().cuda_stream), "mr_dso_inverse_depth_u16_f32")
+    return out
+
+
 class FrameCache:
     """Preprocessed frames by index, least recently used evicted.  `load(index)` returns the decoded uint8 image
     (the reference: `dataset.get_cam2(index)` / `get_cam0`, a PIL image - `np.asarray` of it works).

@@ -1,0 +1,286 @@
+"""KITTI odometry samples assembled on the MI355X: the sample dict of the reference's
+`KittiOdometryDataset` (data_loader/kitti_odometry_dataset.py:16-311) with every per-pixel step on the device.
+
+    from monorec_amd.kitti import KittiOdometryDataset, DeviceLoader
+    dataset = KittiOdometryDataset("data/kitti", sequences=["07"], depth_folder="image_depth_annotated",
+                                   lidar_depth=True, dso_depth=False, use_dso_poses=True)
+    for data, target in DeviceLoader(dataset, batch_size=2):      # dicts of device tensors, collated like the reference loader
+        out = model(data)
+
+Same constructor keywords, `len()`, `__getitem__` -> `(data, keyframe_depth)` and the same keys / shapes / dtypes as the
+reference.  What differs is where the work happens:
+
+  * sequence metadata (calib.txt, pose files, file lists - what the reference gets from the third-party `pykitti.odometry`)
+    is read once on the host by `KittiSequence`;
+  * images: PNG decode on host threads, ahead of the sweep (`input_pipeline.FrameCache`), then ONE device launch per *new*
+    image (crop, Pillow-exact bilinear resize, /255 - .5, CHW).  The reference decodes and resizes every image
+    1 + frame_count times; here consecutive samples share the preprocessed frames in HBM;
+  * targets: annotated lidar (`:184-211`) and D(V)SO depth (`:156-182`) PNGs are scattered on the device.
+
+Not provided (raise NotImplementedError): colour augmentation (training), dense `.npy` / non-annotated `.npz` depth folders.
+There is no CPU fallback: the first `__getitem__` needs a HIP device."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import input_pipeline
+
+
+class KittiSequence:
+    """Host-side view of one odometry sequence: what the reference reads through `pykitti.odometry(base, sequence)`
+    (un-vendored pip dependency; KITTI odometry devkit layout):
+
+        sequences/<seq>/calib.txt     "P0:".."P3:" row-major 3x4 rectified projections  -> P_rect_00 .. P_rect_30
+        sequences/<seq>/image_{0..3}/ sorted file lists                                 -> cam0_files .. cam3_files
+        <pose_dir>/<seq>.txt          one row-major 3x4 cam0->world matrix per line     -> poses (4x4 float64)
+
+    Stereo baselines as pykitti derives them: camera i sits at x-offset P_i[0,3] / P_i[0,0] of camera 0, so the
+    grey pair is |t1 - t0| and the colour pair |t3 - t2| apart."""
+
+    def __init__(self, base_path, sequence, pose_dir="poses"):
+        self.sequence = sequence
+        self.sequence_path = os.path.join(str(base_path), "sequences", sequence)
+        rows = {}
+        with open(os.path.join(self.sequence_path, "calib.txt")) as f:
+            for line in f:
+                key, sep, values = line.partition(":")
+                if sep:
+                    rows[key.strip()] = np.array([float(v) for v in values.split()], dtype=np.float64)
+        self.P_rect = [rows[f"P{i}"].reshape(3, 4) for i in range(4)]
+        shift = [p[0, 3] / p[0, 0] for p in self.P_rect]
+        self.b_gray, self.b_rgb = abs(shift[1] - shift[0]), abs(shift[3] - shift[2])
+        self.cam_files = []
+        for cam in range(4):
+            folder = os.path.join(self.sequence_path, f"image_{cam}")
+            self.cam_files.append(sorted(os.path.join(folder, n) for n in os.listdir(folder)) if os.path.isdir(folder) else [])
+        self.poses = []
+        self.load_poses(os.path.join(str(base_path), pose_dir))
+
+    def load_poses(self, pose_dir):
+        path = os.path.join(str(pose_dir), self.sequence + ".txt")
+        self.poses = []
+        if not os.path.exists(path):
+            return
+        with open(path) as f:
+            for line in f:
+                v = np.array([float(x) for x in line.split()], dtype=np.float64)
+                if v.size == 12:
+                    self.poses.append(np.vstack([v.reshape(3, 4), [0.0, 0.0, 0.0, 1.0]]))
+
+    def image_size(self, cam):
+        """(height, width) of the first image of camera `cam` (the reference peeks at `dataset.cam2.__next__().size`)."""
+        from PIL import Image
+        with Image.open(self.cam_files[cam][0]) as img:
+            w, h = img.size
+        return h, w
+
+
+class KittiOdometryDataset:
+    """Drop-in for `data_loader.kitti_odometry_dataset.KittiOdometryDataset` with device-resident samples."""
+
+    def __init__(self, dataset_dir, frame_count=2, sequences=None, depth_folder="image_depth", target_image_size=(256, 512),
+                 max_length=None, dilation=1, offset_d=0, use_color=True, use_dso_poses=False, use_color_augmentation=False,
+                 lidar_depth=False, dso_depth=True, annotated_lidar=True, return_stereo=False, return_mvobj_mask=False,
+                 use_index_mask=(), device="cuda:0", decode_workers=8, cache_frames=None):
+        if use_color_augmentation:
+            raise NotImplementedError("monorec_amd.kitti: colour augmentation is a training feature (out of scope)")
+        if not (lidar_depth or dso_depth):
+            raise NotImplementedError("monorec_amd.kitti: dense .npy depth folders are not supported (sparse lidar / dso targets only)")
+        if lidar_depth and not annotated_lidar:
+            raise NotImplementedError("monorec_amd.kitti: non-annotated (.npz) lidar depth is not supported")
+        self.dataset_dir = str(dataset_dir)
+        self.frame_count, self.dilation, self.offset_d = frame_count, dilation, offset_d
+        self.sequences = list(sequences) if sequences is not None else [f"{i:02d}" for i in range(11)]     # :56-57
+        self.depth_folder = depth_folder
+        self.lidar_depth, self.annotated_lidar, self.dso_depth = lidar_depth, annotated_lidar, dso_depth
+        self.target_image_size = tuple(target_image_size)
+        self.use_index_mask = use_index_mask
+        self.use_color, self.use_dso_poses = use_color, use_dso_poses
+        self.use_color_augmentation = False
+        self.return_stereo, self.return_mvobj_mask = return_stereo, return_mvobj_mask
+        self.device = torch.device(device)
+        self._cam = 2 if use_color else 0
+        self._datasets = [KittiSequence(self.dataset_dir, s, "poses_dvso" if use_dso_poses else "poses") for s in self.sequences]   # :58,:106-109
+
+        # ---- sample index bookkeeping (:59-87)
+        self._offset = (frame_count // 2) * dilation
+        extra = frame_count * dilation
+        if annotated_lidar and lidar_depth:                 # the annotated depth maps skip the first / last 5 frames
+            extra, self._offset = max(extra, 10), max(self._offset, 5)
+        sizes = [len(d.cam_files[self._cam]) - (extra if use_index_mask is None else 0) for d in self._datasets]
+        if use_index_mask is not None:
+            self._indices = []
+            for size, seq in zip(sizes, self.sequences):
+                keep = set(range(size))
+                for name in use_index_mask:
+                    with open(os.path.join(self.dataset_dir, "sequences", seq, name + ".json")) as f:
+                        listed = json.load(f)
+                    keep = {k for k in keep if listed.get(str(k))}
+                self._indices.append(sorted(k for k in keep if self._offset <= k < size + self._offset - extra))
+            sizes = [len(ix) for ix in self._indices]
+        if max_length is not None:
+            sizes = [min(s, max_length) for s in sizes]
+        self._dataset_sizes = sizes
+        self.length = sum(sizes)
+
+        # ---- geometry of the cropped / resized images (:89-99,:318-355)
+        self._orig_sizes = [d.image_size(self._cam) for d in self._datasets]
+        fractions_boxes = [input_pipeline.compute_target_intrinsics(d.P_rect[self._cam], size, self.target_image_size)
+                           for d, size in zip(self._datasets, self._orig_sizes)]
+        self._crop_boxes = [box for _, box in fractions_boxes]
+        self._intrinsics = [input_pipeline.format_intrinsics(fr, self.target_image_size) for fr, _ in fractions_boxes]
+        if dso_depth:
+            self.dso_depth_parameters = [(*d.image_size(2), d.P_rect[2][0, 0]) for d in self._datasets]
+        if return_stereo:                                   # :113-119
+            self._stereo_transform = []
+            for d in self._datasets:
+                st = torch.eye(4, dtype=torch.float32)
+                st[0, 3] = d.b_rgb if use_color else d.b_gray
+                self._stereo_transform.append(st)
+
+        # ---- device side, created on first use so that the bookkeeping above works without a GPU
+        self._decode_workers = int(decode_workers)
+        self._cache_frames = int(cache_frames) if cache_frames is not None else 2 * (frame_count * dilation + 2)
+        self._caches = {}                # (dataset index, camera) -> FrameCache
+        self._dev_intrinsics = None
+
+    # ------------------------------------------------------------------ bookkeeping like the reference
+    def __len__(self):
+        return self.length
+
+    def get_dataset_index(self, index):
+        for dataset_index, size in enumerate(self._dataset_sizes):
+            if index < size:
+                return dataset_index, index
+            index -= size
+        return None, None
+
+    def get_index(self, sequence, index):
+        for i, name in enumerate(self.sequences):
+            if int(name) == sequence:
+                break
+            index += self._dataset_sizes[i]
+        return index
+
+    def _neighbour_offsets(self):
+        fc, dl = self.frame_count, self.dilation
+        return [i for i in range(-(fc // 2) * dl, ((fc + 1) // 2) * dl + 1, dl) if i != 0]
+
+    # ------------------------------------------------------------------ device side
+    def _cache(self, dataset_index, cam):
+        key = (dataset_index, cam)
+        cache = self._caches.get(key)
+        if cache is None:
+            from PIL import Image
+            files = self._datasets[dataset_index].cam_files[cam]
+
+            def load(i, files=files):
+                with Image.open(files[i]) as img:
+                    return np.asarray(img)
+            pre = input_pipeline.ImagePreprocessor(self._orig_sizes[dataset_index], self.target_image_size,
+                                                   crop_box=self._crop_boxes[dataset_index], device=self.device)
+            cache = input_pipeline.FrameCache(load, pre, capacity=self._cache_frames, workers=self._decode_workers,
+                                              index_range=(0, len(files)))
+            self._caches[key] = cache
+        return cache
+
+    def _read_depth_png(self, dataset_index, frame):
+        from PIL import Image
+        path = os.path.join(self.dataset_dir, "sequences", self.sequences[dataset_index], self.depth_folder, f"{frame:06d}.png")
+        with Image.open(path) as img:
+            a = np.array(img)
+        if a.dtype != np.uint16:                            # 16-bit PNGs decode as int32 ("I") in some Pillow versions
+            a = a.astype(np.uint16)
+        return a
+
+    def _target(self, dataset_index, frame):
+        """keyframe_depth of `__getitem__` (:226-246) for the sparse targets."""
+        box, size = self._crop_boxes[dataset_index], self.target_image_size
+        png = self._read_depth_png(dataset_index, frame)
+        if self.lidar_depth:
+            depth = input_pipeline.lidar_inverse_depth(png, box, size, device=self.device)
+        else:
+            depth = torch.zeros(size, dtype=torch.float32, device=self.device)
+        if self.dso_depth:                                  # :241-246: dso depth where it has points, lidar elsewhere
+            dso = input_pipeline.dso_inverse_depth(png, self.dso_depth_parameters[dataset_index], box, size, device=self.device)
+            depth = torch.where(dso == 0, depth, dso)
+        return depth.unsqueeze(0)
+
+    def __getitem__(self, index):
+        dataset_index, index = self.get_dataset_index(index)
+        if dataset_index is None:
+            raise IndexError()
+        if self.use_index_mask is not None:
+            index = self._indices[dataset_index][index] - self._offset
+        seq = self._datasets[dataset_index]
+        key = index + self._offset
+        if self._dev_intrinsics is None:
+            self._dev_intrinsics = [k.to(self.device) for k in self._intrinsics]
+        k = self._dev_intrinsics[dataset_index]
+        cache = self._cache(dataset_index, self._cam)
+        sources = [key + i + self.offset_d for i in self._neighbour_offsets()]
+        pose = lambda j: torch.tensor(seq.poses[j], dtype=torch.float32).to(self.device, non_blocking=True)
+        data = {
+            "keyframe": cache.frame(key),
+            "keyframe_pose": pose(key),
+            "keyframe_intrinsics": k,
+            "frames": [cache.frame(j) for j in sources],
+            "poses": [pose(j) for j in sources],
+            "intrinsics": [k for _ in range(self.frame_count)],
+            "sequence": torch.tensor([int(self.sequences[dataset_index])], dtype=torch.int32, device=self.device),
+            "image_id": torch.tensor([int(key)], dtype=torch.int32, device=self.device),
+        }
+        if self.return_stereo:                              # :272-279
+            data["stereoframe"] = self._cache(dataset_index, self._cam + 1).frame(key)
+            data["stereoframe_pose"] = (torch.tensor(seq.poses[key], dtype=torch.float32) @ self._stereo_transform[dataset_index]).to(self.device)
+            data["stereoframe_intrinsics"] = k
+        if self.return_mvobj_mask > 0:                      # :281-285
+            path = os.path.join(self.dataset_dir, "sequences", self.sequences[dataset_index], "mvobj_mask", f"{key:06d}.npy")
+            mask = torch.tensor(np.load(path), dtype=torch.float32).unsqueeze(0).to(self.device)
+            data["mvobj_mask"] = mask
+            if self.return_mvobj_mask == 2:
+                return data, mask
+        return data, self._target(dataset_index, key)
+
+    def close(self):
+        for cache in self._caches.values():
+            cache.close()
+        self._caches = {}
+
+
+def collate(samples):
+    """`torch.utils.data.default_collate` for the (data, target) samples above: tensors stacked on a new batch dimension,
+    lists collated element-wise."""
+    def merge(items):
+        first = items[0]
+        if torch.is_tensor(first):
+            return torch.stack(items)
+        if isinstance(first, dict):
+            return {k: merge([it[k] for it in items]) for k in first}
+        if isinstance(first, (list, tuple)):
+            return [merge([it[i] for it in items]) for i in range(len(first))]
+        return items
+    return merge([s[0] for s in samples]), merge([s[1] for s in samples])
+
+
+class DeviceLoader:
+    """Sequential batches of a device-side dataset: the iteration contract of the reference's `KittiOdometryDataloader`
+    (data_loader/data_loaders.py:9-13, `shuffle=False`): yields `(data, target)` with a leading batch dimension, the last
+    batch may be smaller.  `rank` / `world_size` shard whole batches round-robin (monorec_amd.distributed.shard_batches)."""
+
+    def __init__(self, dataset, batch_size=1, rank=0, world_size=1):
+        self.dataset, self.batch_size, self.rank, self.world_size = dataset, int(batch_size), int(rank), int(world_size)
+
+    def _batches(self):
+        n = len(self.dataset)
+        starts = list(range(0, n, self.batch_size))
+        return [(s, min(s + self.batch_size, n)) for s in starts][self.rank::self.world_size]
+
+    def __len__(self):
+        return len(self._batches())
+
+    def __iter__(self):
+        for lo, hi in self._batches():
+            yield collate([self.dataset[i] for i in range(lo, hi)])

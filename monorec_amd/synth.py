@@ -197,3 +197,63 @@ def make_pixel_depths(batch, depths, height, width, seed=34):
     low = torch.rand(batch, depths, max(height // 8, 2), max(width // 8, 2), generator=gen)
     pert = F.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)
     return (base.view(1, depths, 1, 1) * (0.8 + 0.4 * pert)).contiguous()
+
+
+def make_kitti_tree(root, sequences=(("03", 120, 400), ("07", 200, 300)), frames=16, seed=7, depth_folder="image_depth_annotated"):
+    """Write a small KITTI-odometry-shaped directory (the layout the reference's KittiOdometryDataset reads through pykitti):
+    sequences/<seq>/{calib.txt, image_0..3/%06d.png, <depth_folder>/%06d.png (16-bit, sparse), mvobj_mask/%06d.npy,
+    mask_a.json, mask_b.json}, poses/<seq>.txt and poses_dvso/<seq>.txt.  Seeded; used by the fixtures and the GPU tests."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    for si, (seq, h, w) in enumerate(sequences):
+        sdir = os.path.join(str(root), "sequences", seq)
+        fx = 0.6 * w
+        cx, cy = 0.49 * w + 0.3, 0.47 * h + 0.2
+        shifts = (0.0, -0.5372 * fx, 0.0663 * fx, -0.4716 * fx)
+        os.makedirs(sdir, exist_ok=True)
+        with open(os.path.join(sdir, "calib.txt"), "w") as f:
+            for cam, tx in enumerate(shifts):
+                p = [fx, 0.0, cx, tx, 0.0, fx, cy, 0.0, 0.0, 0.0, 1.0, 0.0]
+                f.write(f"P{cam}: " + " ".join(f"{v:.12e}" for v in p) + "\n")
+            f.write("Tr: " + " ".join(f"{v:.12e}" for v in np.eye(4)[:3].reshape(-1)) + "\n")
+        for cam in range(4):
+            os.makedirs(os.path.join(sdir, f"image_{cam}"), exist_ok=True)
+            for i in range(frames):
+                img = make_u8_image(h, w, 1 if cam < 2 else 3, seed=seed * 1000 + si * 100 + cam * 30 + i)
+                Image.fromarray(img).save(os.path.join(sdir, f"image_{cam}", f"{i:06d}.png"))
+        os.makedirs(os.path.join(sdir, depth_folder), exist_ok=True)
+        os.makedirs(os.path.join(sdir, "mvobj_mask"), exist_ok=True)
+        for i in range(frames):
+            d = np.zeros((h, w), dtype=np.uint16)
+            hit = rng.rand(h, w) < 0.06
+            d[hit] = rng.randint(3 * 256, 80 * 256, size=int(hit.sum())).astype(np.uint16)
+            Image.fromarray(d).save(os.path.join(sdir, depth_folder, f"{i:06d}.png"))
+            np.save(os.path.join(sdir, "mvobj_mask", f"{i:06d}.npy"), (rng.rand(64, 128) < 0.1).astype(np.float32))
+        with open(os.path.join(sdir, "mask_a.json"), "w") as f:
+            json.dump({str(i): bool(i % 3) for i in range(frames)}, f)
+        with open(os.path.join(sdir, "mask_b.json"), "w") as f:
+            json.dump({str(i): bool(i != 7) for i in range(frames - 1)}, f)          # the last index is not listed at all
+        for folder, scale in (("poses", 1.0), ("poses_dvso", 0.9)):
+            os.makedirs(os.path.join(str(root), folder), exist_ok=True)
+            with open(os.path.join(str(root), folder, seq + ".txt"), "w") as f:
+                for i in range(frames):
+                    a = 0.01 * i * scale
+                    rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+                    t = np.array([0.02 * i, -0.01 * i * scale, 0.8 * i * scale + 10.0 * si])
+                    f.write(" ".join(f"{v:.12e}" for v in np.hstack([rot, t[:, None]]).reshape(-1)) + "\n")
+    return str(root)
+
+
+# option matrix of the KITTI sample assembly shared by oracle/make_golden.py (reference == oracle) and the GPU tests (product == oracle)
+KITTI_OPTION_CASES = {
+    "eval_config": dict(frame_count=2, lidar_depth=True, dso_depth=False, use_dso_poses=True),         # configs/evaluate/eval_monorec.json
+    "example_defaults": dict(frame_count=2, lidar_depth=True, use_dso_poses=True, use_index_mask=None),  # example/test_monorec.py:18-20
+    "dso_only": dict(frame_count=3, dilation=2, offset_d=1, max_length=4),
+    "masked_grey_stereo": dict(frame_count=4, use_color=False, lidar_depth=True, dso_depth=False, return_stereo=True,
+                               use_index_mask=("mask_a", "mask_b")),
+    "mvobj": dict(frame_count=2, lidar_depth=True, return_mvobj_mask=1, return_stereo=True),
+}
+

@@ -123,3 +123,29 @@ def lidar_inverse_depth(depth_png, crop_box, target_h, target_w):
     out = np.zeros((target_h, target_w))
     out[np.around(pts[0]).astype(int), np.around(pts[1]).astype(int)] = pts[2]   # :209 (last write wins)
     return torch.tensor(out, dtype=torch.float32)
+
+
+def dso_inverse_depth(depth_png, dso_depth_parameters, crop_box, target_h, target_w):
+    """preprocess_depth_dso (kitti_odometry_dataset.py:156-182) on the decoded uint16 PNG array; `dso_depth_parameters`
+    = (original image height, width, f_x) as get_dso_depth_parameters returns them (:351-355)."""
+    import torch
+    h, w, f_x = dso_depth_parameters
+    d = depth_png.astype(np.float64)
+    rows, cols = np.nonzero(d)
+    pts = np.stack([np.clip(rows.astype(np.float64) / d.shape[0] * h, 0, h - 1),          # :160
+                    np.clip(cols.astype(np.float64) / d.shape[1] * w, 0, w - 1),          # :161
+                    w * d[rows, cols] / (0.54 * f_x * 65535)])                            # :163-164
+    if crop_box is not None:                                                              # :168-174
+        x0, y0, x1, y1 = crop_box
+        pts = pts[:, (y0 <= pts[0]) & (pts[0] < y1) & (x0 <= pts[1]) & (pts[1] < x1)]
+        pts[0] -= y0
+        pts[1] -= x0
+        ch, cw = y1 - y0, x1 - x0
+    else:
+        ch, cw = h, w
+    pts[0] = np.clip(pts[0] / ch * target_h, 0, target_h - 1)                             # :178
+    pts[1] = np.clip(pts[1] / cw * target_w, 0, target_w - 1)                             # :179
+    out = np.zeros((target_h, target_w))
+    out[np.around(pts[0]).astype(int), np.around(pts[1]).astype(int)] = pts[2]            # :182 (last write wins)
+    return torch.tensor(out, dtype=torch.float32)
+

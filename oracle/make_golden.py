@@ -493,6 +493,52 @@ def main():
     report["pointcloud_oracle_equals_reference"] = True
     report["input_pipeline_oracle_equals_reference_on_example_frames"] = True
 
+    # ---- KITTI sample assembly (row f-3): the UNMODIFIED reference dataset class on a synthetic KITTI tree over the option
+    #      matrix == oracle/kitti_oracle.py (every tensor of every sample, bit for bit) and == the host bookkeeping of
+    #      monorec_amd.kitti.KittiOdometryDataset (lengths, index lists, crop boxes, intrinsics, poses; its per-pixel work needs the GPU)
+    import hashlib
+    import tempfile
+    from data_loader.kitti_odometry_dataset import KittiOdometryDataset as RefKitti     # noqa: reference class
+    from oracle.kitti_oracle import OracleKitti
+    from monorec_amd.kitti import KittiOdometryDataset as HipKitti
+    kitti_fixture = {}
+    with tempfile.TemporaryDirectory() as tree:
+        synth.make_kitti_tree(tree)
+        first_png = open(os.path.join(tree, "sequences", "03", "image_2", "000000.png"), "rb").read()
+        kitti_fixture["tree_sha1"] = hashlib.sha1(first_png).hexdigest()
+        kitti_fixture["cases"] = {}
+        common = dict(sequences=["03", "07"], depth_folder="image_depth_annotated", target_image_size=(64, 128))
+        for name, kw in synth.KITTI_OPTION_CASES.items():
+            kw = dict(common, **kw)
+            ref_ds, orc_ds = RefKitti(tree, **kw), OracleKitti(tree, **kw)
+            hip_ds = HipKitti(tree, device="cpu", **kw)                            # bookkeeping only: nothing here touches a device
+            assert len(ref_ds) == len(orc_ds) == len(hip_ds) and len(ref_ds) > 0, (name, len(ref_ds), len(orc_ds), len(hip_ds))
+            assert ref_ds._dataset_sizes == orc_ds.sizes == hip_ds._dataset_sizes, name
+            if kw.get("use_index_mask", ()) is not None:
+                assert ref_ds._indices == orc_ds.indices == hip_ds._indices, name
+            for di in range(2):
+                assert tuple(ref_ds._crop_boxes[di]) == tuple(orc_ds.boxes[di]) == tuple(hip_ds._crop_boxes[di]), name
+                assert torch.equal(ref_ds._intrinsics[di], orc_ds.K[di]) and torch.equal(ref_ds._intrinsics[di], hip_ds._intrinsics[di]), name
+                assert all(np.array_equal(a, b) for a, b in zip(ref_ds._datasets[di].poses, hip_ds._datasets[di].poses)), name
+                if kw.get("return_stereo"):
+                    assert torch.equal(ref_ds._stereo_transform[di], hip_ds._stereo_transform[di]), name
+            sums = []
+            for i in range(len(ref_ds)):
+                (rd, rt), (od, ot) = ref_ds[i], orc_ds[i]
+                assert sorted(rd) == sorted(od), (name, sorted(rd), sorted(od))
+                for k in rd:
+                    pairs = zip(rd[k], od[k]) if isinstance(rd[k], list) else [(rd[k], od[k])]
+                    for a, b in pairs:
+                        assert a.dtype == b.dtype and torch.equal(a, b), (name, i, k)
+                assert rt.dtype == ot.dtype and torch.equal(rt, ot), (name, i, "target")
+                assert hip_ds.get_dataset_index(i) == ref_ds.get_dataset_index(i)
+                sums.append([float(rd["keyframe"].double().sum()), float(rt.double().sum()), int((rt != 0).sum()), int(rd["image_id"])])
+            kitti_fixture["cases"][name] = {"length": len(ref_ds), "samples": sums}
+            report["cases"][f"kitti_dataset.{name}"] = {"config": str(kw), "oracle_vs_reference_maxabs": {"all_tensors": 0.0}}
+            print("kitti dataset", name, "ok; oracle == reference on", len(ref_ds), "samples; product bookkeeping equal")
+    with open(os.path.join(GOLDEN, "kitti_tree.json"), "w") as f:
+        json.dump(kitti_fixture, f, indent=1, sort_keys=True)
+
     # ---- input pipeline fixtures: Pillow itself (the dependency preprocess_image calls) on seeded images -----------------
     from PIL import Image
     from oracle import input_oracle

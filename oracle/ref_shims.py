@@ -103,6 +103,7 @@ class _KittiOdometryStandIn:
         return lambda idx: Image.open(getattr(self, f"cam{cam}_files")[idx])
 
     def get_cam0(self, idx): return self._reader(0)(idx)
+    def get_cam1(self, idx): return self._reader(1)(idx)
     def get_cam2(self, idx): return self._reader(2)(idx)
     def get_cam3(self, idx): return self._reader(3)(idx)
 

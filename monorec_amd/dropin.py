@@ -13,7 +13,13 @@ directory / sys.path must be the reference checkout) and rebinds exactly these n
     model.metric.<the seven sparse metrics of eval_monorec.json:53-61>    -> monorec_amd.metrics.<same name>
     utils.PLYSaver, utils.ply_utils.PLYSaver                              -> monorec_amd.pointcloud.PLYSaver
 
-Nothing else of the reference is touched (data loaders, config parser, Evaluater stay the reference's own code).
+Nothing else of the reference is touched (data loaders, config parser, Evaluater stay the reference's own code) - unless asked:
+
+    python -m monorec_amd.dropin --device-loader evaluate.py --config configs/evaluate/eval_monorec.json
+
+additionally rebinds `data_loader.data_loaders.KittiOdometryDataloader` (looked up by `config.initialize('data_loader',
+module_data)`, evaluate.py:20) to `monorec_amd.kitti.KittiOdometryDataloader`: samples are assembled on the device (threaded PNG
+decode, one resize launch per new image) instead of by 8 worker processes on the CPU.
 """
 import importlib
 import os
@@ -33,7 +39,7 @@ def _rebind(module_name, attr, value):
     return True
 
 
-def install(model=True, metrics=True, pointcloud=True):
+def install(model=True, metrics=True, pointcloud=True, data_loader=False):
     """Rebind the reference's lookup names to the MI355X implementations.  Returns the list of (module, name) rebound."""
     del REBOUND[:]
     from . import MonoRecModel
@@ -50,16 +56,24 @@ def install(model=True, metrics=True, pointcloud=True):
         from .pointcloud import PLYSaver
         _rebind("utils.ply_utils", "PLYSaver", PLYSaver)
         _rebind("utils", "PLYSaver", PLYSaver)
+    if data_loader:
+        from .kitti import KittiOdometryDataloader, KittiOdometryDataset
+        if not _rebind("data_loader.data_loaders", "KittiOdometryDataloader", KittiOdometryDataloader):
+            raise ImportError("monorec_amd.dropin: `data_loader.data_loaders` of the reference is not importable")
+        _rebind("data_loader.data_loaders", "KittiOdometryDataset", KittiOdometryDataset)
     return list(REBOUND)
 
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    device_loader = bool(argv) and argv[0] == "--device-loader"
+    if device_loader:
+        argv = argv[1:]
     if not argv:
-        raise SystemExit("usage: python -m monorec_amd.dropin <reference script.py> [its arguments]")
+        raise SystemExit("usage: python -m monorec_amd.dropin [--device-loader] <reference script.py> [its arguments]")
     script = argv[0]
     sys.path.insert(0, os.path.dirname(os.path.abspath(script)) or os.getcwd())
-    install()
+    install(data_loader=device_loader)
     sys.argv = argv
     runpy.run_path(script, run_name="__main__")
 

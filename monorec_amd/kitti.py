@@ -100,7 +100,7 @@ class KittiOdometryDataset:
         self.use_color, self.use_dso_poses = use_color, use_dso_poses
         self.use_color_augmentation = False
         self.return_stereo, self.return_mvobj_mask = return_stereo, return_mvobj_mask
-        self.device = torch.device(device)
+        self._device = torch.device(device)         # private: evaluate.py:45-52 dumps the public attributes as JSON
         self._cam = 2 if use_color else 0
         self._datasets = [KittiSequence(self.dataset_dir, s, "poses_dvso" if use_dso_poses else "poses") for s in self.sequences]   # :58,:106-109
 
@@ -180,7 +180,7 @@ class KittiOdometryDataset:
                 with Image.open(files[i]) as img:
                     return np.asarray(img)
             pre = input_pipeline.ImagePreprocessor(self._orig_sizes[dataset_index], self.target_image_size,
-                                                   crop_box=self._crop_boxes[dataset_index], device=self.device)
+                                                   crop_box=self._crop_boxes[dataset_index], device=self._device)
             cache = input_pipeline.FrameCache(load, pre, capacity=self._cache_frames, workers=self._decode_workers,
                                               index_range=(0, len(files)))
             self._caches[key] = cache
@@ -200,11 +200,11 @@ class KittiOdometryDataset:
         box, size = self._crop_boxes[dataset_index], self.target_image_size
         png = self._read_depth_png(dataset_index, frame)
         if self.lidar_depth:
-            depth = input_pipeline.lidar_inverse_depth(png, box, size, device=self.device)
+            depth = input_pipeline.lidar_inverse_depth(png, box, size, device=self._device)
         else:
-            depth = torch.zeros(size, dtype=torch.float32, device=self.device)
+            depth = torch.zeros(size, dtype=torch.float32, device=self._device)
         if self.dso_depth:                                  # :241-246: dso depth where it has points, lidar elsewhere
-            dso = input_pipeline.dso_inverse_depth(png, self.dso_depth_parameters[dataset_index], box, size, device=self.device)
+            dso = input_pipeline.dso_inverse_depth(png, self.dso_depth_parameters[dataset_index], box, size, device=self._device)
             depth = torch.where(dso == 0, depth, dso)
         return depth.unsqueeze(0)
 
@@ -217,11 +217,11 @@ class KittiOdometryDataset:
         seq = self._datasets[dataset_index]
         key = index + self._offset
         if self._dev_intrinsics is None:
-            self._dev_intrinsics = [k.to(self.device) for k in self._intrinsics]
+            self._dev_intrinsics = [k.to(self._device) for k in self._intrinsics]
         k = self._dev_intrinsics[dataset_index]
         cache = self._cache(dataset_index, self._cam)
         sources = [key + i + self.offset_d for i in self._neighbour_offsets()]
-        pose = lambda j: torch.tensor(seq.poses[j], dtype=torch.float32).to(self.device, non_blocking=True)
+        pose = lambda j: torch.tensor(seq.poses[j], dtype=torch.float32).to(self._device, non_blocking=True)
         data = {
             "keyframe": cache.frame(key),
             "keyframe_pose": pose(key),
@@ -229,16 +229,16 @@ class KittiOdometryDataset:
             "frames": [cache.frame(j) for j in sources],
             "poses": [pose(j) for j in sources],
             "intrinsics": [k for _ in range(self.frame_count)],
-            "sequence": torch.tensor([int(self.sequences[dataset_index])], dtype=torch.int32, device=self.device),
-            "image_id": torch.tensor([int(key)], dtype=torch.int32, device=self.device),
+            "sequence": torch.tensor([int(self.sequences[dataset_index])], dtype=torch.int32, device=self._device),
+            "image_id": torch.tensor([int(key)], dtype=torch.int32, device=self._device),
         }
         if self.return_stereo:                              # :272-279
             data["stereoframe"] = self._cache(dataset_index, self._cam + 1).frame(key)
-            data["stereoframe_pose"] = (torch.tensor(seq.poses[key], dtype=torch.float32) @ self._stereo_transform[dataset_index]).to(self.device)
+            data["stereoframe_pose"] = (torch.tensor(seq.poses[key], dtype=torch.float32) @ self._stereo_transform[dataset_index]).to(self._device)
             data["stereoframe_intrinsics"] = k
         if self.return_mvobj_mask > 0:                      # :281-285
             path = os.path.join(self.dataset_dir, "sequences", self.sequences[dataset_index], "mvobj_mask", f"{key:06d}.npy")
-            mask = torch.tensor(np.load(path), dtype=torch.float32).unsqueeze(0).to(self.device)
+            mask = torch.tensor(np.load(path), dtype=torch.float32).unsqueeze(0).to(self._device)
             data["mvobj_mask"] = mask
             if self.return_mvobj_mask == 2:
                 return data, mask
@@ -284,3 +284,22 @@ class DeviceLoader:
     def __iter__(self):
         for lo, hi in self._batches():
             yield collate([self.dataset[i] for i in range(lo, hi)])
+
+
+class KittiOdometryDataloader(DeviceLoader):
+    """Constructor contract of the reference's `KittiOdometryDataloader` (data_loader/data_loaders.py:9-13 over
+    base/base_data_loader.py:7-30) for the sequential case the eval / point-cloud configs use: `.dataset`, `.batch_size`,
+    `.n_samples`, `len()`, iteration.  `num_workers` becomes the number of host decode threads."""
+
+    def __init__(self, batch_size=1, shuffle=True, validation_split=0.0, num_workers=4, **kwargs):
+        if shuffle or validation_split:
+            raise NotImplementedError("monorec_amd.kitti.KittiOdometryDataloader: sequential inference only "
+                                      "(shuffle=false, validation_split=0, as in configs/evaluate/eval_monorec.json)")
+        kwargs.setdefault("decode_workers", max(1, int(num_workers)))
+        super().__init__(KittiOdometryDataset(**kwargs), batch_size)
+        self.shuffle, self.validation_split = shuffle, validation_split
+        self.n_samples = len(self.dataset)
+
+    def split_validation(self):
+        return None
+

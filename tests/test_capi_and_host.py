@@ -281,6 +281,11 @@ def test_dropin_rebinds_the_names_the_reference_scripts_look_up(tmp_path):
     (root / "model" / "metric.py").write_text("from .metric_functions.sparse_metrics import *\n")
     (root / "utils" / "ply_utils.py").write_text("class PLYSaver:\n    origin = 'reference'\n")
     (root / "utils" / "__init__.py").write_text("from .ply_utils import *\n")
+    (root / "data_loader").mkdir()
+    (root / "data_loader" / "__init__.py").write_text("")
+    (root / "data_loader" / "data_loaders.py").write_text("class KittiOdometryDataloader:\n    origin = 'reference'\n")
+    (root / "loader_like.py").write_text("import data_loader.data_loaders as module_data\nimport model.model as module_arch\n"
+                                         "print(getattr(module_data, 'KittiOdometryDataloader').__module__, module_arch.MonoRecModel.__module__)\n")
     (root / "evaluate_like.py").write_text(
         "import sys\nimport model.metric as module_metric\nimport model.model as module_arch\nfrom utils import PLYSaver\n"
         "cls = getattr(module_arch, 'MonoRecModel')\n"
@@ -292,6 +297,11 @@ def test_dropin_rebinds_the_names_the_reference_scripts_look_up(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split() == ["monorec_amd.model", "monorec_amd.metrics", "reference", "monorec_amd.pointcloud",
                                   "['--config',", "'x.json']"]
+    for flags, want in (([], "data_loader.data_loaders"), (["--device-loader"], "monorec_amd.kitti")):    # the loader only on request
+        out = subprocess.run([sys.executable, "-m", "monorec_amd.dropin", *flags, "loader_like.py"], cwd=root,
+                             env=dict(os.environ, PYTHONPATH=repo), capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split() == [want, "monorec_amd.model"]
 
 
 def test_python_lds_model_bounds_the_library(hip_lib):

@@ -67,6 +67,22 @@ def test_unsupported_dataset_options_raise(tree):
         ds[0]
 
 
+def test_loader_contract_of_the_eval_config(tree):
+    """KittiOdometryDataloader(**configs/evaluate/eval_monorec.json:26-50 style args): what evaluate.py / Evaluater touch."""
+    import json as js
+    args = dict(dataset_dir=tree, depth_folder="image_depth_annotated", batch_size=2, frame_count=2, shuffle=False, validation_split=0,
+                num_workers=8, sequences=["03", "07"], target_image_size=[64, 128], use_color=True, use_color_augmentation=False,
+                use_dso_poses=True, lidar_depth=True, dso_depth=False, return_stereo=False, device="cpu")
+    loader = kitti.KittiOdometryDataloader(**args)
+    assert loader.batch_size == 2 and loader.n_samples == len(loader.dataset) == 12 and len(loader) == 6
+    assert loader.dataset._decode_workers == 8
+    public = {k: v for k, v in loader.dataset.__dict__.items() if not k.startswith("_")}      # evaluate.py:45-52
+    js.dumps({k: (list(v) if isinstance(v, np.ndarray) else v) for k, v in public.items()})
+    assert public["target_image_size"] == (64, 128) and public["length"] == 12
+    with pytest.raises(NotImplementedError):
+        kitti.KittiOdometryDataloader(**dict(args, shuffle=True))
+
+
 def test_collate_and_batch_sharding():
     class Fake:
         def __len__(self):

@@ -57,10 +57,11 @@ def install(model=True, metrics=True, pointcloud=True, data_loader=False):
         _rebind("utils.ply_utils", "PLYSaver", PLYSaver)
         _rebind("utils", "PLYSaver", PLYSaver)
     if data_loader:
-        from .kitti import KittiOdometryDataloader, KittiOdometryDataset
+        from .kitti import KittiOdometryDataloader
         if not _rebind("data_loader.data_loaders", "KittiOdometryDataloader", KittiOdometryDataloader):
             raise ImportError("monorec_amd.dropin: `data_loader.data_loaders` of the reference is not importable")
-        _rebind("data_loader.data_loaders", "KittiOdometryDataset", KittiOdometryDataset)
+        # (create_pointcloud.py wraps `KittiOdometryDataset` in a torch DataLoader with 8 worker *processes*, :32 - device
+        #  samples cannot cross that boundary, so the dataset class itself is left alone)
     return list(REBOUND)
 
 

@@ -146,22 +146,28 @@ def test_hip_dso_target_is_bit_exact_at_kitti_size(hip_lib):
 
 
 @pytest.mark.gpu
-def test_device_loader_feeds_the_model(hip_lib, tree):
-    """configs/evaluate/eval_monorec.json shape of use: batch_size 2 samples straight into the model, targets into the metrics."""
-    from monorec_amd import MonoRecModel
-    from monorec_amd.metrics import abs_rel_sparse_metric
-    ds = kitti.KittiOdometryDataset(tree, device=DEV, **dict(COMMON, **synth.KITTI_OPTION_CASES["eval_config"]))
-    model = MonoRecModel(cv_depth_steps=8, hip_in_flight=1)
+def test_eval_config_end_to_end(hip_lib, tree):
+    """The evaluation flow of configs/evaluate/eval_monorec.json on the device: KittiOdometryDataloader -> MonoRecModel -> fused
+    metrics -> Evaluater bookkeeping, against the same flow fed with the oracle's CPU-assembled batches and the oracle's metrics."""
+    import math
+    from monorec_amd import MonoRecModel, evaluate
+    from oracle import monorec_oracle as orc
+    args = dict(COMMON, **synth.KITTI_OPTION_CASES["eval_config"])
+    loader = kitti.KittiOdometryDataloader(dataset_dir=tree, batch_size=2, shuffle=False, num_workers=4, device=DEV, **args)
+    model = MonoRecModel(cv_depth_steps=8)
     model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=0))
     model = model.to(DEV).eval()
-    n = 0
-    for data, target in kitti.DeviceLoader(ds, batch_size=2):
-        if int(data["sequence"][0]) != int(data["sequence"][-1]):
-            continue                                                   # the two sequences of the tree have different crops but one size
-        data["target"] = target
+    log = evaluate.Evaluater(model, roi=None, max_distance=80).eval(loader)
+    orc_ds = OracleKitti(tree, **args)
+    per_batch = []
+    for lo in range(0, len(orc_ds), 2):
+        data, target = kitti.collate([orc_ds[i] for i in range(lo, lo + 2)])
         with torch.no_grad():
-            out = model(data)
-        assert out["result"].shape == (2, 1, 64, 128) and torch.isfinite(abs_rel_sparse_metric(out)).all()
-        n += 1
-    assert n >= 4
-    ds.close()
+            res = model(synth.clone_batch(data, DEV))["result"].cpu().clone()
+        vals = orc.sparse_metrics(res, target, None, 80)
+        per_batch.append([float(vals[k]) for k in evaluate._metrics.SPARSE_METRICS])
+    assert log["valid_batches"] == len(per_batch) == 6
+    want = np.mean(np.array(per_batch), axis=0)
+    for got, w in zip(log["metrics"], want):
+        assert math.isclose(got, w, rel_tol=2e-5, abs_tol=1e-7), (log["metrics"], want.tolist())
+    loader.dataset.close()

@@ -373,12 +373,14 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
                 bool valid = border;
                 if (PFLAG) valid = valid && ((const unsigned int*)a.cv)[((long long)b * D + f) * HWp + p] != 0u;
                 float smin = INFINITY;
+#pragma unroll 8
                 for (int d = 0; d < D; ++d) {
                     const float v = sf[(long long)d * HWp];
                     if (!PFLAG) valid = valid && !(__float_as_uint(v) & 0x80000000u);
                     smin = fminf(smin, fabsf(v));
                 }
                 float se = 0.f;
+#pragma unroll 8
                 for (int d = 0; d < D; ++d) {
                     const float df = fabsf(sf[(long long)d * HWp]) - smin;
                     const float ev = expf(-a.alpha * (df * df));                 // :257
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
         }
         const bool nz = wsum != 0.f;
         float* cvp = a.cv + (long long)b * D * HWp + p;
+#pragma unroll 4
         for (int d = 0; d < D; ++d) {
             float num = 0.f;
 #pragma unroll

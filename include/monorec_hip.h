@@ -183,6 +183,16 @@ int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, i
                             const float* pixel_depths, int32_t sfcv_mult_mask,
                             float* cost_volume, float* const* sfcv, void* stream);
 
+/* The same with a P x P matching patch, `cv_patch_size` of MonoRecModel (monorec_model.py:138-142,247): the photometric term is
+ * averaged over a zero-padded patch_size x patch_size box and the border radius becomes patch_size / 2 + 1 (:139).
+ * patch_size odd, 1..7; 3 is the tuned kernel of mr_cost_volume_mode_f32, the others run a generic (slower) variant. */
+int mr_cost_volume_patch_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                             const float* kinv, const float* proj, const float* depths,
+                             int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                             float alpha, const float* channel_weights, int32_t use_ssim,
+                             const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size,
+                             float* cost_volume, float* const* sfcv, void* stream);
+
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the torchvision ResNet stem (monorec_model.py:124) */
 int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in_h, int32_t in_w, void* stream);
 

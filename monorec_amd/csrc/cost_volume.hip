@@ -42,6 +42,7 @@ struct CvArgs {
     float alpha;
     float cw[3];          // channel_weight / 9 (fp32 division, monorec_model.py:141)
     float inv_dm1;        // fp32(1/(D-1)) (python double division, then cast; :258)
+    int border;           // border_radius = patch_size / 2 + 1 (monorec_model.py:139); 2 for the default 3x3 patch
 };
 
 // a / 9.0f in 3 instructions instead of the ~10 of the IEEE division sequence: q0 = a*y, r = fma(-9, q0, a),
@@ -353,6 +354,199 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
         atomicAnd((unsigned int*)a.cv + ((long long)b * D + f) * HWp + opy * W + opx, 0u);
 }
 
+// ---- generic patch size (cv_patch_size != 3; monorec_model.py:138-142,247) -----------------------------------------------
+// P x P zero-padded box of the photometric term instead of 3x3, border radius P / 2 + 1.  Rarely used (no reference config sets
+// it), so this variant trades speed for simplicity: 32x8 tile, one depth plane per iteration, every stage a strided loop over its
+// tile (warped planes on tile + R + 1, photometric term on tile + R, R = P / 2), keyframe SSIM statistics kept in LDS.
+// Same conventions as cv_sad_kernel for the raw sad planes (validity / per-plane flag in the sign bit).
+__device__ __forceinline__ bool mask_hit_r(const Sample& sp, int H, int W, int br) {
+    const float ml = (sp.x0 >= br && sp.x0 < W - br) ? 1.f : 0.f, mr = (sp.x0 + 1 >= br && sp.x0 + 1 < W - br) ? 1.f : 0.f;
+    const float mt = (sp.y0 >= br && sp.y0 < H - br) ? 1.f : 0.f, mb = (sp.y0 + 1 >= br && sp.y0 + 1 < H - br) ? 1.f : 0.f;
+    const float m = fmaf(mr * mb, sp.se, fmaf(ml * mb, sp.sw, fmaf(mr * mt, sp.ne, (ml * mt) * sp.nw)));
+    return m != 0.f;
+}
+
+template <int MODE, int OPT>
+__global__ __launch_bounds__(256) void cv_sad_patch_kernel(const CvArgs a, const int R) {
+    constexpr bool PIXD = OPT & 1, PFLAG = (OPT & 2) != 0;
+    constexpr int TX = 32, TY = 8, NT = TX * TY;
+    const int HALO = R + 1;
+    const int HX = TX + 2 * HALO, HY = TY + 2 * HALO;   // warped / keyframe tile
+    const int SX = TX + 2 * R, SY = TY + 2 * R;         // photometric-term tile
+    extern __shared__ float patch_lds[];
+    float* kf = patch_lds;                  // 3 * HY * HX   keyframe + 0.5
+    float* wr = kf + 3 * HY * HX;           // 3 * HY * HX   warped + 0.5
+    float* es = wr + 3 * HY * HX;           // SY * SX       channel-weighted photometric term
+    float* kmu = es + SY * SX;              // 3 * SY * SX   keyframe 3x3 mean
+    float* ksg = kmu + 3 * SY * SX;         // 3 * SY * SX   keyframe 3x3 variance
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W, D = a.D;
+    const int b = blockIdx.z;
+    const int f = blockIdx.y / a.nchunk, chunk = blockIdx.y % a.nchunk;
+    const int d_lo = chunk * a.dchunk, d_hi = min(D, d_lo + a.dchunk);
+    const int ty0 = (blockIdx.x / a.tiles_x) * TY, tx0 = (blockIdx.x % a.tiles_x) * TX;
+    const int HWp = H * W;
+    const float* kimg = a.keyframe + (long long)b * 3 * HWp;
+
+    for (int i = tid; i < 3 * HY * HX; i += NT) {
+        const int c = i / (HY * HX), r = i % (HY * HX);
+        const int gy = ty0 - HALO + r / HX, gx = tx0 - HALO + r % HX;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = kimg[c * HWp + gy * W + gx] + 0.5f;
+        kf[i] = v;
+    }
+    __syncthreads();
+    if (MODE == 1 || MODE == 2) {
+        for (int i = tid; i < SX * SY; i += NT) {
+            const int qy = ty0 - R + i / SX, qx = tx0 - R + i % SX;
+            const bool in = qy >= 0 && qy < H && qx >= 0 && qx < W;
+            for (int c = 0; c < 3; ++c) {
+                float s1 = 0.f, s2 = 0.f;
+                if (in) {
+                    bool first = true;
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int ly = reflect_idx(qy + dy, H) - (ty0 - HALO), lx = reflect_idx(qx + dx, W) - (tx0 - HALO);
+                            const float k = kf[(c * HY + ly) * HX + lx];
+                            const float kk = k * k;
+                            if (first) { s1 = k; s2 = kk; first = false; } else { s1 = s1 + k; s2 = s2 + kk; }
+                        }
+                }
+                const float mu = s1 / 9.0f;
+                kmu[c * SY * SX + i] = mu;
+                ksg[c * SY * SX + i] = s2 / 9.0f - mu * mu;
+            }
+        }
+    }
+
+    const int oly = tid / TX, olx = tid % TX;
+    const int opy = ty0 + oly, opx = tx0 + olx;
+    const bool own_in = opy < H && opx < W;
+    const float* Ki = a.kinv + b * 9;
+    const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;
+    const float* P = a.proj + ((long long)b * a.F + f) * 12;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000);
+    float* sad_out = a.sfcv[f] + (long long)b * D * HWp + opy * W + opx;
+    bool hit_all = true;
+    float kraw[3] = {0.f, 0.f, 0.f};
+    if (PFLAG && own_in) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) kraw[c] = kimg[c * HWp + opy * W + opx];
+    }
+
+    for (int d = d_lo; d < d_hi; ++d) {
+        const float plane_depth = PIXD ? 0.f : a.depths[d];
+        const float* pd = PIXD ? a.pix_depths + ((long long)b * D + d) * HWp : nullptr;
+        bool pflag = true;
+        // ---- (a) warp every in-image position of the tile + halo; the thread of an interior pixel also keeps its flags ----
+        for (int i = tid; i < HX * HY; i += NT) {
+            const int ly = i / HX, lx = i % HX;
+            const int gy = ty0 - HALO + ly, gx = tx0 - HALO + lx;
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+            const bool interior = ly >= HALO && ly < HALO + TY && lx >= HALO && lx < HALO + TX;
+            if (interior) continue;                                     // interior pixels: below, by their own thread
+            float ray[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ray[k] = fmaf(Ki[3 * k + 2], 1.0f, fmaf(Ki[3 * k + 1], (float)gy, Ki[3 * k] * (float)gx));
+            const Sample sp = project(ray[0], ray[1], ray[2], PIXD ? pd[gy * W + gx] : plane_depth, P, H, W);
+            const Taps tp = tap_offsets(sp, H, W);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wr[(c * HY + ly) * HX + lx] = bilinear(img, c * HWp * 4, tp, sp) + 0.5f;
+        }
+        if (own_in) {
+            float ray[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ray[k] = fmaf(Ki[3 * k + 2], 1.0f, fmaf(Ki[3 * k + 1], (float)opy, Ki[3 * k] * (float)opx));
+            const Sample sp = project(ray[0], ray[1], ray[2], PIXD ? pd[opy * W + opx] : plane_depth, P, H, W);
+            hit_all = hit_all && mask_hit_r(sp, H, W, a.border);          // monorec_model.py:218-219
+            const Taps tp = tap_offsets(sp, H, W);
+            bool any_nz = false, all_eq = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float wv = bilinear(img, c * HWp * 4, tp, sp);
+                if (PFLAG) { any_nz = any_nz || wv != 0.f; all_eq = all_eq && wv == kraw[c]; }
+                wr[(c * HY + oly + HALO) * HX + olx + HALO] = wv + 0.5f;
+            }
+            pflag = any_nz || all_eq;                                    // :253
+        }
+        __syncthreads();
+        // ---- (b) photometric term on tile + R ------------------------------------------------------------------
+        for (int i = tid; i < SX * SY; i += NT) {
+            const int sy = i / SX, sx = i % SX;
+            const int qy = ty0 - R + sy, qx = tx0 - R + sx;
+            float e = 0.f;                                              // zero padding of the P x P box (:247)
+            if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+                int lyy[3], lxx[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    lyy[t] = reflect_idx(qy + t - 1, H) - (ty0 - HALO);
+                    lxx[t] = reflect_idx(qx + t - 1, W) - (tx0 - HALO);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sv = 0.f;
+                    if (MODE == 1 || MODE == 2) {
+                        float sx1 = 0.f, sx2 = 0.f, sxy = 0.f;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const int li = (c * HY + lyy[dy]) * HX + lxx[dx];
+                                const float x = wr[li], k = kf[li];
+                                const float xx = x * x, xk = x * k;
+                                if (dy == 0 && dx == 0) { sx1 = x; sx2 = xx; sxy = xk; }
+                                else { sx1 = sx1 + x; sx2 = sx2 + xx; sxy = sxy + xk; }
+                            }
+                        const float mu_x = div9(sx1), mu_y = kmu[c * SY * SX + i];
+                        const float mu_x_sq = mu_x * mu_x, mu_y_sq = mu_y * mu_y, mu_xy = mu_x * mu_y;
+                        const float sig_x = div9(sx2) - mu_x_sq;
+                        const float sig_xy = div9(sxy) - mu_xy;
+                        const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);                      // layers.py:133
+                        const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[c * SY * SX + i] + C2);  // layers.py:134
+                        sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);                           // layers.py:137
+                    }
+                    if (MODE == 0 || MODE == 2) {
+                        const int li = (c * HY + sy + 1) * HX + sx + 1;
+                        const float ad = fabsf(wr[li] - kf[li]);
+                        sv = MODE == 0 ? ad : 0.85f * sv + 0.15f * ad;
+                    }
+                    if (MODE == 3) {
+                        float acc = 0.f;
+                        bool first = true;
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                if (qy + dy < 0 || qy + dy >= H || qx + dx < 0 || qx + dx >= W) continue;   // zero padding
+                                const int li = (c * HY + sy + 1 + dy) * HX + sx + 1 + dx;
+                                const float ad = fabsf(wr[li] - kf[li]);
+                                acc = first ? ad : acc + ad;
+                                first = false;
+                            }
+                        sv = div9(acc);
+                    }
+                    e = (c == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[c], e);
+                }
+            }
+            es[i] = e;
+        }
+        __syncthreads();
+        // ---- (c) P x P box sum -> sad ----------------------------------------------------------------------------
+        if (own_in) {
+            float s = 0.f;
+            for (int dy = 0; dy <= 2 * R; ++dy)
+                for (int dx = 0; dx <= 2 * R; ++dx) {
+                    const float v = es[(oly + dy) * SX + olx + dx];
+                    s = (dy == 0 && dx == 0) ? v : s + v;
+                }
+            if (PFLAG) { if (!pflag) s = -s; }
+            else if (d == d_hi - 1 && !hit_all) s = -s;
+            sad_out[(long long)d * HWp] = s;
+        }
+    }
+    if (PFLAG && own_in && !hit_all)
+        atomicAnd((unsigned int*)a.cv + ((long long)b * D + f) * HWp + opy * W + opx, 0u);
+}
+
 // Per-pixel frame fusion (monorec_model.py:251-269) over the raw sad values kernel A left in the sfcv buffers.
 template <bool PFLAG>
 __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
@@ -362,7 +556,7 @@ __global__ __launch_bounds__(256) void cv_fuse_kernel(const CvArgs a) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int b = (int)(i / HWp), p = (int)(i % HWp);
         const int py = p / a.W, px = p % a.W;
-        const bool border = py >= 2 && py < a.H - 2 && px >= 2 && px < a.W - 2;     // mask_to_warp[0], :219
+        const bool border = py >= a.border && py < a.H - a.border && px >= a.border && px < a.W - a.border;     // mask_to_warp[0], :219
         float wgt[MR_MAX_FRAMES], vmask[MR_MAX_FRAMES];
         float wsum = 0.f;
 #pragma unroll
@@ -463,15 +657,58 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+template <int MODE>
+void launch_sad_patch(const CvArgs& k, int opt, int R, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (opt) {
+        case 1: hipLaunchKernelGGL((cv_sad_patch_kernel<MODE, 1>), grid, dim3(256), lds, stream, k, R); break;
+        case 2: hipLaunchKernelGGL((cv_sad_patch_kernel<MODE, 2>), grid, dim3(256), lds, stream, k, R); break;
+        case 3: hipLaunchKernelGGL((cv_sad_patch_kernel<MODE, 3>), grid, dim3(256), lds, stream, k, R); break;
+        default: hipLaunchKernelGGL((cv_sad_patch_kernel<MODE, 0>), grid, dim3(256), lds, stream, k, R); break;
+    }
+}
+
+int launch_cv_patch(const CvArgs& a, int mode, bool plane_flags, int R, hipStream_t stream) {
+    constexpr int TX = 32, TY = 8;
+    CvArgs k = a;
+    k.tiles_x = (a.W + TX - 1) / TX;
+    const int tiles = k.tiles_x * ((a.H + TY - 1) / TY);
+    int nchunk = 1;
+    while ((long long)tiles * a.F * a.B * nchunk < 1024 && (a.D / (nchunk * 2)) >= 4 && (a.D % (nchunk * 2)) == 0) nchunk *= 2;
+    k.nchunk = nchunk;
+    k.dchunk = a.D / nchunk;
+    const dim3 grid(tiles, a.F * nchunk, a.B);
+    const int opt = (a.pix_depths ? 1 : 0) | (plane_flags ? 2 : 0);
+    const int hx = TX + 2 * (R + 1), hy = TY + 2 * (R + 1), sx = TX + 2 * R, sy = TY + 2 * R;
+    const size_t lds = sizeof(float) * (size_t)(6 * hy * hx + 7 * sy * sx);
+    if (plane_flags) {
+        hipError_t e = hipMemsetAsync(a.cv, 0xff, (size_t)a.B * a.D * a.H * a.W * sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    switch (mode) {
+        case 0: launch_sad_patch<0>(k, opt, R, grid, lds, stream); break;
+        case 2: launch_sad_patch<2>(k, opt, R, grid, lds, stream); break;
+        case 3: launch_sad_patch<3>(k, opt, R, grid, lds, stream); break;
+        default: launch_sad_patch<1>(k, opt, R, grid, lds, stream); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long long total = (long long)a.B * a.H * a.W;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (plane_flags) hipLaunchKernelGGL(cv_fuse_kernel<true>, dim3(blocks), dim3(256), 0, stream, k);
+    else hipLaunchKernelGGL(cv_fuse_kernel<false>, dim3(blocks), dim3(256), 0, stream, k);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
-extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+extern "C" int mr_cost_volume_patch_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
                                        const float* kinv, const float* proj, const float* depths,
                                        int32_t batch, int32_t num_depths, int32_t height, int32_t width,
                                        float alpha, const float* channel_weights, int32_t use_ssim,
-                                       const float* pixel_depths, int32_t sfcv_mult_mask,
+                                       const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size,
                                        float* cost_volume, float* const* sfcv, void* stream) {
     if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
+    if (patch_size < 1 || patch_size > 7 || !(patch_size & 1)) return MR_ERR_UNSUPPORTED;
     if (!sfcv_mult_mask && num_depths < num_frames) return MR_ERR_UNSUPPORTED;      // validity words live in planes 0..F-1
     if (!keyframe || !frames || !kinv || !proj || (!depths && !pixel_depths) || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
@@ -488,9 +725,22 @@ extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const
     a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
     a.tiles_x = 0; a.nchunk = 1; a.dchunk = num_depths;
     a.alpha = alpha;
-    for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / 9.0f;
+    for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / (float)(patch_size * patch_size);      // :141
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
-    return launch_cv<32, 16>(a, use_ssim, !sfcv_mult_mask, (hipStream_t)stream);
+    a.border = patch_size / 2 + 1;                                                                   // :139
+    if (height < 2 * a.border + 1 || width < 2 * a.border + 1) return MR_ERR_BAD_ARGUMENT;
+    if (patch_size == 3) return launch_cv<32, 16>(a, use_ssim, !sfcv_mult_mask, (hipStream_t)stream);
+    return launch_cv_patch(a, use_ssim, !sfcv_mult_mask, patch_size / 2, (hipStream_t)stream);
+}
+
+extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                       const float* kinv, const float* proj, const float* depths,
+                                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                       float alpha, const float* channel_weights, int32_t use_ssim,
+                                       const float* pixel_depths, int32_t sfcv_mult_mask,
+                                       float* cost_volume, float* const* sfcv, void* stream) {
+    return mr_cost_volume_patch_f32(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                                    channel_weights, use_ssim, pixel_depths, sfcv_mult_mask, 3, cost_volume, sfcv, stream);
 }
 
 extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,

@@ -196,7 +196,7 @@ class Plan:
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
-                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False):
+                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -213,6 +213,7 @@ class Plan:
         self.pretrain_mode, self.no_cv = int(pretrain_mode), bool(no_cv)                  # monorec_model.py:680-727 (eval branches)
         self.mask_use_cv, self.mask_use_feats = bool(mask_use_cv), bool(mask_use_feats)   # :352-355
         self.simple_mask = bool(simple_mask)                                              # SimpleMaskModule, :388-473
+        self.cv_patch_size = int(cv_patch_size)                                           # :138-142,247
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
         self.sd = state
@@ -436,10 +437,16 @@ class Plan:
 
         def run_cv(stream):
             pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
-            _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
-                                                   depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
-                                                   1 if self.sfcv_mult_mask else 0,
-                                                   cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
+            if self.cv_patch_size == 3:
+                _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                                       depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
+                                                       1 if self.sfcv_mult_mask else 0,
+                                                       cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
+            else:
+                _lib.check(lib.mr_cost_volume_patch_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                                        depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
+                                                        1 if self.sfcv_mult_mask else 0, self.cv_patch_size,
+                                                        cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_patch_f32")
         if self.no_cv:                     # :682-686: zero volumes, never written (the in-place mask multiply keeps 0)
             sfcv.zero_()
             cv.zero_()

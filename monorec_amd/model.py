@@ -223,7 +223,7 @@ class MonoRecModel(nn.Module):
         self.freeze_resnet = freeze_resnet
         unsupported = dict(pretrain_mode=self.pretrain_mode not in (0, 1, 2, 3), use_mono=not (use_mono or use_stereo or no_cv),
                            use_ssim=use_ssim not in (True, False, 0, 1, 2, 3),
-                           cv_patch_size=cv_patch_size != 3, augmentation=augmentation not in (None, "none"))
+                           cv_patch_size=cv_patch_size not in (1, 3, 5, 7), augmentation=augmentation not in (None, "none"))
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(
@@ -306,7 +306,8 @@ class MonoRecModel(nn.Module):
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
                         use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
                         no_cv=self.no_cv, mask_use_cv=self.mask_use_cv or self.simple_mask,
-                        mask_use_feats=self.mask_use_feats or self.simple_mask, simple_mask=self.simple_mask)
+                        mask_use_feats=self.mask_use_feats or self.simple_mask, simple_mask=self.simple_mask,
+                        cv_patch_size=self.cv_patch_size)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()

@@ -260,6 +260,31 @@ def main():
     print("cv_no_mult_mask ok; oracle == reference on", len(diffs), "tensors; entries differing from the default masking:",
           int((masked_default[0] != sf[0]).sum()))
 
+    # ---- cv_patch_size != 3 (monorec_model.py:138-142,247): P x P matching patch, border radius P // 2 + 1 ---------------------
+    batch = synth.make_batch(2, 48, 80, 2, seed=39, hard_pose=False)
+    for patch in (1, 5, 7):
+        ref = Ref(cv_depth_steps=8, cv_patch_size=patch).eval()
+        dd = synth.clone_batch(batch)
+        dd["inv_depth_min"], dd["inv_depth_max"] = torch.tensor([0.33]), torch.tensor([0.0025])
+        dd["cv_depth_steps"] = torch.tensor([8], dtype=torch.int32)
+        with torch.no_grad():
+            dd = ref.cv_module(dd)
+        cv, sf = orc.cost_volume(batch, steps=8, patch_size=patch)
+        items_ref = {"cost_volume": dd["cost_volume"], **{f"sfcv{i}": t for i, t in enumerate(dd["single_frame_cvs"])}}
+        items_orc = {"cost_volume": cv, **{f"sfcv{i}": t for i, t in enumerate(sf)}}
+        store, diffs = {}, {}
+        for k in items_ref:
+            diffs[k] = float((items_ref[k] - items_orc[k]).abs().max())
+            assert diffs[k] == 0.0, f"oracle deviates from the reference on cv_patch{patch}/{k}: {diffs[k]}"
+            for kk, vv in sample_summary(items_ref[k]).items():
+                store[f"{k}.{kk}"] = vv
+            if patch in (1, 5):
+                store[f"{k}.full"] = items_ref[k].numpy()
+        store["meta"] = np.array([2, 48, 80, 2, 8, 39, 0, 0], dtype=np.int64)
+        np.savez_compressed(os.path.join(GOLDEN, f"cv_patch{patch}.npz"), **store)
+        report["cases"][f"cv_patch{patch}"] = {"config": f"cv_patch_size={patch}", "oracle_vs_reference_maxabs": diffs}
+        print(f"cv_patch{patch} ok; oracle == reference on", len(diffs), "tensors")
+
     # ---- model-level options of row f-4: pretrain_mode 1/2/3 in eval mode (monorec_model.py:693-727; the validation passes of
     #      configs/train/monorec/monorec_depth.json and monorec_mask.json run exactly this), no_cv (:680-686),
     #      mask_use_cv / mask_use_feats = False (:352-355).  One batch, one fixture file, keys "<case>.<tensor>".

@@ -323,12 +323,13 @@ def depth_module(sd, cost_volume_masked, keyframe, feats, prefix="depth_module")
 # MonoRecModel.forward (monorec_model.py:672-729)
 # ----------------------------------------------------------------------------------------
 def forward(sd, batch, inv_depth_min_max=(0.33, 0.0025), cv_depth_steps=32, stages=None, use_ssim=True, cv_depths=None,
-            sfcv_mult_mask=True, pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False):
+            sfcv_mult_mask=True, pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False,
+            cv_patch_size=3):
     """Returns the reference's output dict entries for eval mode (monorec_model.py:672-729); `pretrain_mode` as in :693-727."""
     with torch.no_grad():
         kf = batch["keyframe"]
         if not no_cv:                                                               # :680-686
-            cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, stages=stages,
+            cv, sfcvs = cost_volume(batch, inv_depth_min_max[0], inv_depth_min_max[1], cv_depth_steps, patch_size=cv_patch_size, stages=stages,
                                     use_ssim=use_ssim, cv_depths=cv_depths, sfcv_mult_mask=sfcv_mult_mask)
         else:
             cv = kf.new_zeros(kf.shape[0], cv_depth_steps, kf.shape[2], kf.shape[3])

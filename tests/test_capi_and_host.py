@@ -178,7 +178,7 @@ def test_public_attributes_are_json_serialisable():
 
 
 @pytest.mark.parametrize("kw", [dict(use_mono=False), dict(pretrain_mode=4), dict(use_ssim=4),
-                                dict(cv_patch_size=5), dict(augmentation="depth")])
+                                dict(cv_patch_size=4), dict(cv_patch_size=9), dict(augmentation="depth")])
 def test_unsupported_options_raise(kw):
     with pytest.raises(NotImplementedError):
         MonoRecModel(**kw)

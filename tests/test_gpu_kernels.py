@@ -233,7 +233,7 @@ def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
         assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
 
 
-def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True):
+def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch=3):
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)
     b, _, h, w = kf.shape
@@ -247,7 +247,12 @@ def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True):
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
-    if use_ssim == 1 and cv_depths is None and mult_mask:
+    if patch != 3:
+        _lib.check(lib.mr_cost_volume_patch_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
+                                                b, d, h, w, 10.0, cw, int(use_ssim),
+                                                None if cv_depths is None else cv_depths.data_ptr(), 1 if mult_mask else 0, int(patch),
+                                                cv.data_ptr(), sp, _stream()), "mr_cost_volume_patch_f32")
+    elif use_ssim == 1 and cv_depths is None and mult_mask:
         _lib.check(lib.mr_cost_volume_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
                                           b, d, h, w, 10.0, cw, cv.data_ptr(), sp, _stream()), "mr_cost_volume_f32")
     else:
@@ -329,6 +334,56 @@ def test_cost_volume_per_pixel_depths(hip_lib):
     assert ((cv - ocv).abs() > 1e-4).float().mean().item() <= 2e-4
     ucv, _ = _hip_cost_volume(batch, g.depths)
     assert (ucv - cv).abs().max().item() > 1e-2           # really different from the shared ladder
+
+
+def _volume_errors(got, want, tag):
+    d = (got - want).abs()
+    stats = {"max": d.max().item(), ">5e-6": (d > 5e-6).float().mean().item(), ">2e-5": (d > 2e-5).float().mean().item(),
+             ">1e-3": (d > 1e-3).float().mean().item()}
+    print(tag, {k: f"{v:.2e}" for k, v in stats.items()})
+    return stats
+
+
+@pytest.mark.parametrize("patch", [1, 5, 7])
+def test_cost_volume_patch_sizes(hip_lib, patch):
+    """cv_patch_size != 3 (monorec_model.py:138-142,247): generic P x P variant.
+    Leg 1, the reference fixture (written on the build container's CPU): tight - measured on MI355X: P = 1 bit-identical
+    (max |diff| 0.0), P = 5 6e-7 (only the order of the P x P sum differs from the reference's conv3d).
+    Leg 2, the oracle on THIS host's CPU: loose - another CPU moves the reference itself (measured: oracle-here vs fixture
+    = 9.6e-5 max on 26 % of the entries at P = 1, where nothing averages the ill-conditioned per-pixel SSIM ratio;
+    1.5e-5 at P = 5), exactly like leg 2 of test_cost_volume_matches_oracle_and_reference_fixture."""
+    g = Golden(f"cv_patch{patch}")
+    batch = g.make_inputs()
+    cv, sf = _hip_cost_volume(batch, g.depths, patch=patch)
+    assert not torch.isnan(cv).any() and not any(torch.isnan(s).any() for s in sf)
+    for f in range(g.frames):
+        print(f"patch{patch} sfcv{f} vs reference fixture", g.compare(f"sfcv{f}", sf[f], atol=2e-6, max_outlier_frac=1e-4))
+    print(f"patch{patch} cv vs reference fixture", g.compare("cost_volume", cv, atol=2e-5, max_outlier_frac=1e-3))
+    ocv, osf = orc.cost_volume(batch, steps=g.depths, patch_size=patch)
+    loose = 3e-4 if patch == 1 else 1e-4
+    for f in range(g.frames):
+        st = _volume_errors(sf[f], osf[f], f"patch{patch} sfcv{f} vs oracle on this host")
+        assert ((sf[f] - osf[f]).abs() > loose).float().mean().item() <= 1e-4, st
+    st = _volume_errors(cv, ocv, f"patch{patch} cv vs oracle on this host")
+    assert ((cv - ocv).abs() > 10 * loose).float().mean().item() <= 1e-4, st
+    br = patch // 2 + 1                                                      # the border of radius P // 2 + 1 is invalid
+    assert float(cv[:, :, :br].abs().max()) == 0 and float(cv[:, :, :, -br:].abs().max()) == 0
+    assert ((cv == 0) != (ocv == 0)).float().mean().item() <= 5e-4          # same validity pattern
+
+
+def test_cost_volume_patch_options_compose(hip_lib):
+    """The generic variant shares the option templates: absolute difference, per-plane flags and per-pixel depths with a 5x5 patch."""
+    batch = synth.make_batch(1, 40, 72, 2, seed=43, hard_pose=False)
+    pix = synth.make_pixel_depths(1, 8, 40, 72, seed=44)
+    for kw in (dict(use_ssim=False), dict(use_ssim=2, sfcv_mult_mask=False), dict(use_ssim=3, cv_depths=pix)):
+        ocv, osf = orc.cost_volume(batch, steps=8, patch_size=5, **kw)
+        cv, sf = _hip_cost_volume(batch, 8, use_ssim=int(kw.get("use_ssim", 1)), patch=5, mult_mask=kw.get("sfcv_mult_mask", True),
+                                  cv_depths=None if "cv_depths" not in kw else pix.to(DEV))
+        tag = {k: (v if not torch.is_tensor(v) else "pix") for k, v in kw.items()}
+        st = _volume_errors(sf[1], osf[1], f"{tag} sfcv1")
+        assert st[">2e-5"] <= 1e-3 and st[">1e-3"] <= 5e-4, (tag, st)
+        st = _volume_errors(cv, ocv, f"{tag} cv")
+        assert st[">1e-3"] <= 5e-3, (tag, st)
 
 
 def test_cost_volume_without_mult_mask(hip_lib):

@@ -274,6 +274,19 @@ def test_model_options_against_reference_fixture(hip_lib, case):
         assert float(out["cost_volume"].abs().max()) == 0.0 and len(out["single_frame_cvs"]) == len(batch["poses"])
 
 
+def test_cv_patch_size_through_the_model(hip_lib):
+    batch = synth.make_batch(1, 64, 96, 2, seed=45, hard_pose=False)
+    m = MonoRecModel(cv_depth_steps=8, cv_patch_size=5, hip_in_flight=1)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(_to_dev(batch))
+    torch.cuda.synchronize()
+    ref = orc.forward(sd, batch, cv_depth_steps=8, cv_patch_size=5)
+    _check_against(out, ref, "cv_patch_size=5")
+
+
 def test_depth_large_model(hip_lib):
     """depth_large_model=True (monorec_model.py:482-483): the plan takes the DepthModule widths from the weights."""
     g = Golden("small_large_depth")

@@ -120,6 +120,15 @@ def test_oracle_without_mult_mask_matches_reference_fixture():
         g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
 
 
+@pytest.mark.parametrize("patch", [1, 5, 7])
+def test_oracle_patch_sizes_match_reference_fixture(patch):
+    g = Golden(f"cv_patch{patch}")
+    cv, sf = orc.cost_volume(g.make_inputs(), steps=g.depths, patch_size=patch)
+    g.compare("cost_volume", cv, atol=ATOL, max_outlier_frac=FLIPS)
+    for i, t in enumerate(sf):
+        g.compare(f"sfcv{i}", t, atol=ATOL, max_outlier_frac=FLIPS)
+
+
 OPTION_CASES = {"pm1": dict(pretrain_mode=1), "pm2": dict(pretrain_mode=2), "pm3": dict(pretrain_mode=3),
                 "nocv": dict(no_cv=True), "mask_nocv": dict(mask_use_cv=False), "mask_nofeats": dict(mask_use_feats=False),
                 "simple": dict(simple_mask=True)}

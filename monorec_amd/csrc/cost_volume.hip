@@ -17,6 +17,9 @@
 //     sfcv = (1 - 2 sad) * valid (:251) and the fused volume (:262-269).  HBM-bound (reads F*D twice - the second
 //     time from L2 - writes F*D + D).
 //
+//  A' cv_sad_patch_kernel    the generic variant of A for cv_patch_size != 3 (P x P box, border radius P / 2 + 1): same
+//     arithmetic, strided loops instead of the hand-scheduled 3x3 tile; B is shared.
+//
 // Arithmetic follows the reference operation by operation with contraction disabled
 // (-ffp-contract=off) and explicit fmaf where the CPU reference fuses (MKL sgemm k-ascending FMA
 // chain; ATen grid_sampler unnormalise + bilinear FMA chain; see oracle/make_golden.py for the

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--spinup-seconds", type=float, default=3.0, help="minimum untimed spin-up before the timed steps")
+    ap.add_argument("--bf16x3", action="store_true",
+                    help="EXPERIMENTAL: convolutions as three bf16 MFMAs over hi/lo bf16 splits of both operands (fp32-class accuracy, "
+                         "4e-6 in CPU emulation; not yet validated on hardware - never the headline until it is)")
     ap.add_argument("--bf16", action="store_true",
                     help="convolutions on the bf16 MFMA (BASELINE configs[4] numerics; outside the 1e-4 parity bar - never the headline)")
     ap.add_argument("--in-flight", type=int, default=2,
@@ -214,6 +217,8 @@ def prime_device(args, dev_index):
            "--frames", str(args.frames), "--depths", str(args.depths), "--in-flight", str(args.in_flight)]
     if args.bf16:
         cmd.append("--bf16")
+    if args.bf16x3:
+        cmd.append("--bf16x3")
     if args.graph:
         cmd.append("--graph")
     try:
@@ -252,7 +257,8 @@ def main():
 
     from monorec_amd import MonoRecModel, synth
 
-    model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16)
+    model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16,
+                         hip_bf16x3=args.bf16x3)
     sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -326,7 +332,7 @@ def main():
         achieved = conv_flops / conv_s / 1e12
         cv_row = next(r for r in rows if r["name"] == "cost_volume")
         shape = (args.batch, args.height, args.width, args.frames, args.depths)
-        is_c2_fp32 = shape == (1, 256, 512, 2, 32) and not args.bf16        # the committed profiles are of this command
+        is_c2_fp32 = shape == (1, 256, 512, 2, 32) and not (args.bf16 or args.bf16x3)        # the committed profiles are of this command
         traffic, traffic_src = committed_pmc_traffic() if is_c2_fp32 else (None, None)
         prof_avg, prof_src = committed_kernel_average() if is_c2_fp32 else (None, None)
         cfg_name = {(1, 256, 512, 2, 32): "c2 (BASELINE configs[1])", (8, 256, 512, 4, 64): "c3 (BASELINE configs[2])"}.get(shape, "custom")
@@ -344,11 +350,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.bf16 else "f32",
+            "dtype": "bf16x3" if args.bf16x3 else ("bf16" if args.bf16 else "f32"),
             "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {args.batch} keyframe(s)/step/GPU, {args.height}x{args.width}, "
                                    f"{args.frames} source frames, {args.depths} depth bins, "
-                                   + ("bf16 MFMA convolutions (fp32 storage and cost volume), " if args.bf16 else "fp32, ") + "random-init weights",
+                                   + ("bf16x3 split-MFMA convolutions (experimental; fp32 storage and cost volume), " if args.bf16x3 else
+                                      "bf16 MFMA convolutions (fp32 storage and cost volume), " if args.bf16 else "fp32, ") + "random-init weights",
                        "batch_per_gpu": args.batch, "hip_graph": args.graph, "keyframes_in_flight": args.in_flight,
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else

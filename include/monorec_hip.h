@@ -29,6 +29,7 @@ extern "C" {
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
+#define MR_COMPUTE_BF16X3 2
 
 #define MR_ERR_BAD_ARGUMENT (-1)
 #define MR_ERR_UNSUPPORTED  (-2)
@@ -118,7 +119,12 @@ typedef struct mr_conv_desc {
      * MR_COMPUTE_BF16: v_mfma_f32_16x16x16_bf16 - packed_weights / phase_weights from mr_conv_pack_weights_bf16, the
      * activations (still fp32 in memory) are rounded to bf16 (nearest even) as the B fragment is formed, fp32 accumulate:
      * the numerics of "bf16 weights and activations, fp32 accumulate" (BASELINE configs[4]).  chunk_channels in
-     * {16, 32, 64, 128}; LDS-DMA staged inputs only (in_mode DIRECT / UPSAMPLE2, no in_transform). */
+     * {16, 32, 64, 128}; LDS-DMA staged inputs only (in_mode DIRECT / UPSAMPLE2, no in_transform).
+     * MR_COMPUTE_BF16X3 (EXPERIMENTAL, not yet validated on hardware): fp32-class accuracy on the bf16 matrix cores - every
+     * operand is split into hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits together) and a*b is evaluated as
+     * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation (three v_mfma_f32_16x16x16_bf16 per 16 channels instead of
+     * four v_mfma_f32_16x16x4_f32, which run at 1/16 of the rate).  Weights from mr_conv_pack_weights_bf16x3; the same
+     * restrictions as MR_COMPUTE_BF16.  CPU emulation over the whole network: depth error 4e-6 (fp32 path 1.3e-6, bar 1e-4). */
     int32_t compute_dtype;
 } mr_conv_desc;
 
@@ -143,6 +149,14 @@ size_t mr_conv_packed_weight_floats_bf16(int32_t out_channels, const int32_t* sr
 int mr_conv_pack_weights_bf16(const float* weight, int32_t out_channels, const int32_t* src_channels,
                               int32_t num_src, int32_t kh, int32_t kw, int32_t cout_blocks_per_wg,
                               int32_t chunk_channels, float* dst);
+
+/* ... and for MR_COMPUTE_BF16X3 launches: per lane and k-step 4 bf16 `hi` followed by 4 bf16 `lo` (16 bytes), weight image twice
+ * the bf16 one (= the fp32 size for 16-aligned channel counts). */
+size_t mr_conv_packed_weight_floats_bf16x3(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                           int32_t kh, int32_t kw, int32_t cout_blocks_per_wg, int32_t chunk_channels);
+int mr_conv_pack_weights_bf16x3(const float* weight, int32_t out_channels, const int32_t* src_channels,
+                                int32_t num_src, int32_t kh, int32_t kw, int32_t cout_blocks_per_wg,
+                                int32_t chunk_channels, float* dst);
 
 /* bytes of dynamic LDS the launch will request (for planning / tests); negative MR_ERR_* if invalid */
 int64_t mr_conv2d_lds_bytes(const mr_conv_desc* desc);

@@ -64,6 +64,11 @@ ABI = {
                                                 ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv_packed_weight_floats_bf16": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
                                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mr_conv_packed_weight_floats_bf16x3": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mr_conv_pack_weights_bf16x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.c_void_p]),
     "mr_conv_pack_weights_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_void_p]),

@@ -70,7 +70,7 @@ struct ConvKArgs {
     int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores,
                                // 16 per-workgroup timestamps (tools/wg_timeline.py)
     int ksplit, nchunks, batch, nphase;
-    int bf16;                  // 1: bf16 MFMA mode (weights bf16, activations rounded to bf16 in the B fragment)
+    int bf16;                  // 1: bf16 MFMA mode (weights bf16, activations rounded to bf16 in the B fragment): half-size weight blocks
     int tiles_y, ngroups, ks_shift;   // ks_shift: log2(ksplit) or -1
     long long wgroup_stride;   // packed floats per cout group
     float* ws;
@@ -378,10 +378,65 @@ __device__ __forceinline__ void sweep_chunk_bf16(const ConvKArgs& a, f32x4 (&acc
     }
 }
 
+// ---- bf16x3 sweep (MR_COMPUTE_BF16X3): fp32-class accuracy on the bf16 matrix cores ------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) carries 16 mantissa bits; a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (the dropped
+// lo*lo term and the two roundings are ~2^-16 relative), products exact, fp32 accumulate.  The fp32 MFMA of gfx950 runs at 1/16 of
+// the bf16 rate, so three bf16 MFMAs per 16 channels replace four fp32 MFMAs (16x16x4) at 3/16 of their matrix-core time.
+// Weights arrive pre-split (mr_conv_pack_weights_bf16x3: per lane 4 hi + 4 lo bf16 = 16 bytes, one ds_read_b128), activations
+// stay fp32 in HBM / LDS and are split while the B fragment is formed.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(short h) {
+    return __builtin_bit_cast(float, (unsigned)(unsigned short)h << 16);
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void kstep_bf16x3(f32x4 (&acc)[MB][NB], const float* __restrict__ wt, const float* __restrict__ ldsI,
+                                             const int (&lbase)[NB], int c16, int off, int plane4) {
+    s16x4 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        union { f32x4 f; s16x8 v; } u;
+        u.f = *(const f32x4*)(wt + (c16 * MB + m) * 256);                   // wt already includes lane * 4
+        ah[m] = (s16x4){u.v[0], u.v[1], u.v[2], u.v[3]};
+        al[m] = (s16x4){u.v[4], u.v[5], u.v[6], u.v[7]};
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float* p = ldsI + lbase[i] + off;
+        const float x0 = p[0], x1 = p[plane4], x2 = p[2 * plane4], x3 = p[3 * plane4];
+        bh[i] = pack_bf16x4(x0, x1, x2, x3);
+        bl[i] = pack_bf16x4(x0 - bf16_bits_to_f32(bh[i][0]), x1 - bf16_bits_to_f32(bh[i][1]),
+                            x2 - bf16_bits_to_f32(bh[i][2]), x3 - bf16_bits_to_f32(bh[i][3]));
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {                                     // small terms first
+            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[m], bh[i], acc[m][i], 0, 0, 0);
+            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[m], bl[i], acc[m][i], 0, 0, 0);
+            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[m], bh[i], acc[m][i], 0, 0, 0);
+        }
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void sweep_chunk_bf16x3(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
+                                                   const int (&lbase)[NB], int ck16, int lane) {
+    const float* wl = ldsW + lane * 4;
+    const int plane4 = 4 * a.PLANE;
+    for (int kh = 0; kh < a.KH; ++kh) {
+        for (int kw = 0; kw < a.KW; ++kw) {
+            const int tapoff = kh * a.IWa + kw;
+            const float* wt = wl + (kh * a.KW + kw) * ck16 * (MB * 256);
+            for (int c16 = 0; c16 < ck16; ++c16) kstep_bf16x3<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
+        }
+    }
+}
+
 // DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
 // max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
 // make hipcc drain vmcnt before every sweep and spill SGPRs).
-template <int MB, int NB, bool DMA_IN, int WV, bool BF16>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16>
 __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     dbg_stamp(a, 0);
@@ -497,7 +552,8 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
         }
         if (stamp) dbg_stamp(a, 5);
         if (!MR_DBG(1)) {
-            if (BF16) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
+            if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
+            else if (BF16 == 1) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
             else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
         }
         if (stamp) dbg_stamp(a, 6);
@@ -613,6 +669,7 @@ struct Derived {
     ConvKArgs k;
     size_t lds_bytes;
     int mb, nb, wv;
+    int mode;                  // MR_COMPUTE_*: 0 fp32 MFMA, 1 bf16, 2 bf16x3 split
     dim3 grid;
 };
 
@@ -645,10 +702,11 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.in_mode = d->in_mode;
     k.in_tf = d->in_transform;
     k.CK = d->chunk_channels;
-    const int bf16 = d->compute_dtype == MR_COMPUTE_BF16 ? 1 : 0;
+    const int bf16 = d->compute_dtype == MR_COMPUTE_BF16 ? 1 : d->compute_dtype == MR_COMPUTE_BF16X3 ? 2 : 0;
     if (d->compute_dtype != MR_COMPUTE_F32 && !bf16) return MR_ERR_BAD_ARGUMENT;
     if (bf16 && k.CK < 16) return MR_ERR_BAD_ARGUMENT;
-    k.bf16 = bf16;
+    k.bf16 = bf16 == 1 ? 1 : 0;       // device side: size of a weight block only (bf16x3 blocks are as large as fp32 ones)
+    out->mode = bf16;
     int nchunks = 0, cpad_total = 0;
     for (int s = 0; s < d->num_src; ++s) {
         if (!d->src[s] || d->src_channels[s] < 1) return MR_ERR_BAD_ARGUMENT;
@@ -717,13 +775,13 @@ int derive(const mr_conv_desc* d, Derived* out) {
         k.PLANE = plane; k.ppt = mr_ceil_div(k.IH * k.IW, 256); if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED; }
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
     const int taps = k.KH * k.KW;
-    k.wgroup_stride = (long long)taps * cpad_total * mb * (bf16 ? 8 : 16);
+    k.wgroup_stride = (long long)taps * cpad_total * mb * (bf16 == 1 ? 8 : 16);
     int ck_max = 0;                                              // largest chunk of any source
     for (int s = 0; s < d->num_src; ++s) {
         const int c = k.src_cpad[s] < k.CK ? k.src_cpad[s] : k.CK;
         if (c > ck_max) ck_max = c;
     }
-    k.wmax_floats = taps * ck_max * mb * (bf16 ? 8 : 16);
+    k.wmax_floats = taps * ck_max * mb * (bf16 == 1 ? 8 : 16);
     // two pipeline buffers - one when no workgroup ever streams a second chunk
     const int nbuf = mr_ceil_div(nchunks, d->split_k) > 1 ? 2 : 1;
     out->lds_bytes = nbuf * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);
@@ -744,7 +802,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB, bool DMA_IN, int WV, bool BF16>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16>
 int launch(const Derived& dv, hipStream_t stream) {
     static bool attr_set = false;  // raise the dynamic-LDS ceiling once per instantiation
     if (!attr_set) {
@@ -759,13 +817,17 @@ int launch(const Derived& dv, hipStream_t stream) {
 
 template <int MB, int NB>
 int launch_variant(const Derived& dv, hipStream_t stream) {
-    if (dv.k.bf16) {                                   // LDS-DMA staging only (derive() checked)
-        if (dv.wv == 8) return launch<MB, NB, true, 8, true>(dv, stream);
-        return launch<MB, NB, true, 4, true>(dv, stream);
+    if (dv.mode == 2) {                                // LDS-DMA staging only (derive() checked)
+        if (dv.wv == 8) return launch<MB, NB, true, 8, 2>(dv, stream);
+        return launch<MB, NB, true, 4, 2>(dv, stream);
     }
-    if (dv.wv == 8) return launch<MB, NB, true, 8, false>(dv, stream);     // dwordx4 DMA path only (derive() checked)
-    if (dv.k.dma_in) return launch<MB, NB, true, 4, false>(dv, stream);
-    return launch<MB, NB, false, 4, false>(dv, stream);
+    if (dv.mode == 1) {
+        if (dv.wv == 8) return launch<MB, NB, true, 8, 1>(dv, stream);
+        return launch<MB, NB, true, 4, 1>(dv, stream);
+    }
+    if (dv.wv == 8) return launch<MB, NB, true, 8, 0>(dv, stream);         // dwordx4 DMA path only (derive() checked)
+    if (dv.k.dma_in) return launch<MB, NB, true, 4, 0>(dv, stream);
+    return launch<MB, NB, false, 4, 0>(dv, stream);
 }
 
 template <int MB>
@@ -867,6 +929,53 @@ extern "C" int mr_conv_pack_weights_bf16(const float* weight, int32_t out_channe
                                         v = weight[((size_t)cout * cin_total + (cin_off + cl)) * taps + tap];
                                     *o++ = bf16_rne(v);
                                 }
+            }
+            cin_off += src_channels[s];
+        }
+    }
+    return 0;
+}
+
+extern "C" size_t mr_conv_packed_weight_floats_bf16x3(int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                                      int32_t kh, int32_t kw, int32_t mb, int32_t ck) {
+    return 2 * mr_conv_packed_weight_floats_bf16(out_channels, src_channels, num_src, kh, kw, mb, ck);
+}
+
+extern "C" int mr_conv_pack_weights_bf16x3(const float* weight, int32_t out_channels, const int32_t* src_channels,
+                                           int32_t num_src, int32_t kh, int32_t kw, int32_t mb, int32_t ck, float* dst) {
+    if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES) return MR_ERR_BAD_ARGUMENT;
+    if (!valid_mb(mb) || !valid_ck(ck) || ck < 16) return MR_ERR_BAD_ARGUMENT;
+    const int groups = mr_ceil_div(mr_ceil_div(out_channels, 16), mb);
+    const int taps = kh * kw;
+    int cin_total = 0;
+    for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
+    uint16_t* o = (uint16_t*)dst;
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = mr_pad16(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += ck) {
+                const int ckq = cpad - c0 < ck ? cpad - c0 : ck;
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int c16 = 0; c16 < ckq / 16; ++c16)
+                        for (int m = 0; m < mb; ++m)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                uint16_t hi[4], lo[4];                       // same element order as the bf16 layout
+                                for (int j = 0; j < 4; ++j) {
+                                    const int cout = (g * mb + m) * 16 + (lane & 15);
+                                    const int cl = c0 + c16 * 16 + 4 * j + (lane >> 4);
+                                    float v = 0.f;
+                                    if (cout < out_channels && cl < src_channels[s])
+                                        v = weight[((size_t)cout * cin_total + (cin_off + cl)) * taps + tap];
+                                    hi[j] = bf16_rne(v);
+                                    const uint32_t hb = (uint32_t)hi[j] << 16;
+                                    float hf;
+                                    memcpy(&hf, &hb, 4);
+                                    lo[j] = bf16_rne(v - hf);
+                                }
+                                for (int j = 0; j < 4; ++j) *o++ = hi[j];
+                                for (int j = 0; j < 4; ++j) *o++ = lo[j];
+                            }
             }
             cin_off += src_channels[s];
         }

@@ -39,14 +39,16 @@ def same_pad(n, k, s):
 def pack_conv_weight(weight, src_channels, mb, ck, bf16=False):
     """(Cout, sum(src_channels), kh, kw) fp32 CPU tensor -> packed A-fragment stream (CPU tensor) for a
     launch with `mb` cout blocks per workgroup and `ck` channels per LDS chunk (csrc/conv_layout.h);
-    bf16=True: the bf16 stream of MR_COMPUTE_BF16 launches."""
+    bf16 = compute mode: 0 / False fp32, 1 / True the bf16 stream of MR_COMPUTE_BF16 launches, 2 the hi / lo bf16 pairs of
+    MR_COMPUTE_BF16X3."""
     lib = _lib.load()
     w = weight.detach().to(torch.float32).contiguous().cpu()
     cout, cin, kh, kw = w.shape
     assert cin == sum(src_channels), (cin, src_channels)
     sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
-    count, pack = ((lib.mr_conv_packed_weight_floats_bf16, lib.mr_conv_pack_weights_bf16) if bf16 else
-                   (lib.mr_conv_packed_weight_floats, lib.mr_conv_pack_weights_f32))
+    count, pack = {0: (lib.mr_conv_packed_weight_floats, lib.mr_conv_pack_weights_f32),
+                   1: (lib.mr_conv_packed_weight_floats_bf16, lib.mr_conv_pack_weights_bf16),
+                   2: (lib.mr_conv_packed_weight_floats_bf16x3, lib.mr_conv_pack_weights_bf16x3)}[int(bf16)]
     n = count(cout, sc, len(src_channels), kh, kw, mb, ck)
     assert n > 0, (mb, ck)
     out = torch.empty(n, dtype=torch.float32)
@@ -107,7 +109,7 @@ def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False):
     ck_max = max(min(c, ck) for c in cpads)
     nchunks = sum(math.ceil(c / ck) for c in cpads)
     nbuf = 2 if math.ceil(nchunks / split_k) > 1 else 1
-    return nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if bf16 else 16))
+    return nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if int(bf16) == 1 else 16))    # bf16x3 blocks: hi + lo = fp32 size
 
 
 TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
@@ -127,7 +129,7 @@ _load_tuned()
 
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False):
     return (f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
-            + ("_bf16" if bf16 else ""))
+            + ("", "_bf16", "_bf16x3")[int(bf16)])
 
 
 def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False):
@@ -215,7 +217,7 @@ class Plan:
         self.simple_mask = bool(simple_mask)                                              # SimpleMaskModule, :388-473
         self.cv_patch_size = int(cv_patch_size)                                           # :138-142,247
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
-        self.bf16 = bool(bf16)        # convolutions through the bf16 MFMA (MR_COMPUTE_BF16); everything else stays fp32
+        self.bf16 = int(bf16)         # convolutions: 0 fp32 MFMA, 1 bf16 MFMA (MR_COMPUTE_BF16), 2 bf16x3 split (MR_COMPUTE_BF16X3); everything else fp32
         self.sd = state
         self.buf = {}
         self.keep = []          # packed weights / biases (device tensors kept alive)
@@ -274,7 +276,7 @@ class Plan:
         assert cin == sum(src_channels), (name, cin, src_channels)
         out_h, out_w = grid
         nph = 1 if phases is None else len(phases)
-        bf16 = self.bf16 and in_mode != IN_MAXPOOL2 and tf == TF_NONE       # bf16 mode needs the LDS-DMA staging
+        bf16 = self.bf16 if (in_mode != IN_MAXPOOL2 and tf == TF_NONE) else 0   # the bf16 modes need the LDS-DMA staging
         sched = self.schedule_override.get(name) or choose_schedule(cout, src_channels, kh, kw, stride[0], stride[1],
                                                                     out_h, out_w, n, nph, bf16)
         mb, nb, split_k, ck = sched[:4]
@@ -307,7 +309,7 @@ class Plan:
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
         d.waves_per_wg = waves
-        d.compute_dtype = 1 if bf16 else 0
+        d.compute_dtype = int(bf16)
         if split_k > 1:
             self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
                                          split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)

@@ -198,7 +198,7 @@ class MonoRecModel(nn.Module):
                  pretrain_dropout_mode=0, augmentation=None, use_mono=True, use_stereo=False, use_ssim=True,
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
-                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False):
+                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -231,8 +231,10 @@ class MonoRecModel(nn.Module):
                 f"unsupported non-default options: {bad} (SURVEY.md section 8 f-4)")
         self._hip_graph = bool(hip_graph)
         self._in_flight = max(1, int(hip_in_flight))
-        self._bf16 = bool(hip_bf16)     # convolutions on the bf16 MFMA (weights/activations rounded to bf16, fp32 accumulate):
-                                        # BASELINE configs[4]; NOT within the 1e-4 parity bar of the fp32 default
+        # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
+        # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL and not
+        # yet validated on hardware: hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
+        self._bf16 = 2 if hip_bf16x3 else (1 if hip_bf16 else 0)
         self._next_slot = 0
         self._plans = {}
         self._graphs = {}

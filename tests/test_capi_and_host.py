@@ -262,6 +262,44 @@ def test_bf16_weight_packing_layout(hip_lib):
     assert o == u16.size
 
 
+def test_bf16x3_weight_packing_layout(hip_lib):
+    """mr_conv_pack_weights_bf16x3: the bf16 element order, per lane 4 `hi` = bf16(w) followed by 4 `lo` = bf16(w - hi); hi + lo
+    carries 16 mantissa bits of the weight."""
+    import numpy as np
+    g = torch.Generator().manual_seed(3)
+    srcs, cout, kh, kw, mb, ck = [20, 5], 40, 1, 3, 2, 16
+    w = torch.randn(cout, sum(srcs), kh, kw, generator=g)
+    packed = engine.pack_conv_weight(w, srcs, mb, ck, bf16=2)
+    assert packed.numel() == 2 * engine.pack_conv_weight(w, srcs, mb, ck, bf16=1).numel()
+    u16 = packed.numpy().view(np.uint16)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    hi_bits, lo_bits = (t.view(torch.int16).numpy().view(np.uint16) for t in (hi, lo))
+    assert ((hi.float() + lo.float() - w).abs() <= w.abs() * 2.0 ** -16).all()
+    o = 0
+    groups = -(-(-(-cout // 16)) // mb)
+    for grp in range(groups):
+        cin_off = 0
+        for sc in srcs:
+            cpad = -(-sc // 16) * 16
+            for c0 in range(0, cpad, ck):
+                ckq = min(ck, cpad - c0)
+                for tap in range(kh * kw):
+                    for c16 in range(ckq // 16):
+                        for m in range(mb):
+                            blk = u16[o:o + 512].reshape(64, 8)
+                            o += 512
+                            for lane in (0, 17, 35, 63):
+                                for j in range(4):
+                                    co, cl = (grp * mb + m) * 16 + (lane & 15), c0 + c16 * 16 + 4 * j + (lane >> 4)
+                                    inside = co < cout and cl < sc
+                                    idx = (co, cin_off + cl, tap // kw, tap % kw)
+                                    assert blk[lane, j] == (hi_bits[idx] if inside else 0), (grp, sc, c0, tap, c16, m, lane, j)
+                                    assert blk[lane, 4 + j] == (lo_bits[idx] if inside else 0), (grp, sc, c0, tap, c16, m, lane, j)
+            cin_off += sc
+    assert o == u16.size
+
+
 def test_dropin_rebinds_the_names_the_reference_scripts_look_up(tmp_path):
     """python -m monorec_amd.dropin <script>: a miniature checkout with the reference's import structure (model/model.py re-export,
     model/metric.py star imports, utils/__init__.py star import) - the script itself is untouched."""
@@ -314,7 +352,7 @@ def test_python_lds_model_bounds_the_library(hip_lib):
               (48, [35], 7, 1, 1, 1, 256, 512), (64, [48], 1, 7, 1, 2, 128, 256), (1, [24], 3, 3, 1, 1, 256, 512),
               (512, [512], 3, 3, 1, 1, 8, 16), (256, [128], 1, 1, 2, 2, 16, 32), (24, [32], 3, 3, 1, 1, 50, 70)]
     checked = 0
-    for (cout, srcs, kh, kw, sh, sw, oh, ow), bf16 in itertools.product(shapes, (False, True)):
+    for (cout, srcs, kh, kw, sh, sw, oh, ow), bf16 in itertools.product(shapes, (0, 1, 2)):      # fp32, bf16, bf16x3
         cands = engine.candidate_schedules(cout, srcs, kh, kw, sh, sw, oh, ow, 1, lds_cap=160 * 1024, bf16=bf16)
         for cd in rnd.sample(cands, min(len(cands), 25)):
             d = _lib.ConvDesc()
@@ -327,13 +365,13 @@ def test_python_lds_model_bounds_the_library(hip_lib):
             d.dst_plane_h, d.dst_plane_w, d.out_step_h, d.out_step_w = oh, ow, 1, 1
             d.packed_weights = 16
             d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = cd["mb"], cd["nb"], cd["split_k"], cd["ck"]
-            d.waves_per_wg, d.compute_dtype = cd["waves"], 1 if bf16 else 0
+            d.waves_per_wg, d.compute_dtype = cd["waves"], bf16
             got = int(hip_lib.mr_conv2d_lds_bytes(ctypes.byref(d)))
             if got == -2 and cd["waves"] == 8:            # 8-wave tiles need the dwordx4 path: legitimately refused for some geometries
                 continue
             assert 0 < got <= cd["lds"] <= 160 * 1024, (cout, srcs, kh, kw, cd, got)
             checked += 1
-    assert checked > 200
+    assert checked > 300
 
 
 def test_frame_cache_reads_ahead_on_worker_threads():

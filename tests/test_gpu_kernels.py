@@ -2,6 +2,7 @@
 references, every call going through the C ABI (monorec_amd.engine.Plan -> ctypes -> mr_*)."""
 import ctypes
 import math
+import os
 
 import pytest
 import torch
@@ -186,6 +187,53 @@ BF16_CASES = [
     ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, False, (4, 1, 1, 16, 8)),
     ((24,), 1, (3, 3), (1, 1), (1, 1), (32, 64), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, False, (1, 4, 1, 32, 4)),
 ]
+
+
+# MR_COMPUTE_BF16X3 was written after this round's GPU budget was spent: compiled for gfx950, host side tested, never launched.
+# A faulting kernel would take the whole pytest process down, so these run only on request (MR_TEST_EXPERIMENTAL=1).
+experimental = pytest.mark.skipif(os.environ.get("MR_TEST_EXPERIMENTAL") != "1",
+                                  reason="bf16x3 mode not yet validated on hardware; set MR_TEST_EXPERIMENTAL=1")
+
+
+@experimental
+@pytest.mark.parametrize("case", BF16_CASES, ids=[f"bf16x3conv{i}" for i in range(len(BF16_CASES))])
+def test_bf16x3_conv_matches_fp32_reference(hip_lib, case):
+    """MR_COMPUTE_BF16X3: hi/lo bf16 split of both operands, three bf16 MFMAs per product - against the float64 convolution of
+    the UNROUNDED operands to 2^-15 relative (fp32-class), i.e. ~100x closer than the plain bf16 mode."""
+    srcs_c, cout, k, stride, pad, (hs, ws), n, act, in_mode, use_res, sched = case
+    g = torch.Generator().manual_seed(11)
+    srcs = [torch.randn(n, c, hs, ws, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    weight = torch.randn(cout, cin, *k, generator=g) / math.sqrt(cin * k[0] * k[1])
+    bias = torch.randn(cout, generator=g)
+    x = torch.cat(srcs, 1)
+    if in_mode == IN_UPSAMPLE2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    hin, win = x.shape[2], x.shape[3]
+    ho = (hin + 2 * pad[0] - k[0]) // stride[0] + 1
+    wo = (win + 2 * pad[1] - k[1]) // stride[1] + 1
+    if in_mode == IN_UPSAMPLE2:
+        ho, wo = hin, win
+        xr = F.pad(x, [0, 1, 0, 1])
+    else:
+        xr = F.pad(x, [pad[1], pad[1], pad[0], pad[0]])
+    ref = F.conv2d(xr.double(), weight.double(), bias.double(), stride=stride).float()[:, :, :ho, :wo]
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    p0, p1 = (0.1, 0.0) if act == ACT_LEAKY_RELU else (0.0025, 0.33)
+    ref = _act_ref(ref, act, p0, p1)
+    plan = engine.Plan.bare(DEV, schedule_override={"t": sched}, bf16=2)
+    out = plan.alloc("out", n, cout, ho, wo)
+    out.fill_(float("nan"))
+    plan.conv("main", "t", [s.to(DEV) for s in srcs], weight, bias, out, stride=stride, pad=pad, grid=(ho, wo),
+              act=act, p0=p0, p1=p1, in_mode=in_mode, residual=res.to(DEV) if use_res else None)
+    assert plan.conv_log[0]["bf16"] == 2
+    _run(plan)
+    got = out.cpu()
+    assert not torch.isnan(got).any()
+    err = (got - ref).abs().max().item()
+    assert err < 6e-5 * max(1.0, ref.abs().max().item()), err
 
 
 @pytest.mark.parametrize("case", BF16_CASES, ids=[f"bf16conv{i}" for i in range(len(BF16_CASES))])

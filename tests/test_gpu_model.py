@@ -1,5 +1,7 @@
 """GPU (MI355X): end-to-end parity of monorec_amd.MonoRecModel against the CPU oracle and the
 committed outputs of the real reference (tests/golden), through the drop-in dict API."""
+import os
+
 import pytest
 import torch
 
@@ -324,6 +326,22 @@ def test_bf16_mode_end_to_end(hip_lib):
     assert 1e-6 < err.max().item() < 5e-2 and err.mean().item() < 5e-3      # bf16-sized error, not garbage, not fp32
     # the unmasked part of the cost volume comes from the fp32 cost-volume kernel; only the bf16 mask scales it
     assert cverr < 5e-2
+
+
+@pytest.mark.skipif(os.environ.get("MR_TEST_EXPERIMENTAL") != "1",
+                    reason="bf16x3 mode not yet validated on hardware; set MR_TEST_EXPERIMENTAL=1")
+def test_bf16x3_mode_end_to_end(hip_lib):
+    """hip_bf16x3=True: convolutions as three bf16 MFMAs over hi/lo splits.  CPU emulation of this arithmetic over the whole network
+    gives 4e-6 on the depth (fp32 path: 1.3e-6): it has to meet the same 1e-4 bar as the fp32 default."""
+    m = MonoRecModel(cv_depth_steps=16, hip_in_flight=1, hip_bf16x3=True)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    batch = synth.make_batch(1, 128, 192, 2, seed=3)
+    with torch.no_grad():
+        out = m(_to_dev(batch))
+    torch.cuda.synchronize()
+    _check_against(out, orc.forward(sd, batch, cv_depth_steps=16), "bf16x3")
 
 
 def test_batch_independence(hip_lib):

@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--finalists", type=int, default=4, help="candidates re-timed in the second pass")
     ap.add_argument("--final-reps", type=int, default=20, help="launches per round of the second pass (0 = skip it)")
     ap.add_argument("--bf16", action="store_true", help="tune the MR_COMPUTE_BF16 launches (hip_bf16=True plans)")
+    ap.add_argument("--bf16x3", action="store_true", help="tune the MR_COMPUTE_BF16X3 launches (hip_bf16x3=True plans)")
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
     model = MonoRecModel(cv_depth_steps=args.depths)
     sd = synth.seeded_state_dict(model.state_dict())
     engine.TUNED.clear()
-    plan = engine.Plan(sd, args.batch, args.height, args.width, args.frames, args.depths, (0.33, 0.0025), "cpu", bf16=args.bf16)
+    plan = engine.Plan(sd, args.batch, args.height, args.width, args.frames, args.depths, (0.33, 0.0025), "cpu", bf16=2 if args.bf16x3 else int(args.bf16))
     table = {}
     if args.merge and os.path.exists(args.out):
         table = json.load(open(args.out))

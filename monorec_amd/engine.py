@@ -173,21 +173,37 @@ def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, pha
     sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16)
     if sig in TUNED:
         return TUNED[sig]
+    if int(bf16) == 2:
+        # bf16x3 has no measured table yet: start from the schedule measured for the plain bf16 launch of the same layer (same
+        # input staging, weight blocks twice as large), then from the fp32 one, whichever still fits the LDS
+        cpads = [(c + 15) // 16 * 16 for c in src_channels]
+        nchunks = lambda ck: sum(math.ceil(c / ck) for c in cpads)
+        for other in (1, 0):
+            t = TUNED.get(schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, other))
+            if t is None or t[3] < 16 or t[2] > nchunks(t[3]):
+                continue
+            waves = t[4] if len(t) > 4 else 4
+            geo = conv_geometry(out_h, out_w, kh, kw, sh, sw, t[1], waves)
+            if lds_bytes(geo, kh * kw, cpads, t[0], t[3], t[2], 2) <= 160 * 1024:
+                return t
     best = None
-    for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=80 * 1024, bf16=bf16):
-        if c["waves"] != 4:          # 8-wave workgroups only through the measured table
-            continue
-        reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
-        fill = min(1.0, c["wgs"] / 768.0)
-        per_wg_steps = c["nchunks"] / c["split_k"]
-        score = c["eff"] * fill * (0.5 + 0.5 * min(reuse, 1.5) / 1.5)
-        score *= 1.0 - 0.04 * math.log2(c["split_k"])              # workspace round trip + extra launch
-        score *= 1.0 + 0.03 * math.log2(c["ck"] / 16)              # fewer barriers
-        if per_wg_steps < 2:
-            score *= 0.8
-        cand = (score, c["mb"], c["nb"], c["split_k"], c["ck"])
-        if best is None or cand > best:
-            best = cand
+    for lds_cap in (80 * 1024, 160 * 1024):      # prefer two workgroups per CU; a one-per-CU budget only if nothing else launches
+        for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=lds_cap, bf16=bf16):
+            if c["waves"] != 4:          # 8-wave workgroups only through the measured table
+                continue
+            reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
+            fill = min(1.0, c["wgs"] / 768.0)
+            per_wg_steps = c["nchunks"] / c["split_k"]
+            score = c["eff"] * fill * (0.5 + 0.5 * min(reuse, 1.5) / 1.5)
+            score *= 1.0 - 0.04 * math.log2(c["split_k"])              # workspace round trip + extra launch
+            score *= 1.0 + 0.03 * math.log2(c["ck"] / 16)              # fewer barriers
+            if per_wg_steps < 2:
+                score *= 0.8
+            cand = (score, c["mb"], c["nb"], c["split_k"], c["ck"])
+            if best is None or cand > best:
+                best = cand
+        if best is not None:
+            break
     if best is None:
         raise ValueError("no launchable schedule")
     return best[1:]

@@ -262,6 +262,22 @@ def test_bf16_weight_packing_layout(hip_lib):
     assert o == u16.size
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_every_launch_of_a_plan_is_accepted_by_the_library(hip_lib, mode):
+    """A plan built on the CPU device packs every weight and sends every conv descriptor through derive() of the library
+    (mr_conv2d_lds_bytes) - for the fp32, bf16 and bf16x3 arithmetic, at a small and at the BASELINE configs[1] shape."""
+    for (h, w, d) in ((64, 96, 8), (256, 512, 32)):
+        m = MonoRecModel(cv_depth_steps=d)
+        plan = engine.Plan(synth.seeded_state_dict(m.state_dict()), 1, h, w, 2, d, (0.33, 0.0025), "cpu", bf16=mode)
+        assert len(plan.conv_log) == 78 and {int(c["bf16"]) for c in plan.conv_log} == {mode}
+        assert all(0 < c["lds"] <= 160 * 1024 for c in plan.conv_log)
+        assert abs(plan.conv_macs() - sum(c["macs"] for c in plan.conv_log)) == 0
+    if mode == 2:      # no measured table yet: seeded from the bf16 / fp32 entries of the same layer where those still fit
+        seeded = sum(1 for c in plan.conv_log if (c["mb"], c["nb"], c["split_k"], c["ck"]) ==
+                     tuple(engine.TUNED.get(c["sig"].replace("_bf16x3", "_bf16"), ())[:4]))
+        assert seeded >= 40, seeded
+
+
 def test_bf16x3_weight_packing_layout(hip_lib):
     """mr_conv_pack_weights_bf16x3: the bf16 element order, per lane 4 `hi` = bf16(w) followed by 4 `lo` = bf16(w - hi); hi + lo
     carries 16 mantissa bits of the weight."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 2
+#define MR_ABI_VERSION 3
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1

@@ -420,3 +420,22 @@ def test_frame_cache_reads_ahead_on_worker_threads():
     assert got == want
     assert sorted(calls) == sorted(set(calls)) and set(range(0, 31)) >= set(calls) >= set(range(0, 31 - 1))   # once each, never past the range
     assert cache.decoded == 31 and main not in threads - {main} and len(threads - {main}) >= 1
+
+
+def test_header_is_a_c_abi_usable_from_plain_c(hip_lib, tmp_path):
+    """include/monorec_hip.h compiled as C99 by gcc (-Wall -Wextra -Werror) into a program that links libmonorec_hip.so and drives
+    the host-side entry points (weight repack, launch planning, resize tables) - no C++, no torch on that side of the boundary."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(repo, "monorec_amd")
+    exe = str(tmp_path / "host_smoke")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(repo, "include"),
+                    os.path.join(repo, "tests", "c_abi", "host_smoke.c"), "-o", exe, "-L" + libdir, "-l:libmonorec_hip.so", "-lm",
+                    "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("c abi ok"), (out.returncode, out.stdout, out.stderr[-500:])
+

@@ -29,6 +29,7 @@
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "../../include/monorec_hip.h"
 #include "conv_layout.h"
@@ -804,12 +805,17 @@ int derive(const mr_conv_desc* d, Derived* out) {
 
 template <int MB, int NB, bool DMA_IN, int WV, int BF16>
 int launch(const Derived& dv, hipStream_t stream) {
-    static bool attr_set = false;  // raise the dynamic-LDS ceiling once per instantiation
-    if (!attr_set) {
+    // raise the dynamic-LDS ceiling once per instantiation AND device (the attribute lives in the device's code object:
+    // a process that drives several GPUs - nn.DataParallel replicas - must set it on each)
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();

@@ -62,10 +62,38 @@ def gather_sums(local_sums, device=None):
     return torch.stack(out).cpu()
 
 
+def gather_batch_records(per_batch_metrics, batch_sizes, batch_indices, n_metrics):
+    """The one collective of a multi-rank evaluation: every rank contributes (global batch index, batch size, metric vector)
+    for the batches it evaluated and receives the index-sorted union.  Two all-gathers of float64 - the record counts, then the
+    records padded to the largest count - a few hundred bytes per rank; NaN metric values travel unchanged (the validity rule
+    is applied afterwards by `evaluate.evaluation_log`, exactly as in one process)."""
+    rank, world = world_info()
+    local = torch.full((len(per_batch_metrics), n_metrics + 2), float("nan"), dtype=torch.float64)
+    for r, (m, bs, gi) in enumerate(zip(per_batch_metrics, batch_sizes, batch_indices)):
+        local[r, 0], local[r, 1] = float(gi), float(bs)
+        local[r, 2:] = torch.as_tensor([float(v) for v in m], dtype=torch.float64)
+    if world == 1:
+        rows = local
+    else:
+        counts = gather_sums([float(local.shape[0])]).reshape(-1).to(torch.int64)
+        width = int(counts.max().item())
+        padded = torch.full((width, n_metrics + 2), float("nan"), dtype=torch.float64)
+        padded[: local.shape[0]] = local
+        allr = gather_sums(padded.reshape(-1)).reshape(world, width, n_metrics + 2)
+        rows = torch.cat([allr[r, : int(counts[r])] for r in range(world)]) if width else local
+    order = torch.argsort(rows[:, 0]) if rows.shape[0] else torch.zeros(0, dtype=torch.int64)
+    rows = rows[order]
+    idx = [int(v) for v in rows[:, 0].tolist()]
+    if len(set(idx)) != len(idx):
+        raise RuntimeError(f"gather_batch_records: batch indices evaluated twice across ranks: {idx}")
+    return [r[2:].tolist() for r in rows], [int(v) for v in rows[:, 1].tolist()], idx
+
+
 def reduce_batch_metrics(per_batch_metrics):
-    """Combine per-batch metric vectors evaluated on this rank's shard into the global per-batch mean -
-    exactly what Evaluater.eval computes in one process (sum over batches / number of batches,
-    evaluater.py:94-103,116).  per_batch_metrics: list of equal-length sequences (one per local batch)."""
+    """Global mean over VALID batches of per-batch metric vectors evaluated on this rank's shard: what `Evaluater.eval`
+    reports as 'metrics' (evaluater.py:45-49,116) - a batch with any NaN metric contributes neither values nor a count.
+    Returns (means, number of valid batches).  (`Evaluater.eval(distributed=True)` uses `gather_batch_records` instead,
+    which also reproduces 'metrics_correct'.)"""
     n_metrics = len(per_batch_metrics[0]) if per_batch_metrics else 0
     _, world = world_info()
     if world > 1:   # ranks with an empty shard still need the vector length
@@ -73,7 +101,13 @@ def reduce_batch_metrics(per_batch_metrics):
         n_metrics = int(lens.max().item())
     local = torch.zeros(n_metrics + 1, dtype=torch.float64)
     for m in per_batch_metrics:
-        local[:n_metrics] += torch.as_tensor(m, dtype=torch.float64)
+        v = torch.as_tensor(m, dtype=torch.float64)
+        if bool(torch.isnan(v).any()):
+            continue
+        local[:n_metrics] += v
         local[n_metrics] += 1
     total = gather_sums(local).sum(0)
-    return (total[:n_metrics] / total[n_metrics].clamp_min(1)).tolist(), int(total[n_metrics].item())
+    valid = int(total[n_metrics].item())
+    if valid == 0:
+        return [float("nan")] * n_metrics, 0
+    return (total[:n_metrics] / total[n_metrics]).tolist(), valid

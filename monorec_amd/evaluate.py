@@ -43,16 +43,27 @@ def evaluation_log(per_batch_metrics, batch_sizes):
 class Evaluater:
     """`Evaluater(model, roi=, max_distance=).eval(data_loader)` -> the reference's log dict (without the loss entries,
     which are constant zero there, evaluater.py:85-86).  `data_loader` yields `(data_dict, target)` like the reference's
-    loaders; tensors may live on the host (they are moved) or already on the model's device."""
+    loaders; tensors may live on the host (they are moved) or already on the model's device.
 
-    def __init__(self, model, roi=None, max_distance=None, metric_names=_metrics.SPARSE_METRICS, in_flight=2):
+    `eval(data_loader, distributed=True)` is the multi-GPU form (one process per GPU, `monorec_amd.distributed`): whole
+    batches are sharded round-robin over the ranks - by the loader itself when it was built with this rank / world size
+    (`kitti.DeviceLoader(rank=, world_size=)`), otherwise by skipping the batches of the other ranks - every rank evaluates
+    its batches exactly as the single process would, and ONE all-gather (RCCL over xGMI; 10 float64 per batch) hands every
+    rank the per-batch metric vectors, batch sizes and batch indices of all ranks.  The reference's bookkeeping
+    (`evaluation_log`: NaN batch => invalid, mean over valid batches, batch-size-weighted running mean, evaluater.py:45-49,
+    94-118) then runs on the index-sorted union, so the log equals the single-process log bit for bit on every rank."""
+
+    def __init__(self, model, roi=None, max_distance=None, metric_names=_metrics.SPARSE_METRICS, in_flight=2, sums_fn=None):
         unknown = [m for m in metric_names if m not in _metrics.SPARSE_METRICS]
         if unknown:
             raise NotImplementedError(f"metrics outside the fused sparse set: {unknown}")
         self.model, self.roi, self.max_distance = model, roi, max_distance
         self.metric_names = tuple(metric_names)
         self._cols = [_metrics.SPARSE_METRICS.index(m) for m in self.metric_names]
-        self.in_flight = max(1, in_flight)
+        # forwards kept in flight: never more than the model has slots - a deeper queue would let submit() reuse a slot whose
+        # resident `result` has not been reduced yet (the metric launch would then read the wrong keyframe's prediction)
+        self.in_flight = max(1, min(int(in_flight), int(getattr(model, "_in_flight", in_flight))))
+        self._sums_fn = sums_fn or _metrics.sparse_metric_sums_device   # (B, 8) per-sample sums; injectable for host-logic tests
 
     @staticmethod
     def _to(obj, device):
@@ -64,33 +75,42 @@ class Evaluater:
             return {k: Evaluater._to(v, device) for k, v in obj.items()}
         return obj
 
-    def eval(self, data_loader):
+    def eval(self, data_loader, distributed=False):
+        from . import distributed as _dist
+        rank, world = _dist.world_info() if distributed else (0, 1)
+        # a loader that already yields this rank's shard (DeviceLoader(rank=, world_size=)) is taken as is
+        presharded = world > 1 and getattr(data_loader, "world_size", 1) == world and getattr(data_loader, "rank", None) == rank
         device = next(self.model.parameters()).device
-        sums, sizes = [], []
+        sums, sizes, indices = [], [], []
         pending = collections.deque()
 
         def collect():
-            data, handle = pending.popleft()
+            data, handle, gidx = pending.popleft()
             out = handle.result()                                   # ordered behind the forward on the caller's stream
-            sums.append(_metrics.sparse_metric_sums_device({"result": out["result"], "target": data["target"]},
-                                                           self.roi, self.max_distance))
+            sums.append(self._sums_fn({"result": out["result"], "target": data["target"]}, self.roi, self.max_distance))
             sizes.append(int(data["target"].shape[0]))
+            indices.append(gidx)
 
         self.model.eval()
         with torch.no_grad():
-            for data, target in data_loader:
+            for i, (data, target) in enumerate(data_loader):
+                if world > 1 and not presharded and i % world != rank:
+                    continue
                 data = self._to(data, device)
                 data["target"] = self._to(target, device)
-                pending.append((data, self.model.submit(data)))
+                pending.append((data, self.model.submit(data), rank + i * world if presharded else i))
                 if len(pending) >= self.in_flight:
                     collect()
             while pending:
                 collect()
-        if not sums:
-            return evaluation_log([], [])
-        host = [s.cpu() for s in sums] if len({tuple(s.shape) for s in sums}) > 1 else list(torch.stack(sums).cpu())
         per_batch = []
-        for s in host:
-            vals = _metrics.metrics_from_sums(s)
-            per_batch.append([float(vals[c]) for c in self._cols])
+        if sums:
+            host = [s.cpu() for s in sums] if len({tuple(s.shape) for s in sums}) > 1 else list(torch.stack(sums).cpu())
+            for s in host:
+                vals = _metrics.metrics_from_sums(s)
+                per_batch.append([float(vals[c]) for c in self._cols])
+        if world > 1:
+            per_batch, sizes, indices = _dist.gather_batch_records(per_batch, sizes, indices, len(self._cols))
+        if not per_batch:
+            return evaluation_log([], [])
         return evaluation_log(per_batch, sizes)

@@ -8,7 +8,9 @@ dict-in / dict-out `forward` (reference model/monorec/monorec_model.py:560-729),
 launch plan in `engine.py`.  There is no PyTorch/CPU fallback: calling `forward` without a HIP device
 or without the built library raises.
 """
+import threading
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -16,6 +18,8 @@ from torch import nn
 
 from . import _lib
 from .engine import Plan
+
+_METRIC_CACHE_KEY = "_monorec_amd_metric_sums"      # monorec_amd.metrics caches its fused sums on the dict under this key
 
 
 class _ParamsOnly(nn.Module):
@@ -73,6 +77,18 @@ class ResnetEncoder(_ParamsOnly):
             setattr(enc, f"layer{li}", _seq(*blocks))
         enc.fc = nn.Linear(512, 1000)   # present in torchvision's state dict; unused by the path
         self.encoder = enc
+        # monorec_model.py:104-113 builds torchvision.models.resnet18(pretrained): the ImageNet weights come from torchvision's
+        # download cache.  Same here when torchvision is importable; otherwise the encoder stays randomly initialised and
+        # MonoRecModel warns at its first forward unless a checkpoint / state dict supplied `_feature_extractor.*`.
+        self._weights_loaded = False
+        if pretrained:
+            try:
+                import torchvision
+                tv = torchvision.models.resnet18(pretrained)
+                enc.load_state_dict(tv.state_dict(), strict=True)
+                self._weights_loaded = True
+            except Exception:
+                pass
 
 
 class CostVolumeModule(_ParamsOnly):
@@ -232,14 +248,16 @@ class MonoRecModel(nn.Module):
         self._hip_graph = bool(hip_graph)
         self._in_flight = max(1, int(hip_in_flight))
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
-        # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL and not
-        # yet validated on hardware: hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
+        # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
+        # hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
         self._bf16 = 2 if hip_bf16x3 else (1 if hip_bf16 else 0)
         self._next_slot = 0
         self._plans = {}
         self._graphs = {}
         self._streams = {}
         self._packed_state = None
+        self._lock = threading.RLock()   # one enqueue at a time per model object (nn.DataParallel calls replicas from threads)
+        self._warned_encoder = False
 
         self._feature_extractor = ResnetEncoder(num_layers=18, pretrained=True)
         if self.freeze_resnet:
@@ -279,7 +297,13 @@ class MonoRecModel(nn.Module):
             module.eval()
             for param in module.parameters(True):
                 param.requires_grad_(False)
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+        self.register_load_state_dict_post_hook(MonoRecModel._after_load_state_dict)
+
+    @staticmethod
+    def _after_load_state_dict(module, incompatible):
+        module._invalidate()
+        if not any(k.startswith("_feature_extractor.") and not k.endswith("num_batches_tracked") for k in incompatible.missing_keys):
+            module._feature_extractor._weights_loaded = True
 
     # ------------------------------------------------------------------ plan management
     def _invalidate(self):
@@ -291,10 +315,22 @@ class MonoRecModel(nn.Module):
         self._invalidate()
         return super()._apply(fn, *a, **k)
 
+    def __getstate__(self):          # copy.deepcopy / pickle: device plans, streams, graphs and the lock are rebuilt on demand
+        state = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
+        for k in ("_plans", "_graphs", "_streams"):
+            state[k] = {}
+        state["_packed_state"] = None
+        state.pop("_lock", None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._lock = threading.RLock()
+
     def _slot_streams(self, slot, device):
         st = self._streams.get((slot, str(device)))
         if st is None:
-            st = {n: torch.cuda.Stream(device) for n in ("main", "enc", "side")}
+            st = {n: torch.cuda.Stream(device) for n in ("main", "enc", "geom")}
             self._streams[(slot, str(device))] = st
         return st
 
@@ -302,7 +338,7 @@ class MonoRecModel(nn.Module):
         key = (slot, batch, h, w, nf, self.cv_depth_steps, str(device))
         plan = self._plans.get(key)
         if plan is None:
-            if self._packed_state is None or self._packed_state[0] != str(device):
+            if self._packed_state is None:          # CPU fp32 copy of the weights, shared by the plans of every slot / device
                 self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
             plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
@@ -313,14 +349,33 @@ class MonoRecModel(nn.Module):
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
+            plan.geom_uploaded = None       # event behind the last H2D copy out of host_geom
             self._plans[key] = plan
         return key, plan
 
     # ------------------------------------------------------------------ forward
+    # tensor-valued outputs the path writes into the dict (monorec_model.py:256-279,690,713-727)
+    _OUTPUT_KEYS = ("cost_volume", "single_frame_cvs", "image_features", "cv_mask", "predicted_inverse_depths")
+
     def forward(self, data_dict):
-        """Reference contract (monorec_model.py:672-729): fills and returns `data_dict`; the outputs are ordered
-        on the caller's current stream like any PyTorch op.  Equivalent to `self.submit(data_dict).result()`."""
-        return self.submit(data_dict).result()
+        """Reference contract (monorec_model.py:672-729): fills and returns `data_dict`; the outputs are ordered on the
+        caller's current stream like any PyTorch op and - like the reference's - are tensors the caller OWNS: they stay
+        valid whatever is run afterwards (create_pointcloud.py:79-98 keeps `result` of five keyframes and multiplies the
+        middle one in place).  `submit()` is the zero-copy interface."""
+        out = self.submit(data_dict).result()
+        with torch.cuda.device(out["keyframe"].device):
+            for k in self._OUTPUT_KEYS:
+                v = out.get(k)
+                if torch.is_tensor(v):
+                    out[k] = v.clone()
+                elif isinstance(v, list):
+                    out[k] = [t.clone() for t in v]
+        if self.pretrain_mode == 2:                           # :723-727, same aliasing as the reference
+            out["result"] = out["cv_mask"]
+        else:
+            out["result"] = out["predicted_inverse_depths"][0]
+            out["mask"] = out["cv_mask"]
+        return out
 
     def submit(self, data_dict):
         """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
@@ -330,8 +385,9 @@ class MonoRecModel(nn.Module):
 
             pending.append(model.submit(batch));  out = pending.popleft().result() once len(pending) == hip_in_flight
 
-        The inputs must stay unmodified until `.result()`; outputs are views of the slot's resident buffers and stay
-        valid until that slot is reused (`hip_in_flight` submits later)."""
+        The inputs must stay unmodified until `.result()`.  Zero-copy: the outputs are VIEWS of the slot's resident buffers
+        and are overwritten by the submit that reuses the slot (`hip_in_flight` submits later) - consume or clone them
+        before that.  `forward()` returns owned tensors instead."""
         if self.training:
             raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
         keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
@@ -351,12 +407,23 @@ class MonoRecModel(nn.Module):
             raise RuntimeError("monorec_amd.MonoRecModel needs its inputs on a HIP device (cuda:N on ROCm); "
                                "there is no CPU path")
         _lib.load()
+        if not self._feature_extractor._weights_loaded and not self._warned_encoder:
+            self._warned_encoder = True
+            warnings.warn("monorec_amd.MonoRecModel: the ResNet-18 encoder has neither ImageNet weights (torchvision is not "
+                          "importable / has no cached weights; the reference builds resnet18(pretrained=True), "
+                          "monorec_model.py:104-113) nor `_feature_extractor.*` entries from a checkpoint or state dict: "
+                          "it runs with its random initialisation")
+        data_dict.pop(_METRIC_CACHE_KEY, None)                # cached metric sums of an earlier forward on this dict are stale now
         cv_depths = data_dict.get("cv_depths")                # per-pixel depth hypotheses (monorec_model.py:181-182)
         if cv_depths is not None and self._hip_graph:
             raise NotImplementedError("cv_depths with hip_graph=True: the captured launch has no per-pixel depth pointer")
         b, c, h, w = keyframe.shape
         nf = len(frames)
         device = keyframe.device
+        with self._lock, torch.cuda.device(device):
+            return self._submit_locked(data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device)
+
+    def _submit_locked(self, data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device):
         data_dict["inv_depth_min"] = keyframe.new_tensor([self.inv_depth_min_max[0]])
         data_dict["inv_depth_max"] = keyframe.new_tensor([self.inv_depth_min_max[1]])
         data_dict["cv_depth_steps"] = keyframe.new_tensor([self.cv_depth_steps], dtype=torch.int32)
@@ -365,23 +432,28 @@ class MonoRecModel(nn.Module):
         self._next_slot = (slot + 1) % self._in_flight
         key, plan = self._plan_for(slot, b, h, w, nf, device)
         streams = self._slot_streams(slot, device)
-        main, enc, side = streams["main"], streams["enc"], streams["side"]
+        main, enc, geom = streams["main"], streams["enc"], streams["geom"]
         caller = torch.cuda.current_stream(device)
         start_time = time.time()
 
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(caller)
-        main.wait_event(inputs_ready)
-        with torch.cuda.stream(main):
-            # 1. pose / intrinsics matrices -> pinned host memory on a side stream (tiny, overlaps the encoder)
-            mats = torch.stack([kf_intrinsics, kf_pose] + intrinsics + poses).float()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        # 1. pose / intrinsics matrices -> pinned host memory.  Their own stream, ordered only behind the caller's inputs: the
+        #    copy must not queue behind the slot's previous keyframe (the host waits for it below).  Matrices that already live
+        #    on the host (a loader that keeps the 4x4s on the CPU) are used in place, without any device round trip.
+        mat_list = [kf_intrinsics, kf_pose] + intrinsics + poses
+        mats_on_host = all(not m.is_cuda for m in mat_list)
+        mats_done = None
+        if not mats_on_host:
+            geom.wait_event(inputs_ready)
+            with torch.cuda.stream(geom):
+                mats = torch.stack([m.to(device=device, dtype=torch.float32) for m in mat_list])
                 plan.host_mats.copy_(mats, non_blocking=True)
                 mats_done = torch.cuda.Event()
-                mats_done.record(side)
-            mats.record_stream(side)
-
+                mats_done.record(geom)
+            mats.record_stream(geom)
+        main.wait_event(inputs_ready)
+        with torch.cuda.stream(main):
             # 2. images into the slot's resident buffers; ResNet encoder stage (pose independent) on its own stream
             plan.buf["keyframe"].copy_(keyframe)
             for f in range(nf):
@@ -398,13 +470,21 @@ class MonoRecModel(nn.Module):
             tail_done = torch.cuda.Event()
             tail_done.record(enc)
 
-            # 3. host 4x4 algebra while the encoder runs, then upload
-            mats_done.synchronize()
-            hm = plan.host_mats
+            # 3. host 4x4 algebra (same ATen CPU operators as the reference: bit-identical matrices) while the encoder runs,
+            #    then one H2D copy of 9 + 12 F floats per sample
+            if mats_on_host:
+                hm = [m.detach().float() for m in mat_list]
+            else:
+                mats_done.synchronize()                       # a ~100 byte copy enqueued before the encoder launches: done by now
+                hm = plan.host_mats
             kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+            if plan.geom_uploaded is not None:
+                plan.geom_uploaded.synchronize()              # the slot's previous upload has left the pinned buffer (long ago)
             plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
             plan.host_geom[b * 9:].copy_(proj.reshape(-1))
             plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
+            plan.geom_uploaded = torch.cuda.Event()
+            plan.geom_uploaded.record(main)
 
             plan.pix_depths_on = cv_depths is not None
             if cv_depths is not None:

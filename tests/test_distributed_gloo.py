@@ -73,3 +73,116 @@ def test_single_process_fallback():
     assert mrd.shard_batches(5) == [0, 1, 2, 3, 4]
     means, n = mrd.reduce_batch_metrics([[1.0, 2.0], [3.0, 4.0]])
     assert n == 2 and means == [2.0, 3.0]
+
+
+# ---- Evaluater.eval(distributed=True): the multi-rank evaluation reproduces the single-process log exactly ----------------------
+class _StubHandle:
+    def __init__(self, out):
+        self._out = out
+
+    def result(self):
+        return self._out
+
+
+class _StubModel:
+    """Stands in for MonoRecModel on the CPU: `submit()` derives a deterministic 'prediction' from the keyframe."""
+    _in_flight = 2
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        yield torch.zeros(1)
+
+    def submit(self, data):
+        return _StubHandle({"result": data["keyframe"].abs().mean(dim=1, keepdim=True) * 0.3 + 0.01})
+
+
+def _cpu_sums(data, roi, max_distance):
+    """(B, 8) per-sample sums in the column order of mr_sparse_metric_sums_f32 (count, abs_rel, sq_rel, se, sle, a1, a2, a3);
+    a plain torch restatement for the host-logic test (the product reduces on the device)."""
+    pred, gt = data["result"].double(), data["target"].double()
+    out = torch.zeros(pred.shape[0], 8, dtype=torch.float64)
+    for b in range(pred.shape[0]):
+        m = gt[b] > 1 / 80
+        p, g = 1 / pred[b][m].clamp_min(1 / 80), 1 / gt[b][m]
+        r = torch.maximum(p / g, g / p)
+        out[b] = torch.tensor([m.sum(), ((p - g).abs() / g).sum(), ((p - g) ** 2 / g).sum(), ((p - g) ** 2).sum(),
+                               ((p.log() - g.log()) ** 2).sum(), (r < 1.25).sum(), (r < 1.25 ** 2).sum(), (r < 1.25 ** 3).sum()])
+    return out
+
+
+def _eval_batches():
+    g = torch.Generator().manual_seed(7)
+    batches = []
+    for i, bs in enumerate([2, 2, 1, 2, 2, 2, 1]):
+        kf = torch.rand(bs, 3, 8, 12, generator=g) - 0.5
+        target = torch.rand(bs, 1, 8, 12, generator=g) * 0.3 + 0.02
+        target[torch.rand(bs, 1, 8, 12, generator=g) < 0.5] = 0
+        if i == 3:
+            target[:] = 0                      # a batch without ground truth: NaN metrics -> invalid batch (evaluater.py:45-49)
+        batches.append(({"keyframe": kf}, target))
+    return batches
+
+
+class _ShardedLoader:
+    """Yields only this rank's batches, like kitti.DeviceLoader(rank=, world_size=)."""
+
+    def __init__(self, batches, rank, world_size):
+        self.batches, self.rank, self.world_size = batches, rank, world_size
+
+    def __iter__(self):
+        return iter(self.batches[self.rank::self.world_size])
+
+
+def _eval_worker(rank, world, port, presharded, q):
+    from monorec_amd import evaluate
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mrd.init_from_env("gloo")
+    batches = _eval_batches()
+    loader = _ShardedLoader(batches, rank, world) if presharded else batches
+    log = evaluate.Evaluater(_StubModel(), max_distance=80, sums_fn=_cpu_sums).eval(loader, distributed=True)
+    q.put((rank, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_eval(presharded):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, presharded, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _same(a, b):
+    return a == b or (a != a and b != b)
+
+
+def test_distributed_evaluater_equals_single_process_log():
+    from monorec_amd import evaluate
+    single = evaluate.Evaluater(_StubModel(), max_distance=80, sums_fn=_cpu_sums).eval(_eval_batches())
+    assert single["valid_batches"] == 6                                # the batch without ground truth is invalid
+    for presharded in (False, True):
+        for rank, log in _run_eval(presharded):
+            assert log["valid_batches"] == single["valid_batches"]
+            for key in ("metrics", "metrics_correct"):                 # bit for bit, on every rank
+                assert all(_same(a, b) for a, b in zip(log[key], single[key])), (presharded, rank, key, log[key], single[key])
+
+
+def test_reduce_batch_metrics_skips_nan_batches():
+    means, n = mrd.reduce_batch_metrics([[1.0, 2.0], [float("nan"), 5.0], [3.0, 4.0]])
+    assert n == 2 and means == [2.0, 3.0]
+    means, n = mrd.reduce_batch_metrics([[float("nan")]])
+    assert n == 0 and means[0] != means[0]
+
+
+def test_evaluater_in_flight_is_clamped_to_the_models_slots():
+    from monorec_amd import evaluate
+    assert evaluate.Evaluater(_StubModel(), in_flight=8, sums_fn=_cpu_sums).in_flight == 2

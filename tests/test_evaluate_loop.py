@@ -77,3 +77,58 @@ def test_evaluater_matches_oracle_chain(hip_lib):
         want.append([float(vals["a1_sparse_metric"]), float(vals["abs_rel_sparse_metric"])])
     m2, _, _ = _reference_loop(want, [2, 2])
     assert all(math.isclose(a, b, rel_tol=2e-5) for a, b in zip(sub["metrics"], m2))
+
+
+def _dist_eval_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from monorec_amd import MonoRecModel, distributed as mrd
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mrd.init_from_env("gloo")                          # both ranks share the box's one GPU; the collective runs over gloo
+    log = _eval_log(distributed=True)
+    q.put((rank, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _eval_log(distributed):
+    from monorec_amd import MonoRecModel
+    dev = "cuda:0"
+    model = MonoRecModel(cv_depth_steps=8)
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=0))
+    model = model.to(dev).eval()
+    batches = []
+    for i in range(5):
+        data = synth.make_batch(2 if i != 3 else 1, 64, 96, 2, seed=40 + i)
+        _, target = synth.make_depth_pair(2 if i != 3 else 1, 64, 96, seed=60 + i)
+        if i == 2:
+            target[1] = 0
+        batches.append((data, target))
+    return evaluate.Evaluater(model, roi=None, max_distance=80).eval(batches, distributed=distributed)
+
+
+@pytest.mark.gpu
+def test_two_rank_evaluation_equals_one_rank(hip_lib):
+    """model -> fused metrics -> all-gather on 2 ranks (one device, gloo) == the single-process log to 1e-12."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    single = _eval_log(distributed=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert single["valid_batches"] == 4
+    for rank, log in res:
+        assert log["valid_batches"] == single["valid_batches"]
+        for key in ("metrics", "metrics_correct"):
+            for a, b in zip(log[key], single[key]):
+                assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (rank, key, a, b)

@@ -381,3 +381,54 @@ def test_two_keyframes_in_flight_equal_sequential_forwards(hip_lib):
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert torch.equal(g, w)
+
+
+@pytest.mark.gpu
+def test_forward_outputs_are_owned_and_submit_outputs_are_views(hip_lib):
+    """monorec_model.py:713-727: every forward allocates its outputs.  `forward()` therefore returns tensors that later
+    forwards never touch; `submit()` is the documented zero-copy interface (views of the slot's resident buffers)."""
+    from monorec_amd import MonoRecModel
+    model = MonoRecModel(cv_depth_steps=8, hip_in_flight=2)
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=0))
+    model = model.to(DEV).eval()
+    batches = [synth.clone_batch(synth.make_batch(1, 64, 96, 2, seed=70 + i), DEV) for i in range(5)]
+    with torch.no_grad():
+        outs = [model(dict(b)) for b in batches]
+        torch.cuda.synchronize()
+        snap = [{k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in o.items()
+                 if k in MonoRecModel._OUTPUT_KEYS + ("result", "mask")} for o in outs]
+        for b in batches[::-1]:                                         # four more forwards over every slot
+            model(dict(b))
+        torch.cuda.synchronize()
+    for o, s in zip(outs, snap):
+        assert o["result"] is o["predicted_inverse_depths"][0] and o["mask"] is o["cv_mask"]     # the reference's aliasing (:723-727)
+        for k, v in s.items():
+            for a, b in zip(v if isinstance(v, list) else [v], o[k] if isinstance(o[k], list) else [o[k]]):
+                assert torch.equal(a, b), k
+    assert not torch.equal(outs[0]["result"], outs[2]["result"])        # slot 0 served both keyframes
+    with torch.no_grad():                                                # zero-copy interface: same storage two submits later
+        h0 = model.submit(dict(batches[0])).synchronize()
+        model.submit(dict(batches[1])).synchronize()
+        h2 = model.submit(dict(batches[2])).synchronize()
+    assert h0["result"].data_ptr() == h2["result"].data_ptr()
+
+
+@pytest.mark.gpu
+def test_data_parallel_wrap_matches_plain_forward(hip_lib):
+    """base/base_trainer.py:26-29 / evaluater.py:27-30 wrap the model in nn.DataParallel when n_gpu > 1 (every reference config
+    says 8).  Two replicas (both on cuda:0 here - the box has one GPU; the replicas still run from two threads over scattered
+    half batches and are gathered) must reproduce the plain batch-2 forward."""
+    from monorec_amd import MonoRecModel
+    model = MonoRecModel(cv_depth_steps=8)
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=0))
+    model = model.to(DEV).eval()
+    batch = synth.clone_batch(synth.make_batch(2, 64, 96, 2, seed=3), DEV)
+    with torch.no_grad():
+        plain = model(dict(batch))
+        plain = {k: plain[k].clone() for k in ("result", "cv_mask")}
+        wrapped = torch.nn.DataParallel(model, device_ids=[0, 0])
+        out = wrapped(dict(batch))
+    torch.cuda.synchronize()
+    assert out["result"].shape == plain["result"].shape
+    for k in ("result", "cv_mask"):
+        assert float((out[k] - plain[k]).abs().max()) <= 1e-6, k

@@ -114,3 +114,83 @@ def test_builder_runs_the_reference_loop(hip_lib):
     want = torch.cat(want)
     assert got.shape == want.shape and got.shape[0] > 1000, (got.shape, want.shape)
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_unchanged_reference_loop_body_with_two_keyframes_in_flight(hip_lib):
+    """The loop body of the reference's create_pointcloud.py:66-102, statement for statement (buffers of 5, no clones,
+    `depth *= mask` in place), over `model(data)` with the default two in-flight slots: `forward()` must hand out tensors the
+    caller owns (monorec_model.py:713-727 allocates its outputs), otherwise depth_buffer[key_index] is the slot the newest
+    keyframe has just overwritten.  Compared frame for frame with the oracle chain on per-forward copies of the outputs."""
+    import torch.nn.functional as F
+    from monorec_amd import MonoRecModel
+    from monorec_amd.pointcloud import PLYSaver
+    model = MonoRecModel(cv_depth_steps=8)                                 # hip_in_flight defaults to 2
+    assert model._in_flight == 2
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=0))
+    model = model.to(DEV).eval()
+    max_d, min_d, mask_fill, use_mask, roi = 400, 3, 32, True, [4, 120, 8, 180]
+    plysaver = PLYSaver(128, 192, min_d=min_d, max_d=max_d, batch_size=1, roi=roi, dropout=0)
+    plysaver.to(DEV)
+    loader = [(synth.make_batch(1, 128, 192, 2, seed=20 + i), None) for i in range(7)]
+    kept, per_frame = [], []
+
+    pose_buffer = []
+    intrinsics_buffer = []
+    mask_buffer = []
+    keyframe_buffer = []
+    depth_buffer = []
+
+    buffer_length = 5
+    min_hits = 1
+    key_index = buffer_length // 2
+
+    with torch.no_grad():
+        for i, (data, target) in enumerate(loader):
+            data = synth.clone_batch(data, DEV)
+            result = model(data)
+            if not isinstance(result, dict):
+                result = {"result": result[0]}
+            output = result["result"]
+            if "cv_mask" not in result:
+                result["cv_mask"] = output.new_zeros(output.shape)
+            # (test only) random-init weights call almost every pixel "moving": keep the strongest response per keyframe
+            result["cv_mask"] = (result["cv_mask"] >= result["cv_mask"].flatten().topk(1).values[-1]).float()
+            kept.append(dict(depth=output.cpu().clone(), cv_mask=result["cv_mask"].cpu().clone(), keyframe=data["keyframe"].cpu().clone(),
+                             K=data["keyframe_intrinsics"].cpu().clone(), pose=data["keyframe_pose"].cpu().clone()))
+            mask = (result["cv_mask"] >= .1).to(dtype=torch.float32)
+            mask = (F.conv2d(mask, mask.new_ones((1, 1, mask_fill + 1, mask_fill + 1)), padding=mask_fill // 2) < 1).to(dtype=torch.float32)
+
+            pose_buffer += data["keyframe_pose"]
+            intrinsics_buffer += [data["keyframe_intrinsics"]]
+            mask_buffer += [mask]
+            keyframe_buffer += [data["keyframe"]]
+            depth_buffer += [output]
+
+            if len(pose_buffer) >= buffer_length:
+                pose = pose_buffer[key_index]
+                intrinsics = intrinsics_buffer[key_index]
+                keyframe = keyframe_buffer[key_index]
+                depth = depth_buffer[key_index]
+
+                mask = (torch.sum(torch.stack(mask_buffer), dim=0) > buffer_length - min_hits).to(dtype=torch.float32)
+                if use_mask:
+                    depth *= mask
+
+                before = len(plysaver.data) // 6
+                plysaver.add_depthmap(depth, keyframe, intrinsics, pose)
+                per_frame.append(torch.tensor(plysaver.data[before * 6:], dtype=torch.float32).view(-1, 6))
+
+                del pose_buffer[0]
+                del intrinsics_buffer[0]
+                del mask_buffer[0]
+                del keyframe_buffer[0]
+                del depth_buffer[0]
+    assert len(per_frame) == 3
+    for n, j in enumerate(range(2, 5)):                                  # key index 2 of each full 5-window
+        masks = [orc.static_mask(e["cv_mask"], mask_fill) for e in kept[j - 2:j + 3]]
+        k = kept[j]
+        want = orc.pointcloud_records(k["depth"], k["keyframe"], k["K"], k["pose"], min_d, max_d, roi, 0, None, masks, min_hits)
+        got = per_frame[n]
+        assert got.shape == want.shape and got.shape[0] > 300, (n, got.shape, want.shape)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-4), (n, float((got - want).abs().max()))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 3
+#define MR_ABI_VERSION 4
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -126,6 +126,12 @@ typedef struct mr_conv_desc {
      * four v_mfma_f32_16x16x4_f32, which run at 1/16 of the rate).  Weights from mr_conv_pack_weights_bf16x3; the same
      * restrictions as MR_COMPUTE_BF16.  CPU emulation over the whole network: depth error 4e-6 (fp32 path 1.3e-6, bar 1e-4). */
     int32_t compute_dtype;
+    /* per-phase filter sizes (num_phases == 4): phase p sweeps phase_kh[p] x phase_kw[p] taps of phase_weights[p] (packed with
+     * that size); 0 = the common kh / kw, which must be the maximum over the phases (it sizes the input tile).  This is how
+     * layers.Upconv (nearest x2 -> pad(0,1,0,1) -> conv2x2, model/layers.py:349-356) runs on the LOW-resolution input: output
+     * parity (py, px) is a (1+py) x (1+px) convolution with the 2x2 filter's rows / columns summed where both fall on the same
+     * input pixel - 9 instead of 16 multiply-adds per 2x2 output block. */
+    int32_t phase_kh[4], phase_kw[4];
 } mr_conv_desc;
 
 /* number of floats of the packed weight image for a conv with the given source split and schedule
@@ -196,6 +202,16 @@ int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, i
                             float alpha, const float* channel_weights, int32_t use_ssim,
                             const float* pixel_depths, int32_t sfcv_mult_mask,
                             float* cost_volume, float* const* sfcv, void* stream);
+
+/* mr_cost_volume_mode_f32 on the round-1 kernels (LDS-tiled sad kernel + three-pass fusion kernel) whatever the options: the
+ * default configuration (use_ssim 1, sfcv_mult_mask 1) otherwise runs the LDS-free marching kernel + register-resident fusion
+ * kernel, whose results are bit-identical.  Kept as the A/B reference of that claim (tests/test_gpu_kernels.py) and for timing. */
+int mr_cost_volume_tiled_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                             const float* kinv, const float* proj, const float* depths,
+                             int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                             float alpha, const float* channel_weights, int32_t use_ssim,
+                             const float* pixel_depths, int32_t sfcv_mult_mask,
+                             float* cost_volume, float* const* sfcv, void* stream);
 
 /* The same with a P x P matching patch, `cv_patch_size` of MonoRecModel (monorec_model.py:138-142,247): the photometric term is
  * averaged over a zero-padded patch_size x patch_size box and the border radius becomes patch_size / 2 + 1 (:139).

@@ -52,6 +52,7 @@ class ConvDesc(ctypes.Structure):
         ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4),
         ("waves_per_wg", ctypes.c_int32),
         ("compute_dtype", ctypes.c_int32),
+        ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
     ]
 
 
@@ -84,6 +85,11 @@ ABI = {
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_float, _c_float_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "mr_cost_volume_tiled_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_float, _c_float_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "mr_cost_volume_patch_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -151,7 +157,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 3:
+    if lib.mr_abi_version() != 4:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -73,7 +73,8 @@ struct ConvKArgs {
     int ksplit, nchunks, batch, nphase;
     int bf16;                  // 1: bf16 MFMA mode (weights bf16, activations rounded to bf16 in the B fragment): half-size weight blocks
     int tiles_y, ngroups, ks_shift;   // ks_shift: log2(ksplit) or -1
-    long long wgroup_stride;   // packed floats per cout group
+    long long wgroup_stride[4];   // packed floats per cout group, per phase
+    int KHp[4], KWp[4];        // taps swept by each phase (<= KH, KW; the common KH / KW size the input tile)
     float* ws;
     const float* w[4];         // per phase
     int PT[4], PL[4], ooff_h[4], ooff_w[4];
@@ -291,7 +292,7 @@ __device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCurso
 
 template <int MB, int NB>
 __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
-                                            const int (&lbase)[NB], int ck4, int lane) {
+                                            const int (&lbase)[NB], int ck4, int lane, int KH, int KW) {
     const float* wl = ldsW + lane;
     // MB = NB = 1 has a single accumulator: every MFMA waits for the previous one to retire.  Two partial sums
     // (even / odd channel quads) keep two MFMAs in flight; they are added once per chunk.
@@ -303,10 +304,10 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
 #pragma unroll
             for (int i = 0; i < NB; ++i) acc2[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int kh = 0; kh < a.KH; ++kh) {
-        for (int kw = 0; kw < a.KW; ++kw) {
+    for (int kh = 0; kh < KH; ++kh) {
+        for (int kw = 0; kw < KW; ++kw) {
             const int tapoff = kh * a.IWa + kw;
-            const float* wt = wl + (kh * a.KW + kw) * ck4 * (MB * 64);
+            const float* wt = wl + (kh * KW + kw) * ck4 * (MB * 64);
             int c4 = 0;
             for (; c4 + 4 <= ck4; c4 += 4) {          // manual 4x unroll: LDS reads of 4 k-steps overlap
                 kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
@@ -362,13 +363,13 @@ __device__ __forceinline__ void kstep_bf16(f32x4 (&acc)[MB][NB], const float* __
 
 template <int MB, int NB>
 __device__ __forceinline__ void sweep_chunk_bf16(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
-                                                 const int (&lbase)[NB], int ck16, int lane) {
+                                                 const int (&lbase)[NB], int ck16, int lane, int KH, int KW) {
     const float* wl = ldsW + lane * 2;
     const int plane4 = 4 * a.PLANE;
-    for (int kh = 0; kh < a.KH; ++kh) {
-        for (int kw = 0; kw < a.KW; ++kw) {
+    for (int kh = 0; kh < KH; ++kh) {
+        for (int kw = 0; kw < KW; ++kw) {
             const int tapoff = kh * a.IWa + kw;
-            const float* wt = wl + (kh * a.KW + kw) * ck16 * (MB * 128);
+            const float* wt = wl + (kh * KW + kw) * ck16 * (MB * 128);
             int c16 = 0;
             for (; c16 + 2 <= ck16; c16 += 2) {
                 kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
@@ -422,13 +423,13 @@ __device__ __forceinline__ void kstep_bf16x3(f32x4 (&acc)[MB][NB], const float* 
 
 template <int MB, int NB>
 __device__ __forceinline__ void sweep_chunk_bf16x3(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
-                                                   const int (&lbase)[NB], int ck16, int lane) {
+                                                   const int (&lbase)[NB], int ck16, int lane, int KH, int KW) {
     const float* wl = ldsW + lane * 4;
     const int plane4 = 4 * a.PLANE;
-    for (int kh = 0; kh < a.KH; ++kh) {
-        for (int kw = 0; kw < a.KW; ++kw) {
+    for (int kh = 0; kh < KH; ++kh) {
+        for (int kw = 0; kw < KW; ++kw) {
             const int tapoff = kh * a.IWa + kw;
-            const float* wt = wl + (kh * a.KW + kw) * ck16 * (MB * 256);
+            const float* wt = wl + (kh * KW + kw) * ck16 * (MB * 256);
             for (int c16 = 0; c16 < ck16; ++c16) kstep_bf16x3<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
         }
     }
@@ -527,8 +528,9 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
 
     const int q_lo = a.ks_shift >= 0 ? (ks * a.nchunks) >> a.ks_shift : (ks * a.nchunks) / a.ksplit;
     const int q_hi = a.ks_shift >= 0 ? ((ks + 1) * a.nchunks) >> a.ks_shift : ((ks + 1) * a.nchunks) / a.ksplit;
-    const int T = a.KH * a.KW;
-    const float* wgrp = a.w[ph] + (long long)grp * a.wgroup_stride;
+    const int KH = a.KHp[ph], KW = a.KWp[ph];
+    const int T = KH * KW;
+    const float* wgrp = a.w[ph] + (long long)grp * a.wgroup_stride[ph];
 
     // ---- software pipeline over K chunks: chunk q+1 streams into the other buffer while q is swept ----------
     ChunkCursor cur = {0, 0, 0};
@@ -553,9 +555,9 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
         }
         if (stamp) dbg_stamp(a, 5);
         if (!MR_DBG(1)) {
-            if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
-            else if (BF16 == 1) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane);
-            else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane);
+            if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
+            else if (BF16 == 1) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
+            else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KH, KW);
         }
         if (stamp) dbg_stamp(a, 6);
         dma_wait_all();                                // this wave's share of the next chunk has landed
@@ -738,6 +740,9 @@ int derive(const mr_conv_desc* d, Derived* out) {
             k.w[p] = d->phase_weights[p]; k.PT[p] = d->phase_pad_top[p]; k.PL[p] = d->phase_pad_left[p];
             k.ooff_h[p] = d->phase_out_off_h[p]; k.ooff_w[p] = d->phase_out_off_w[p];
         }
+        k.KHp[p] = (nphase == 4 && d->phase_kh[p] > 0) ? d->phase_kh[p] : d->kh;
+        k.KWp[p] = (nphase == 4 && d->phase_kw[p] > 0) ? d->phase_kw[p] : d->kw;
+        if (k.KHp[p] > d->kh || k.KWp[p] > d->kw) return MR_ERR_BAD_ARGUMENT;      // kh / kw size the input tile: the maximum
         if (!k.w[p] || k.ooff_h[p] < 0 || k.ooff_w[p] < 0) return MR_ERR_BAD_ARGUMENT;
         if ((k.Ho - 1) * k.ostep_h + k.ooff_h[p] >= k.dst_H || (k.Wo - 1) * k.ostep_w + k.ooff_w[p] >= k.dst_W)
             return MR_ERR_BAD_ARGUMENT;
@@ -776,7 +781,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
         k.PLANE = plane; k.ppt = mr_ceil_div(k.IH * k.IW, 256); if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED; }
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
     const int taps = k.KH * k.KW;
-    k.wgroup_stride = (long long)taps * cpad_total * mb * (bf16 == 1 ? 8 : 16);
+    for (int p = 0; p < nphase; ++p) k.wgroup_stride[p] = (long long)k.KHp[p] * k.KWp[p] * cpad_total * mb * (bf16 == 1 ? 8 : 16);
     int ck_max = 0;                                              // largest chunk of any source
     for (int s = 0; s < d->num_src; ++s) {
         const int c = k.src_cpad[s] < k.CK ? k.src_cpad[s] : k.CK;

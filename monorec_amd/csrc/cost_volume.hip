@@ -26,6 +26,7 @@
 // bitwise pinning), so warped samples, SSIM values and the validity mask reproduce the CPU bits.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/monorec_hip.h"
 
@@ -357,6 +358,258 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
         atomicAnd((unsigned int*)a.cv + ((long long)b * D + f) * HWp + opy * W + opx, 0u);
 }
 
+// ---- A2  cv_sad_march_kernel: the default configuration (SSIM, 3x3 patch, all-depth validity) without LDS ------------------
+// One WAVE owns a strip of 64 image columns (60 of them produce output, 2 + 2 are halo), a segment of TY rows, one source frame
+// and DP depth planes, and marches down the rows.  Lane l holds the warped pixel of column x0 - 2 + l of the current row in
+// registers; the left / right neighbours of a 3x3 window come from the adjacent lanes through DPP wave shifts
+// (v_add_f32_dpp wave_shr:1 / wave_shl:1 - the shift rides on the add, no LDS, no barrier), the rows above from two rows of
+// register state per quantity: the horizontal sum of the window's top row and the raw values of its middle row.  The additions
+// are issued in the reference's order (row-major over the window, AvgPool2d / conv3d), so every sum - and with it every SSIM
+// value and sad - is bit-identical to cv_sad_kernel's and to the CPU reference; only the data movement differs:
+//   * cv_sad_kernel re-reads 2 x 9 LDS words per channel, plane and SSIM position (39 % bank-conflict cycles at pitch 36/34),
+//     evaluates 612 SSIM positions with 512 threads in two unbalanced rounds and synchronises twice per pair of planes;
+//   * here a window costs 8 VALU adds per quantity, every (pixel, plane) is warped once per strip (halo overhead 64/60 x
+//     (TY+4)/TY), and nothing waits on anything but its own gathers.
+// Image borders: the reflection padding of the SSIM windows (layers.py:112) is realised by warping "virtual" row -1 / H and
+// column -1 / W from the reflected coordinate (1 / H-2, 1 / W-2): the neighbour lane / previous row then IS the reflected tap.
+// Validity (monorec_model.py:218-219): the sign bit of every raw sad plane carries "this plane's border-mask sample was 0"
+// for its own pixel; cv_fuse ANDs the signs of all planes, which is the reference's product over the depth axis.
+// TAG only keeps the compiler from merging two reads of the same neighbour (the middle row's neighbours feed both the window
+// and the next top-row sum): merged, they become one v_mov_b32_dpp plus two plain adds; apart, each rides on its v_add_f32_dpp.
+// Lanes without a neighbour read 0 either way (bound_ctrl with a zero `old`, or `old` = 0 kept).
+template <bool TAG>
+__device__ __forceinline__ float dpp_left(float v) {    // value of lane - 1 (0 for lane 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, TAG));
+}
+template <bool TAG>
+__device__ __forceinline__ float dpp_right(float v) {   // value of lane + 1 (0 for lane 63)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, TAG));
+}
+// ((l + c) + r): the horizontal part of a row-major 3x3 sum
+__device__ __forceinline__ float hsum3(float v) { return (dpp_left<true>(v) + v) + dpp_right<true>(v); }
+// top-row sum, then middle and bottom row tap by tap, in the reference's order
+__device__ __forceinline__ float win9(float hT, float m, float b) {
+    float s = hT + dpp_left<false>(m);
+    s = s + m;
+    s = s + dpp_right<false>(m);
+    s = s + dpp_left<false>(b);
+    s = s + b;
+    return s + dpp_right<false>(b);
+}
+
+struct MarchGeom {
+    int strips, pitch, TY, ysegs, npairs;
+};
+
+// Raw values of one image row held by a wave: x, x^2, x*k per channel and plane; k, k^2 per channel; e per plane.
+template <int DP>
+struct MarchRow {
+    float x[DP][3], xx[DP][3], xk[DP][3];
+    float k[3], kk[3];
+    float e[DP];
+};
+// Horizontal sums ((l + c) + r) of the row two steps back: the top row of the current windows.
+template <int DP>
+struct MarchTop {
+    float x[DP][3], xx[DP][3], xk[DP][3];
+    float k[3], kk[3];
+    float e[DP];
+};
+
+template <int DP>
+struct MarchCtx {
+    const CvArgs& a;
+    const float* kimg;
+    const float* Ki;
+    const float* P;
+    __amdgpu_buffer_rsrc_t img;
+    float kix[3];
+    float depth[DP];
+    const float* pixd;      // per-pixel depths of plane d0 of this sample, or null
+    float* out;             // raw sad plane d0 of frame f, sample b
+    int cx, vx, y0, y1;
+    bool col_in, out_lane;
+};
+
+// One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
+// sad of output row r - 2 (box over the e rows), then turn `mid` into the next top sums.  The caller alternates two MarchRow
+// objects as mid / cur, so the raw rows never move between registers.
+template <int DP, bool PIXD>
+__device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchTop<DP>& top, MarchRow<DP>& mid, MarchRow<DP>& cur,
+                                           unsigned (&hits)[DP]) {
+    const CvArgs& a = c.a;
+    const int H = a.H, W = a.W;
+    const int HWp = H * W;
+    const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;   // fp32(0.01**2), fp32(0.03**2)  layers.py:116-117
+    // ---- warp virtual row r (image row reflect(r)) for DP planes ---------------------------------------------------------
+    int wr = r < 0 ? -r : (r >= H ? 2 * H - 2 - r : r);
+    wr = min(max(wr, 0), H - 1);
+    const int pix = wr * W + c.cx;
+    float ray[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ray[i] = fmaf(c.Ki[3 * i + 2], 1.0f, fmaf(c.Ki[3 * i + 1], (float)wr, c.kix[i]));
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { cur.k[ch] = c.kimg[ch * HWp + pix] + 0.5f; cur.kk[ch] = cur.k[ch] * cur.k[ch]; }
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+        const float dep = PIXD ? c.pixd[(long long)u * HWp + pix] : c.depth[u];
+        const Sample sp = project(ray[0], ray[1], ray[2], dep, c.P, H, W);
+        hits[u] = (hits[u] << 1) | (mask_hit(sp, H, W) ? 1u : 0u);         // monorec_model.py:218-219
+        const Taps tp = tap_offsets(sp, H, W);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float x = bilinear(c.img, ch * HWp * 4, tp, sp) + 0.5f;
+            cur.x[u][ch] = x; cur.xx[u][ch] = x * x; cur.xk[u][ch] = x * cur.k[ch];
+        }
+    }
+    // ---- SSIM row q = r - 1 (windows over virtual rows r-2, r-1, r), channel-weighted -> e --------------------------------
+    const int q = r - 1;
+    const bool row_in = q >= 0 && q < H;                                    // wave-uniform
+    float kmu[3], ksg[3], kmu2[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float mu = div9(win9(top.k[ch], mid.k[ch], cur.k[ch]));       // AvgPool2d(3,1): row-major sum / 9
+        kmu[ch] = mu;
+        kmu2[ch] = mu * mu;
+        ksg[ch] = div9(win9(top.kk[ch], mid.kk[ch], cur.kk[ch])) - mu * mu;  // layers.py:130
+    }
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+        float ev = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float mu_x = div9(win9(top.x[u][ch], mid.x[u][ch], cur.x[u][ch])), mu_y = kmu[ch];
+            const float mu_x_sq = mu_x * mu_x, mu_y_sq = kmu2[ch], mu_xy = mu_x * mu_y;
+            const float sig_x = div9(win9(top.xx[u][ch], mid.xx[u][ch], cur.xx[u][ch])) - mu_x_sq;
+            const float sig_xy = div9(win9(top.xk[u][ch], mid.xk[u][ch], cur.xk[u][ch])) - mu_xy;
+            const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
+            const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[ch] + C2);   // layers.py:134
+            const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
+            ev = (ch == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[ch], ev);
+        }
+        cur.e[u] = (row_in && c.col_in) ? ev : 0.f;                         // zero padding of the 3x3 box (:247)
+    }
+    // ---- 3x3 box over e rows r-3, r-2, r-1 -> sad of output row y = r - 2 ---------------------------------------------
+    const int y = r - 2;
+    if (y >= c.y0 && y < c.y1) {                                            // wave-uniform
+#pragma unroll
+        for (int u = 0; u < DP; ++u) {
+            float sad = win9(top.e[u], mid.e[u], cur.e[u]);
+            if (!(hits[u] & 4u)) sad = -sad;                                // sad >= 0: the sign bit is free (-0.0 keeps it)
+            if (c.out_lane) c.out[(long long)u * HWp + y * W + c.vx] = sad;
+        }
+    }
+    // ---- the middle row becomes the top row of the next step (as horizontal sums) -----------------------------------------
+#pragma unroll
+    for (int u = 0; u < DP; ++u) {
+        top.e[u] = hsum3(mid.e[u]);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            top.x[u][ch] = hsum3(mid.x[u][ch]); top.xx[u][ch] = hsum3(mid.xx[u][ch]); top.xk[u][ch] = hsum3(mid.xk[u][ch]);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { top.k[ch] = hsum3(mid.k[ch]); top.kk[ch] = hsum3(mid.kk[ch]); }
+}
+
+template <int DP, bool PIXD>
+__global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const MarchGeom g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, W = a.W, D = a.D;
+    const int HWp = H * W;
+    const int strip = blockIdx.x % g.strips, yseg = blockIdx.x / g.strips;
+    const int gy = (g.npairs + 3) >> 2;                       // groups of 4 plane sets (one per wave) per frame
+    const int f = blockIdx.y / gy;
+    const int pi = (blockIdx.y - f * gy) * 4 + wave;          // plane set of this wave
+    const int b = blockIdx.z;
+    if (pi >= g.npairs) return;
+    const int d0 = pi * DP;
+
+    const int vx = strip * g.pitch + lane - 2;                // virtual column of this lane
+    int cx = vx < 0 ? -vx : (vx >= W ? 2 * W - 2 - vx : vx);  // reflected (layers.py:112) ...
+    cx = min(max(cx, 0), W - 1);                              // ... and kept inside the image for the lanes nothing reads
+    const int y0 = yseg * g.TY;
+    MarchCtx<DP> c = {a,
+                      a.keyframe + (long long)b * 3 * HWp,
+                      a.kinv + b * 9,
+                      a.proj + ((long long)b * a.F + f) * 12,
+                      __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000),
+                      {0.f, 0.f, 0.f}, {}, PIXD ? a.pix_depths + ((long long)b * D + d0) * HWp : nullptr,
+                      a.sfcv[f] + ((long long)b * D + d0) * HWp,
+                      cx, vx, y0, min(y0 + g.TY, H),
+                      vx >= 0 && vx < W,                      // SSIM positions outside the image contribute 0 to the box (:247)
+                      lane >= 2 && lane < 2 + g.pitch && vx < W};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.kix[i] = c.Ki[3 * i] * (float)cx;   // Kinv[:, 0] * x, the first product of the ray's FMA chain (:199)
+#pragma unroll
+    for (int u = 0; u < DP; ++u) c.depth[u] = PIXD ? 0.f : a.depths[d0 + u];
+
+    MarchTop<DP> top = {};
+    MarchRow<DP> rowA = {}, rowB = {};
+    unsigned hits[DP];                                        // bit j: border-mask sample of the row warped j steps ago != 0
+#pragma unroll
+    for (int u = 0; u < DP; ++u) hits[u] = 0u;
+    const int r_last = c.y1 + 1;
+    for (int r = y0 - 2; r <= r_last; r += 2) {
+        march_step<DP, PIXD>(c, r, top, rowA, rowB, hits);
+        if (r + 1 <= r_last) march_step<DP, PIXD>(c, r + 1, top, rowB, rowA, hits);
+    }
+}
+
+// Per-pixel frame fusion with the raw sads of a pixel held in registers: every sad is read once, every output written once
+// (cv_fuse_kernel reads the F*D raw values three times - twice from L2).  Same arithmetic, same order.
+template <int DD>
+__global__ __launch_bounds__(256) void cv_fuse_reg_kernel(const CvArgs a) {
+    const int HWp = a.H * a.W;
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int py = p / a.W, px = p - py * a.W;
+    const bool border = py >= a.border && py < a.H - a.border && px >= a.border && px < a.W - a.border;     // mask_to_warp[0], :219
+    // plane d of a volume = buffer offset p*4 (per lane) + d*HW*4 (scalar): no 64-bit per-plane addresses in VGPRs; lanes beyond
+    // the image read 0 / write nothing through the descriptor's range check
+    const int voff = p < HWp ? p * 4 : -1;
+    const int vol_bytes = DD * HWp * 4;
+    float num[DD];
+    float wsum = 0.f;
+    for (int f = 0; f < a.F; ++f) {
+        const __amdgpu_buffer_rsrc_t sf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.sfcv[f] + (long long)b * DD * HWp), 0, vol_bytes, 0x00020000);
+        float v[DD];
+#pragma unroll
+        for (int d = 0; d < DD; ++d) v[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sf, voff, d * HWp * 4, 0));
+        bool valid = border;
+        float smin = INFINITY;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+            valid = valid && !(__float_as_uint(v[d]) & 0x80000000u);
+            v[d] = fabsf(v[d]);
+            smin = fminf(smin, v[d]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+            const float df = v[d] - smin;
+            const float ev = expf(-a.alpha * (df * df));                 // :257
+            se = d == 0 ? ev : se + ev;
+        }
+        const float vm = valid ? 1.f : 0.f;
+        float w = 1.0f - a.inv_dm1 * (se - 1.0f);                        // :258
+        w = w * vm;                                                      // :260
+        wsum = f == 0 ? w : wsum + w;                                    // :264
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((1.0f - v[d] * 2.0f) * vm), sf, voff, d * HWp * 4, 0);   // :251
+            const float t = v[d] * w;                                    // :262
+            num[d] = f == 0 ? t : num[d] + t;
+        }
+    }
+    const bool nz = wsum != 0.f;
+    const __amdgpu_buffer_rsrc_t cvr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cv + (long long)b * DD * HWp), 0, vol_bytes, 0x00020000);
+#pragma unroll
+    for (int d = 0; d < DD; ++d)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nz ? 1.0f - 2.0f * (num[d] / wsum) : 0.f), cvr, voff, d * HWp * 4, 0);   // :266-269
+}
+
 // ---- generic patch size (cv_patch_size != 3; monorec_model.py:138-142,247) -----------------------------------------------
 // P x P zero-padded box of the photometric term instead of 3x3, border radius P / 2 + 1.  Rarely used (no reference config sets
 // it), so this variant trades speed for simplicity: 32x8 tile, one depth plane per iteration, every stage a strided loop over its
@@ -629,9 +882,65 @@ void launch_sad_opt(const CvArgs& k, int opt, dim3 grid, hipStream_t stream) {
     }
 }
 
+void launch_fuse(const CvArgs& k, bool plane_flags, bool tiled, hipStream_t stream) {
+    const long long total = (long long)k.B * k.H * k.W;
+    if (!plane_flags && !tiled && (k.D == 32 || k.D == 48 || k.D == 64)) {
+        const dim3 grid((unsigned)(((long long)k.H * k.W + 255) / 256), (unsigned)k.B);
+        if (k.D == 32) hipLaunchKernelGGL(cv_fuse_reg_kernel<32>, grid, dim3(256), 0, stream, k);
+        else if (k.D == 48) hipLaunchKernelGGL(cv_fuse_reg_kernel<48>, grid, dim3(256), 0, stream, k);
+        else hipLaunchKernelGGL(cv_fuse_reg_kernel<64>, grid, dim3(256), 0, stream, k);
+        return;
+    }
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (plane_flags) hipLaunchKernelGGL(cv_fuse_kernel<true>, dim3(blocks), dim3(256), 0, stream, k);
+    else hipLaunchKernelGGL(cv_fuse_kernel<false>, dim3(blocks), dim3(256), 0, stream, k);
+}
+
+// Marching kernel geometry: strips of <= 60 output columns (equal pitch, so that every strip carries the same load) and row
+// segments of TY rows.  A wave is the unit of work (it never migrates), so the makespan is ceil(waves / SIMDs) wave-lengths: TY
+// trades the 4 halo rows every segment warps twice against how evenly the waves divide over the chip's 1024 SIMDs
+// (c2: TY 32 -> 2304 waves = 3 rounds at 2.25 average; TY 37 -> 2016 waves = 2 full rounds).
+MarchGeom march_geometry(const CvArgs& a, int dp) {
+    MarchGeom g;
+    g.strips = (a.W + 59) / 60;
+    g.pitch = (a.W + g.strips - 1) / g.strips;
+    g.npairs = a.D / dp;
+    static const int forced = [] { const char* e = getenv("MR_CV_MARCH_TY"); return e ? atoi(e) : 0; }();   // tuning aid
+    int best_ty = 64;
+    if (forced >= 4) best_ty = forced;
+    else {
+        const double simds = 1024.0;
+        const long long per_seg = (long long)g.strips * a.F * a.B * g.npairs;
+        double best = -1.0;
+        for (int ty = 8; ty <= 64; ++ty) {
+            const int segs = (a.H + ty - 1) / ty;
+            const double waves = (double)per_seg * segs;
+            const double rounds = waves / simds;
+            const double balance = rounds >= 8.0 ? 1.0 : rounds / (double)(long long)(rounds + 0.999999);
+            const double rows = (double)a.H / ((double)segs * (ty + 4));      // useful rows / warped rows
+            const double score = balance * rows;
+            if (score > best + 1e-9) { best = score; best_ty = ty; }
+        }
+    }
+    g.TY = best_ty;
+    g.ysegs = (a.H + best_ty - 1) / best_ty;
+    return g;
+}
+
 template <int TX, int TY>
-int launch_cv(const CvArgs& a, int mode, bool plane_flags, hipStream_t stream) {
+int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream_t stream) {
     CvArgs k = a;
+    if (mode == 1 && !plane_flags && !tiled) {
+        // default configuration: LDS-free marching kernel, two depth planes per wave
+        const MarchGeom g = march_geometry(a, 2);
+        const dim3 grid((unsigned)(g.strips * g.ysegs), (unsigned)(a.F * ((g.npairs + 3) / 4)), (unsigned)a.B);
+        if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true>), grid, dim3(256), 0, stream, k, g);
+        else hipLaunchKernelGGL((cv_sad_march_kernel<2, false>), grid, dim3(256), 0, stream, k, g);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        launch_fuse(k, false, false, stream);
+        return (int)hipGetLastError();
+    }
     k.tiles_x = (a.W + TX - 1) / TX;
     const int tiles = k.tiles_x * ((a.H + TY - 1) / TY);
     // depth chunks: enough workgroups to put >= 4 on every CU, chunks of an even number of planes
@@ -653,10 +962,7 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, hipStream_t stream) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const long long total = (long long)a.B * a.H * a.W;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (plane_flags) hipLaunchKernelGGL(cv_fuse_kernel<true>, dim3(blocks), dim3(256), 0, stream, k);
-    else hipLaunchKernelGGL(cv_fuse_kernel<false>, dim3(blocks), dim3(256), 0, stream, k);
+    launch_fuse(k, plane_flags, tiled, stream);
     return (int)hipGetLastError();
 }
 
@@ -695,21 +1001,16 @@ int launch_cv_patch(const CvArgs& a, int mode, bool plane_flags, int R, hipStrea
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const long long total = (long long)a.B * a.H * a.W;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (plane_flags) hipLaunchKernelGGL(cv_fuse_kernel<true>, dim3(blocks), dim3(256), 0, stream, k);
-    else hipLaunchKernelGGL(cv_fuse_kernel<false>, dim3(blocks), dim3(256), 0, stream, k);
+    launch_fuse(k, plane_flags, false, stream);
     return (int)hipGetLastError();
 }
 
-}  // namespace
-
-extern "C" int mr_cost_volume_patch_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
-                                       const float* kinv, const float* proj, const float* depths,
-                                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
-                                       float alpha, const float* channel_weights, int32_t use_ssim,
-                                       const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size,
-                                       float* cost_volume, float* const* sfcv, void* stream) {
+int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t num_frames,
+                      const float* kinv, const float* proj, const float* depths,
+                      int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                      float alpha, const float* channel_weights, int32_t use_ssim,
+                      const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size, bool tiled,
+                      float* cost_volume, float* const* sfcv, void* stream) {
     if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
     if (patch_size < 1 || patch_size > 7 || !(patch_size & 1)) return MR_ERR_UNSUPPORTED;
     if (!sfcv_mult_mask && num_depths < num_frames) return MR_ERR_UNSUPPORTED;      // validity words live in planes 0..F-1
@@ -732,8 +1033,30 @@ extern "C" int mr_cost_volume_patch_f32(const float* keyframe, const float* cons
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
     a.border = patch_size / 2 + 1;                                                                   // :139
     if (height < 2 * a.border + 1 || width < 2 * a.border + 1) return MR_ERR_BAD_ARGUMENT;
-    if (patch_size == 3) return launch_cv<32, 16>(a, use_ssim, !sfcv_mult_mask, (hipStream_t)stream);
+    if (patch_size == 3) return launch_cv<32, 16>(a, use_ssim, !sfcv_mult_mask, tiled, (hipStream_t)stream);
     return launch_cv_patch(a, use_ssim, !sfcv_mult_mask, patch_size / 2, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" int mr_cost_volume_patch_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                       const float* kinv, const float* proj, const float* depths,
+                                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                       float alpha, const float* channel_weights, int32_t use_ssim,
+                                       const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size,
+                                       float* cost_volume, float* const* sfcv, void* stream) {
+    return cost_volume_entry(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                             channel_weights, use_ssim, pixel_depths, sfcv_mult_mask, patch_size, false, cost_volume, sfcv, stream);
+}
+
+extern "C" int mr_cost_volume_tiled_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                       const float* kinv, const float* proj, const float* depths,
+                                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                       float alpha, const float* channel_weights, int32_t use_ssim,
+                                       const float* pixel_depths, int32_t sfcv_mult_mask,
+                                       float* cost_volume, float* const* sfcv, void* stream) {
+    return cost_volume_entry(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                             channel_weights, use_ssim, pixel_depths, sfcv_mult_mask, 3, true, cost_volume, sfcv, stream);
 }
 
 extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, int32_t num_frames,

@@ -86,6 +86,25 @@ def transposed_phase_weights(wt):
     return out
 
 
+def upconv_phase_weights(w):
+    """layers.Upconv (model/layers.py:349-356): nearest x2 -> pad (0, 1, 0, 1) -> conv 2x2, as four convolutions on the
+    LOW-resolution input, one per output parity (py, px).
+
+    Output (2y + py, 2x + px) reads the upsampled rows 2y + py + dy, dy = 0, 1: for py = 0 both are input row y (the two filter
+    rows add up), for py = 1 they are input rows y and y + 1 (zero below the image: the bottom pad); same for columns.  Parity
+    (py, px) therefore is a (1 + py) x (1 + px) filter with pad 0 - 9 multiply-adds per 2x2 output block instead of 16.  The
+    summed taps are formed in fp64 and rounded once (the reference adds the products instead; the difference is rounding
+    noise of the fp32 accumulation, far inside the 1e-4 bar).  w: (Cout, Cin, 2, 2) -> {(py, px): (Cout, Cin, 1 + py, 1 + px)}."""
+    wd = w.detach().double()
+    out = {}
+    for py in (0, 1):
+        r = wd if py == 1 else wd[:, :, 0:1, :] + wd[:, :, 1:2, :]
+        for px in (0, 1):
+            c = r if px == 1 else r[:, :, :, 0:1] + r[:, :, :, 1:2]
+            out[(py, px)] = c.float().contiguous()
+    return out
+
+
 def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4):
     """Tile geometry used by mr_conv2d_f32 for a given NB / waves per workgroup (mirrors derive() in csrc/conv_mfma.hip)."""
     twb = 2 if out_w >= 32 else 1
@@ -127,9 +146,10 @@ def _load_tuned():
 _load_tuned()
 
 
-def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False):
+def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
+    """`mixed_phases`: the phases sweep different tap counts (phase-decomposed Upconv: 1, 2, 2 and 4 taps of a 2x2 tile)."""
     return (f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
-            + ("", "_bf16", "_bf16x3")[int(bf16)])
+            + ("u" if mixed_phases else "") + ("", "_bf16", "_bf16x3")[int(bf16)])
 
 
 def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False):
@@ -166,11 +186,11 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
     return out
 
 
-def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, bf16=False):
+def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, bf16=False, mixed_phases=False):
     """(MB, NB, split_k, CK) for mr_conv2d_f32.  A tuned table (tools/tune_conv.py, measured on MI355X)
     wins; otherwise a model: biggest register tile that still puts >= 3 workgroups on each of the 256 CUs,
     deepest chunk that keeps >= 3 workgroups' LDS on a CU, split-K only to fill the machine."""
-    sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16)
+    sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16, mixed_phases)
     if sig in TUNED:
         return TUNED[sig]
     if int(bf16) == 2:
@@ -239,6 +259,9 @@ class Plan:
         self.keep = []          # packed weights / biases (device tensors kept alive)
         self.stages = {"encoder": [], "encoder_tail": [], "cv": [], "main": []}
         self.conv_log = []      # (name, macs, mb, nb, split_k, wgs) for bench / tuning
+        self.input_ptr = {}       # "keyframe" -> device pointer the launches read the keyframe from (resident copy or the caller's tensor)
+        self._input_srcs = []     # (ConvDesc, source index, "keyframe"): descriptor slots that follow input_ptr
+        self._frame_ptrs = None   # ctypes array of the F source-frame pointers handed to the cost-volume launch
         self._ws_floats = {}      # stage -> floats: stages may run concurrently on different streams,
         self._pending_ws = []     # so every stage gets its own split-K workspace
         if build:
@@ -280,7 +303,7 @@ class Plan:
 
     def conv(self, stage, name, srcs, weight, bias, out, *, stride=(1, 1), pad=(0, 0), grid=None,
              act=ACT_NONE, p0=0.0, p1=0.0, in_mode=IN_DIRECT, tf=TF_NONE, residual=None,
-             out_step=(1, 1), out_off=(0, 0), out_ch_offset=0, phases=None):
+             out_step=(1, 1), out_off=(0, 0), out_ch_offset=0, phases=None, ref_macs=None):
         """Append one mr_conv2d_f32 launch. srcs: list of (N,C,Hs,Ws) tensors concatenated on channels.
         phases: optional list of 4 (weight, pad_top, pad_left, out_off_h, out_off_w) run in one launch."""
         n, _, hs, ws = srcs[0].shape
@@ -289,18 +312,23 @@ class Plan:
             assert s.shape[0] == n and s.shape[2] == hs and s.shape[3] == ws and s.is_contiguous()
         w0 = weight if phases is None else phases[0][0]
         cout, cin, kh, kw = w0.shape
+        if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
+            kh, kw = max(p[0].shape[2] for p in phases), max(p[0].shape[3] for p in phases)
+        mixed = phases is not None and any(tuple(p[0].shape[2:]) != (kh, kw) for p in phases)
         assert cin == sum(src_channels), (name, cin, src_channels)
         out_h, out_w = grid
         nph = 1 if phases is None else len(phases)
         bf16 = self.bf16 if (in_mode != IN_MAXPOOL2 and tf == TF_NONE) else 0   # the bf16 modes need the LDS-DMA staging
         sched = self.schedule_override.get(name) or choose_schedule(cout, src_channels, kh, kw, stride[0], stride[1],
-                                                                    out_h, out_w, n, nph, bf16)
+                                                                    out_h, out_w, n, nph, bf16, mixed)
         mb, nb, split_k, ck = sched[:4]
         waves = sched[4] if len(sched) > 4 else 4
         d = ConvDesc()
         for i, s in enumerate(srcs):
             d.src[i] = s.data_ptr()
             d.src_channels[i] = src_channels[i]
+            if "keyframe" in self.buf and s is self.buf["keyframe"]:
+                self._input_srcs.append((d, i, "keyframe"))
         d.num_src, d.batch, d.src_h, d.src_w = len(srcs), n, hs, ws
         d.in_mode, d.in_transform = in_mode, tf
         d.kh, d.kw, d.stride_h, d.stride_w, d.pad_top, d.pad_left = kh, kw, stride[0], stride[1], pad[0], pad[1]
@@ -318,6 +346,7 @@ class Plan:
             for i, (wp, pt, pl, oh, ow) in enumerate(phases):
                 d.phase_weights[i] = self._dev(pack_conv_weight(wp, src_channels, mb, ck, bf16)).data_ptr()
                 d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh, ow
+                d.phase_kh[i], d.phase_kw[i] = wp.shape[2], wp.shape[3]
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         if residual is not None:
             assert residual.shape == out.shape
@@ -334,17 +363,19 @@ class Plan:
         lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} sched={sched}")
-        macs = nph * n * out_h * out_w * cout * cin * kh * kw
+        taps = kh * kw if phases is None else sum(p[0].shape[2] * p[0].shape[3] for p in phases)
+        macs = n * out_h * out_w * cout * cin * taps
         geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves)
         wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
-        self.conv_log.append(dict(name=name, macs=macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
-                                  sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16), bf16=bf16,
+                                  sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16, mixed), bf16=bf16,
                                   spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),
                                             stride=tuple(stride), pad=tuple(pad), grid=(out_h, out_w), in_mode=in_mode,
                                             tf=tf, act=act, p0=p0, p1=p1, residual=residual is not None,
                                             out_shape=tuple(out.shape), out_step=tuple(out_step), out_off=tuple(out_off),
-                                            phases=None if phases is None else [(pt, pl, oh, ow) for _, pt, pl, oh, ow in phases])))
+                                            phases=None if phases is None else [(pt, pl, oh, ow, int(wp.shape[2]), int(wp.shape[3]))
+                                                                                for wp, pt, pl, oh, ow in phases])))
         self.keep += [d, out, residual] + list(srcs)      # the descriptor only holds raw pointers
         self.stages[stage].append((name, self._launch_conv(d, name)))
         return out
@@ -384,6 +415,16 @@ class Plan:
         return self.conv(stage, name, srcs, None, bias, out, stride=(1, 1), grid=(h, w), act=ACT_LEAKY_RELU,
                          p0=LEAKY_SLOPE, out_step=(2, 2), phases=phases)
 
+    def upconv(self, stage, name, srcs, wkey, bkey, out):
+        """layers.Upconv (model/layers.py:349-356) phase-decomposed on the low-resolution input: the 4 output parities as the 4
+        phases of ONE launch with 1, 2, 2 and 4 taps (upconv_phase_weights) - 2.25 instead of 4 multiply-adds per output, the
+        input staged by the direct dwordx4 LDS-DMA path instead of the upsampling dword reads."""
+        h, w = srcs[0].shape[2], srcs[0].shape[3]
+        phases = [(wp, 0, 0, py, px) for (py, px), wp in upconv_phase_weights(self.sd[wkey]).items()]
+        cout, cin = self.sd[wkey].shape[:2]
+        return self.conv(stage, name, srcs, None, self.sd[bkey] if bkey else None, out, stride=(1, 1), grid=(h, w), act=ACT_NONE,
+                         out_step=(2, 2), phases=phases, ref_macs=srcs[0].shape[0] * 4 * h * w * cout * cin * 4)
+
     def add(self, stage, name, fn):
         self.stages[stage].append((name, fn))
 
@@ -406,8 +447,10 @@ class Plan:
         # input normalisation as its own 3 us pass so that the stem runs on the DMA-staged conv path
         kfn = self.alloc("keyframe_norm", B, 3, H, W)
 
-        def run_norm(stream, src=kf, dst=kfn):
-            _lib.check(lib.mr_resnet_normalize_f32(src.data_ptr(), dst.data_ptr(), B * 3 * H * W, stream),
+        self.input_ptr["keyframe"] = kf.data_ptr()
+
+        def run_norm(stream, dst=kfn):
+            _lib.check(lib.mr_resnet_normalize_f32(self.input_ptr["keyframe"], dst.data_ptr(), B * 3 * H * W, stream),
                        "mr_resnet_normalize_f32")
         self.add(st, "resnet.normalize", run_norm)
         self.conv(st, "resnet.conv1", [kfn], w, b, f0, stride=(2, 2), pad=(3, 3), grid=(H // 2, W // 2), act=ACT_RELU)
@@ -451,17 +494,18 @@ class Plan:
         frame_ptrs = (ctypes.c_void_p * F)(*[frames[f].data_ptr() for f in range(F)])
         sfcv_ptrs = (ctypes.c_void_p * F)(*[sfcv[f].data_ptr() for f in range(F)])
         self.keep += [frame_ptrs, sfcv_ptrs]
+        self._frame_ptrs = frame_ptrs
         kinv, proj, depths = self.buf["kinv"], self.buf["proj"], self.buf["depths"]
 
         def run_cv(stream):
             pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
             if self.cv_patch_size == 3:
-                _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                _lib.check(lib.mr_cost_volume_mode_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                        depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                        1 if self.sfcv_mult_mask else 0,
                                                        cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
             else:
-                _lib.check(lib.mr_cost_volume_patch_f32(kf.data_ptr(), frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                _lib.check(lib.mr_cost_volume_patch_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                         depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                         1 if self.sfcv_mult_mask else 0, self.cv_patch_size,
                                                         cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_patch_f32")
@@ -526,8 +570,7 @@ class Plan:
             up_ch = sd[f"{am}.dec.{i}.0.conv.weight"].shape[0]
             dec_ch = {i: sd[f"{am}.dec.{i}.1.conv.weight"].shape[0]}
             u = self.alloc(f"mask.dec{i}.up", B, up_ch, hi, wi)
-            self.same_conv(st, f"mask.dec{i}.0", x_srcs, f"{am}.dec.{i}.0.conv.weight", f"{am}.dec.{i}.0.conv.bias", u,
-                           act=ACT_NONE, in_mode=IN_UPSAMPLE2)                        # Upconv, layers.py:353-356
+            self.upconv(st, f"mask.dec{i}.0", x_srcs, f"{am}.dec.{i}.0.conv.weight", f"{am}.dec.{i}.0.conv.bias", u)   # layers.py:349-356
             cat = [cvf[3 - i], u] if i == 3 else [cvf[3 - i], mfeats[2 - i], u]      # :374-380
             a = self.alloc(f"mask.dec{i}.a", B, dec_ch[i], hi, wi)
             xo = self.alloc(f"mask.dec{i}.x", B, dec_ch[i], hi, wi)
@@ -607,10 +650,37 @@ class Plan:
         head(3, x4, 0)
         self.preds = preds
 
+    # ------------------------------------------------------------------ inputs
+    def bind_inputs(self, keyframe, frames, in_place):
+        """Point every launch that reads the keyframe / source frames at the caller's tensors (`in_place`: dense fp32 tensors of
+        the plan's shape on its device - no device copy at all) or at the resident buffers after copying into them (anything
+        else, and always under hipGraph replay, whose captured launches keep their pointers).  Returns True when bound in place."""
+        ok = in_place and all(t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device and
+                              tuple(t.shape) == (self.B, 3, self.H, self.W) for t in [keyframe] + list(frames))
+        if ok:
+            kptr, fptrs = keyframe.data_ptr(), [f.data_ptr() for f in frames]
+        else:
+            self.buf["keyframe"].copy_(keyframe)
+            for f in range(self.F):
+                self.buf["frames"][f].copy_(frames[f])
+            kptr, fptrs = self.buf["keyframe"].data_ptr(), [self.buf["frames"][f].data_ptr() for f in range(self.F)]
+        self.input_ptr["keyframe"] = kptr
+        for f in range(self.F):
+            self._frame_ptrs[f] = fptrs[f]
+        for d, i, _ in self._input_srcs:
+            d.src[i] = kptr
+        return ok
+
     # ------------------------------------------------------------------ execution
     def run_stage(self, stage, stream):
         for _, fn in self.stages[stage]:
             fn(stream)
 
     def conv_macs(self):
+        """Multiply-adds the launches execute."""
         return sum(c["macs"] for c in self.conv_log)
+
+    def conv_ref_macs(self):
+        """Multiply-adds of the reference's Conv2d / ConvTranspose2d calls (forward hooks): the algorithmic work.
+        Differs from conv_macs() by the phase-decomposed Upconv layers (9 instead of 16 taps per 2x2 output block)."""
+        return sum(c["ref_macs"] for c in self.conv_log)

@@ -258,6 +258,7 @@ class MonoRecModel(nn.Module):
         self._packed_state = None
         self._lock = threading.RLock()   # one enqueue at a time per model object (nn.DataParallel calls replicas from threads)
         self._warned_encoder = False
+        self._geometry_override = None   # (kinv (B,9), proj (B,F,12)) CPU tensors replacing host_geometry's result; tests only
 
         self._feature_extractor = ResnetEncoder(num_layers=18, pretrained=True)
         if self.freeze_resnet:
@@ -455,11 +456,12 @@ class MonoRecModel(nn.Module):
         main.wait_event(inputs_ready)
         with torch.cuda.stream(main):
             # 2. images into the slot's resident buffers; ResNet encoder stage (pose independent) on its own stream
-            plan.buf["keyframe"].copy_(keyframe)
-            for f in range(nf):
-                plan.buf["frames"][f].copy_(frames[f])
+            # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
+            # captured launches keep their pointers - goes through the slot's resident buffers
+            plan.bind_inputs(keyframe, frames, in_place=not self._hip_graph)
             for t in [keyframe] + frames:
                 t.record_stream(main)
+                t.record_stream(enc)
             enc.wait_stream(main)
             self._run_stage(key, plan, "encoder", enc)
             enc_done = torch.cuda.Event()
@@ -478,6 +480,8 @@ class MonoRecModel(nn.Module):
                 mats_done.synchronize()                       # a ~100 byte copy enqueued before the encoder launches: done by now
                 hm = plan.host_mats
             kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+            if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
+                kinv, proj = self._geometry_override
             if plan.geom_uploaded is not None:
                 plan.geom_uploaded.synchronize()              # the slot's previous upload has left the pinned buffer (long ago)
             plan.host_geom[: b * 9].copy_(kinv.reshape(-1))

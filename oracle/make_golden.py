@@ -136,6 +136,51 @@ def pin_low_level():
     return facts
 
 
+def fixture_geometry(batch):
+    """kinv (B,9) / proj (B,F,12) exactly as the reference forms them (the oracle's `projection_matrix` and `inverse(K)` lines, which
+    make_golden pins on the reference) - asserted equal to the product's host function `monorec_amd.model.host_geometry`."""
+    from monorec_amd.model import host_geometry
+    b, nf = batch["keyframe"].shape[0], len(batch["frames"])
+    kinv = torch.stack([torch.inverse(batch["keyframe_intrinsics"][n]).unsqueeze(0)[:, :3, :3].reshape(9) for n in range(b)])
+    proj = torch.stack([torch.stack([orc.projection_matrix(batch["intrinsics"][f][n], batch["poses"][f][n],
+                                                           batch["keyframe_pose"][n]).reshape(12) for f in range(nf)]) for n in range(b)])
+    hk, hp = host_geometry(batch["keyframe_intrinsics"], batch["keyframe_pose"], batch["intrinsics"], batch["poses"])
+    assert torch.equal(hk, kinv) and torch.equal(hp, proj), "host_geometry deviates from the reference's matrix algebra"
+    return kinv, proj
+
+
+def fixture_validity(batch, steps):
+    """(F, H, W) all-depth validity of the single-frame volumes (monorec_model.py:218-219) on this host, np.packbits'ed: the
+    strided samples of the big volumes cannot tell whether a handful of pixels flipped."""
+    st = {}
+    orc.cost_volume(batch, steps=steps, stages=st)
+    valid = torch.stack(st["valid"])[0].squeeze(1)                  # sample 0: (F,H,W)
+    return np.packbits(valid.numpy().astype(np.uint8))
+
+
+def patch_kitti_geometry():
+    """Add geom.kinv / geom.proj to an existing kitti_example_169.npz (same host as the one that generated it): checks first that
+    the oracle run here still reproduces the stored reference output bit for bit."""
+    path = os.path.join(GOLDEN, "kitti_example_169.npz")
+    z = dict(np.load(path))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import Golden
+    g = Golden("kitti_example_169")
+    batch = g.make_inputs()
+    from monorec_amd.model import MonoRecModel
+    sd = synth.seeded_state_dict(MonoRecModel(cv_depth_steps=32).state_dict(), seed=0)
+    out = orc.forward(sd, batch, cv_depth_steps=32)
+    assert np.array_equal(out["result"].numpy(), z["result.full"]), "this host does not reproduce the fixture: regenerate it instead"
+    kinv, proj = fixture_geometry(batch)
+    z["geom.kinv"], z["geom.proj"] = kinv.numpy(), proj.numpy()
+    z["geom.valid_bits"] = fixture_validity(batch, 32)
+    sfz = [(s[0] == 0).all(0) for s in out["single_frame_cvs"]]    # consistency: invalid <=> the stored volume is 0 over all depths
+    vb = np.unpackbits(z["geom.valid_bits"]).reshape(len(sfz), *sfz[0].shape).astype(bool)
+    assert all(np.array_equal(~vb[f], sfz[f].numpy()) for f in range(len(sfz)))
+    np.savez_compressed(path, **z)
+    print("kitti_example_169: oracle here == stored reference output bit for bit; stored geom.kinv", kinv.shape, "geom.proj", proj.shape)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -442,6 +487,12 @@ def main():
     store["input.poses"] = torch.stack(kbatch["poses"]).numpy()
     store["input.intrinsics"] = torch.stack(kbatch["intrinsics"]).numpy()
     store["input.target"] = ktarget.numpy()
+    # the 3x3 / 3x4 matrices the reference derives from these poses on THIS host (monorec_model.py:171,198,207): real poses
+    # sit ~80 m from the origin, inverse(pose_f) @ pose_kf cancels in fp32 and LAPACK on another CPU rounds it differently -
+    # with the matrices stored, a consumer of the C ABI can be checked against this fixture without that host dependence
+    kinv_fix, proj_fix = fixture_geometry(kbatch)
+    store["geom.kinv"], store["geom.proj"] = kinv_fix.numpy(), proj_fix.numpy()
+    store["geom.valid_bits"] = fixture_validity(kbatch, 32)        # the full all-depth validity maps (F,H,W), bit packed
     store["input.lidar_idx"], store["input.lidar_val"] = lidar_idx, lidar_val      # the raw 370x1226 depth PNG, sparse
     store["input.lidar_shape"] = np.array(lidar_png.shape, dtype=np.int64)
     store["input.lidar_target"] = lidar_ref.numpy()                                # preprocess_depth_annotated_lidar of it
@@ -601,4 +652,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--patch-kitti-geometry" in sys.argv:
+        patch_kitti_geometry()
+    else:
+        main()

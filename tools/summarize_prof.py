@@ -14,6 +14,48 @@ import sqlite3
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def short_kernel_name(k):
+    """'void (anonymous namespace)::cv_sad_kernel<32, 16, 1, 0>((anonymous namespace)::CvArgs)' -> 'cv_sad_kernel<32, 16, 1, 0>':
+    drop the namespace and return type first, THEN cut the parameter list (round 1 cut at the first '(' and collapsed every
+    anonymous-namespace kernel into one nameless bucket)."""
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    depth = 0
+    for i, ch in enumerate(k):           # the parameter list starts at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return k[:i].strip()
+    return k.strip()
+
+
+def family_metrics(agg, match):
+    """Counters summed over every kernel whose name contains `match`, with the derived figures the bench line quotes."""
+    tot = collections.defaultdict(float)
+    n = 0
+    for k, v in agg.items():
+        if match in k:
+            for cn, d in v.items():
+                tot[cn] += d["sum"]
+            n = max(n, max(d["dispatches"] for d in v.values()))
+    if not n:
+        return None
+    d = {"dispatches": n}
+    for cn in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES",
+               "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE",
+               "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+        if cn in tot:
+            d[cn + "_per_dispatch"] = tot[cn] / n
+    if "SQ_LDS_BANK_CONFLICT" in tot and tot.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"]
+    if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+        d["hbm_bytes_per_dispatch_raw"] = (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / n
+    if "SQ_ACTIVE_INST_VALU" in tot and "SQ_BUSY_CYCLES" in tot and tot["SQ_BUSY_CYCLES"]:
+        d["note_valu"] = "SQ_INSTS_VALU = wave-level VALU instructions; x64 lanes / 78.6e12 lane-instr/s = VALU-issue floor of the launch"
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -42,7 +84,7 @@ def main():
         conv = collections.defaultdict(float)
         conv_n = 0
         for k, v in agg.items():
-            short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            short = short_kernel_name(k)
             summary[short] = v
             if "conv_mfma_kernel" in k:
                 for cn, d in v.items():
@@ -67,6 +109,10 @@ def main():
             d["wait_any_frac_of_wave_cycles"] = conv["SQ_WAIT_ANY"] / conv["SQ_WAVE_CYCLES"]
         if "SQ_LDS_BANK_CONFLICT" in conv:
             d["lds_bank_conflict_cycles"] = conv["SQ_LDS_BANK_CONFLICT"]
+        for fam in ("cv_sad", "cv_fuse"):
+            m = family_metrics(agg, fam)
+            if m:
+                derived[fam + "_kernels"] = m
         with open(os.path.join(out_dir, f"{args.tag}_pmc_summary.json"), "w") as f:
             json.dump({"derived": derived, "per_kernel": summary}, f, indent=1, sort_keys=True)
         print(json.dumps(derived, indent=1))

@@ -64,7 +64,7 @@ def build_candidate(spec, sched, tensors, bf16=False):
     srcs, out, res, weight, bias, phase_w = tensors
     phases = None
     if spec["phases"] is not None:
-        phases = [(phase_w[i], *spec["phases"][i]) for i in range(len(spec["phases"]))]
+        phases = [(phase_w[i], *spec["phases"][i][:4]) for i in range(len(spec["phases"]))]
     plan.conv("main", "t", srcs, weight, bias, out, stride=spec["stride"], pad=spec["pad"], grid=spec["grid"],
               act=spec["act"], p0=spec["p0"], p1=spec["p1"], in_mode=spec["in_mode"], tf=spec["tf"],
               residual=res, out_step=spec["out_step"], out_off=spec["out_off"], phases=phases)
@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--final-reps", type=int, default=20, help="launches per round of the second pass (0 = skip it)")
     ap.add_argument("--bf16", action="store_true", help="tune the MR_COMPUTE_BF16 launches (hip_bf16=True plans)")
     ap.add_argument("--bf16x3", action="store_true", help="tune the MR_COMPUTE_BF16X3 launches (hip_bf16x3=True plans)")
+    ap.add_argument("--only", default=None, help="tune only the layers whose name contains one of these comma-separated strings")
+    ap.add_argument("--missing", action="store_true", help="tune only the layer signatures the table has no entry for")
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
@@ -106,6 +108,10 @@ def main():
     g = torch.Generator().manual_seed(0)
     for c in plan.conv_log:
         if c["sig"] is None or c["sig"] in seen:
+            continue
+        if args.only and not any(tok in c["name"] for tok in args.only.split(",")):
+            continue
+        if args.missing and c["sig"] in table:
             continue
         seen.add(c["sig"])
         spec = c["spec"]
@@ -130,7 +136,7 @@ def main():
         res = torch.randn(*spec["out_shape"], generator=g).to(DEV) if spec["residual"] else None
         weight = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
         bias = torch.randn(cout, generator=g)
-        phase_w = [torch.randn(cout, cin, kh, kw, generator=g) * 0.05 for _ in range(nph)] if nph > 1 else None
+        phase_w = [torch.randn(cout, cin, ph[4], ph[5], generator=g) * 0.05 for ph in spec["phases"]] if nph > 1 else None
         best = None
         rows = []
         for cd in keep:

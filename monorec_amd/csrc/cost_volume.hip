@@ -385,34 +385,118 @@ template <bool TAG>
 __device__ __forceinline__ float dpp_right(float v) {   // value of lane + 1 (0 for lane 63)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, TAG));
 }
-// ((l + c) + r): the horizontal part of a row-major 3x3 sum
-__device__ __forceinline__ float hsum3(float v) { return (dpp_left<true>(v) + v) + dpp_right<true>(v); }
-// top-row sum, then middle and bottom row tap by tap, in the reference's order
-__device__ __forceinline__ float win9(float hT, float m, float b) {
-    float s = hT + dpp_left<false>(m);
-    s = s + m;
-    s = s + dpp_right<false>(m);
-    s = s + dpp_left<false>(b);
-    s = s + b;
-    return s + dpp_right<false>(b);
+// The window sums of one step are NQ independent chains of dependent adds (a dependent VALU instruction issues ~8 cycles after
+// its producer on this chip, an independent one ~4.6 cycles after the previous instruction of the wave): all chains advance one
+// tap at a time, level by level, so that neighbouring instructions are independent.
+//   s = ((l + c) + r) of `m`: the horizontal part of a row-major 3x3 sum
+template <int N>
+__device__ __forceinline__ void hsum3_batch(float (&out)[N], const float (&m)[N]) {
+    float t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = dpp_left<true>(m[i]) + m[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = t[i] + dpp_right<true>(m[i]);
+}
+//   top-row sum, then middle and bottom row tap by tap, in the reference's order (AvgPool2d / conv3d: row-major)
+template <int N>
+__device__ __forceinline__ void win9_batch(float (&s)[N], const float (&hT)[N], const float (&m)[N], const float (&b)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = hT[i] + dpp_left<false>(m[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = s[i] + m[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = s[i] + dpp_right<false>(m[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = s[i] + dpp_left<false>(b[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = s[i] + b[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = s[i] + dpp_right<false>(b[i]);
+}
+//   a / 9 for N values, stage by stage (see div9)
+template <int N>
+__device__ __forceinline__ void div9_batch(float (&a)[N]) {
+    const float y = 0x1.c71c72p-4f;
+    float q0[N], r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q0[i] = a[i] * y;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fmaf(-9.0f, q0[i], a[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = fmaf(r[i], y, q0[i]);
+}
+
+// project() for N depth hypotheses of one pixel ray, stage by stage (same operations, same order per hypothesis)
+template <int N>
+__device__ __forceinline__ void project_batch(Sample (&o)[N], float r0, float r1, float r2, const float (&depth)[N], const float* P, int H, int W) {
+    float X0[N], X1[N], X2[N], px[N], py[N], pz[N], u[N], v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { X0[i] = depth[i] * r0; X1[i] = depth[i] * r1; X2[i] = depth[i] * r2; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { px[i] = P[0] * X0[i]; py[i] = P[4] * X0[i]; pz[i] = P[8] * X0[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { px[i] = fmaf(P[1], X1[i], px[i]); py[i] = fmaf(P[5], X1[i], py[i]); pz[i] = fmaf(P[9], X1[i], pz[i]); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { px[i] = fmaf(P[2], X2[i], px[i]); py[i] = fmaf(P[6], X2[i], py[i]); pz[i] = fmaf(P[10], X2[i], pz[i]); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { px[i] = fmaf(P[3], 1.0f, px[i]); py[i] = fmaf(P[7], 1.0f, py[i]); pz[i] = fmaf(P[11], 1.0f, pz[i]); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) pz[i] = pz[i] + 1e-7f;                  // layers.py:66
+#pragma unroll
+    for (int i = 0; i < N; ++i) { u[i] = px[i] / pz[i]; v[i] = py[i] / pz[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { u[i] = u[i] / (float)(W - 1); v[i] = v[i] / (float)(H - 1); }              // layers.py:67-68
+#pragma unroll
+    for (int i = 0; i < N; ++i) {                                       // layers.py:69 + clamp(-2,2) monorec_model.py:208
+        u[i] = fminf(fmaxf((u[i] - 0.5f) * 2.0f, -2.0f), 2.0f);
+        v[i] = fminf(fmaxf((v[i] - 0.5f) * 2.0f, -2.0f), 2.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {                                       // grid_sample(align_corners=False), see project()
+        const float sx = fmaf(u[i] + 1.0f, (float)W * 0.5f, -0.5f);
+        const float sy = fmaf(v[i] + 1.0f, (float)H * 0.5f, -0.5f);
+        const float fx = floorf(sx), fy = floorf(sy);
+        const float w = sx - fx, e = 1.0f - w, n = sy - fy, s_ = 1.0f - n;
+        o[i].x0 = (int)fx;
+        o[i].y0 = (int)fy;
+        o[i].nw = s_ * e; o[i].ne = s_ * w; o[i].sw = n * e; o[i].se = n * w;
+    }
+}
+
+// bilinear() for N planes x 3 channels: all 12 N gathers first, then the N * 3 FMA chains level by level
+template <int N>
+__device__ __forceinline__ void bilinear_batch(float (&out)[N * 3], __amdgpu_buffer_rsrc_t img, int plane_bytes, const Taps (&t)[N],
+                                               const Sample (&sp)[N]) {
+    float a[N * 3], b[N * 3], c[N * 3], d[N * 3];
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) {
+        const int so = (i % 3) * plane_bytes;
+        a[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].a, so, 0));
+        b[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].b, so, 0));
+        c[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].c, so, 0));
+        d[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].d, so, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = a[i] * sp[i / 3].nw;
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = fmaf(b[i], sp[i / 3].ne, out[i]);
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = fmaf(c[i], sp[i / 3].sw, out[i]);
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = fmaf(d[i], sp[i / 3].se, out[i]);
 }
 
 struct MarchGeom {
     int strips, pitch, TY, ysegs, npairs;
 };
 
-// Raw values of one image row held by a wave: x, x^2, x*k per channel and plane; k, k^2 per channel; e per plane.
-template <int DP>
+// Quantities a wave tracks per image row (one register each): for plane u, channel ch: x, x^2, x*k at (u*3 + ch)*3 + {0,1,2};
+// and - unless the keyframe statistics come from the prepass (KFS) - keyframe k, k^2 of channel ch at DP*9 + ch*2 + {0,1}.
+// MarchRow holds the raw values of a row or (as `top`) the horizontal sums ((l + c) + r) of the row two steps back; e = the
+// channel-weighted SSIM distance.
+template <int DP, bool KFS>
 struct MarchRow {
-    float x[DP][3], xx[DP][3], xk[DP][3];
-    float k[3], kk[3];
-    float e[DP];
-};
-// Horizontal sums ((l + c) + r) of the row two steps back: the top row of the current windows.
-template <int DP>
-struct MarchTop {
-    float x[DP][3], xx[DP][3], xk[DP][3];
-    float k[3], kk[3];
+    float q[DP * 9 + (KFS ? 0 : 6)];
     float e[DP];
 };
 
@@ -426,6 +510,7 @@ struct MarchCtx {
     float kix[3];
     float depth[DP];
     const float* pixd;      // per-pixel depths of plane d0 of this sample, or null
+    const float* kstats;    // prepass output of this sample: 3 planes of the keyframe's 3x3 mean, 3 of its variance (KFS), or null
     float* out;             // raw sad plane d0 of frame f, sample b
     int cx, vx, y0, y1;
     bool col_in, out_lane;
@@ -434,9 +519,10 @@ struct MarchCtx {
 // One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
 // sad of output row r - 2 (box over the e rows), then turn `mid` into the next top sums.  The caller alternates two MarchRow
 // objects as mid / cur, so the raw rows never move between registers.
-template <int DP, bool PIXD>
-__device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchTop<DP>& top, MarchRow<DP>& mid, MarchRow<DP>& cur,
+template <int DP, bool PIXD, bool KFS>
+__device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid, MarchRow<DP, KFS>& cur,
                                            unsigned (&hits)[DP]) {
+    constexpr int NQ = DP * 9 + (KFS ? 0 : 6), KQ = DP * 9;
     const CvArgs& a = c.a;
     const int H = a.H, W = a.W;
     const int HWp = H * W;
@@ -448,71 +534,127 @@ __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchTo
     float ray[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) ray[i] = fmaf(c.Ki[3 * i + 2], 1.0f, fmaf(c.Ki[3 * i + 1], (float)wr, c.kix[i]));
+    float K[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) { cur.k[ch] = c.kimg[ch * HWp + pix] + 0.5f; cur.kk[ch] = cur.k[ch] * cur.k[ch]; }
+    for (int ch = 0; ch < 3; ++ch) K[ch] = c.kimg[ch * HWp + pix] + 0.5f;
+    Sample sp[DP];
+    Taps tp[DP];
+    float dep[DP];
+#pragma unroll
+    for (int u = 0; u < DP; ++u) dep[u] = PIXD ? c.pixd[(long long)u * HWp + pix] : c.depth[u];
+    project_batch<DP>(sp, ray[0], ray[1], ray[2], dep, c.P, H, W);
 #pragma unroll
     for (int u = 0; u < DP; ++u) {
-        const float dep = PIXD ? c.pixd[(long long)u * HWp + pix] : c.depth[u];
-        const Sample sp = project(ray[0], ray[1], ray[2], dep, c.P, H, W);
-        hits[u] = (hits[u] << 1) | (mask_hit(sp, H, W) ? 1u : 0u);         // monorec_model.py:218-219
-        const Taps tp = tap_offsets(sp, H, W);
+        hits[u] = (hits[u] << 1) | (mask_hit(sp[u], H, W) ? 1u : 0u);     // monorec_model.py:218-219
+        tp[u] = tap_offsets(sp[u], H, W);
+    }
+    float xw[DP * 3];
+    bilinear_batch<DP>(xw, c.img, HWp * 4, tp, sp);
+#pragma unroll
+    for (int i = 0; i < DP * 3; ++i) cur.q[i * 3] = xw[i] + 0.5f;
+    if (!KFS) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { cur.q[KQ + ch * 2] = K[ch]; cur.q[KQ + ch * 2 + 1] = K[ch] * K[ch]; }
+    }
+#pragma unroll
+    for (int u = 0; u < DP; ++u)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float x = bilinear(c.img, ch * HWp * 4, tp, sp) + 0.5f;
-            cur.x[u][ch] = x; cur.xx[u][ch] = x * x; cur.xk[u][ch] = x * cur.k[ch];
+            const float x = cur.q[(u * 3 + ch) * 3];
+            cur.q[(u * 3 + ch) * 3 + 1] = x * x;
+            cur.q[(u * 3 + ch) * 3 + 2] = x * K[ch];
         }
-    }
-    // ---- SSIM row q = r - 1 (windows over virtual rows r-2, r-1, r), channel-weighted -> e --------------------------------
+    // ---- 3x3 sums of every quantity over virtual rows r-2, r-1, r; / 9 (AvgPool2d(3,1): row-major sum, then the division) ----
+    float s[NQ];
+    win9_batch<NQ>(s, top.q, mid.q, cur.q);
+    div9_batch<NQ>(s);
+    // ---- SSIM row q = r - 1, channel-weighted -> e (layers.py:119-137, monorec_model.py:133,141) ----------------------------
     const int q = r - 1;
     const bool row_in = q >= 0 && q < H;                                    // wave-uniform
-    float kmu[3], ksg[3], kmu2[3];
+    float kmu[3], kmu2[3], ksg[3];
+    if (KFS) {                                                              // keyframe statistics of SSIM position (q, x): prepass
+        const int sp_ = min(max(q, 0), H - 1) * W + c.cx;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float mu = div9(win9(top.k[ch], mid.k[ch], cur.k[ch]));       // AvgPool2d(3,1): row-major sum / 9
-        kmu[ch] = mu;
-        kmu2[ch] = mu * mu;
-        ksg[ch] = div9(win9(top.kk[ch], mid.kk[ch], cur.kk[ch])) - mu * mu;  // layers.py:130
+        for (int ch = 0; ch < 3; ++ch) { kmu[ch] = c.kstats[ch * HWp + sp_]; ksg[ch] = c.kstats[(3 + ch) * HWp + sp_]; }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) kmu2[ch] = kmu[ch] * kmu[ch];
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) kmu[ch] = s[KQ + ch * 2];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) kmu2[ch] = kmu[ch] * kmu[ch];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) ksg[ch] = s[KQ + ch * 2 + 1] - kmu2[ch];                   // layers.py:130
     }
+    constexpr int NS = DP * 3;
+    float mu_x_sq[NS], mu_xy[NS], sig_x[NS], sig_xy[NS], sn[NS], sd[NS], sv[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) mu_x_sq[i] = s[i * 3] * s[i * 3];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) mu_xy[i] = s[i * 3] * kmu[i % 3];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sig_x[i] = s[i * 3 + 1] - mu_x_sq[i];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sig_xy[i] = s[i * 3 + 2] - mu_xy[i];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sn[i] = (2.0f * mu_xy[i] + C1) * (2.0f * sig_xy[i] + C2);                       // layers.py:133
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sd[i] = (mu_x_sq[i] + kmu2[i % 3] + C1) * (sig_x[i] + ksg[i % 3] + C2);         // layers.py:134
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sv[i] = fminf(fmaxf((1.0f - sn[i] / sd[i]) / 2.0f, 0.0f), 1.0f);                // layers.py:137
 #pragma unroll
     for (int u = 0; u < DP; ++u) {
-        float ev = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float mu_x = div9(win9(top.x[u][ch], mid.x[u][ch], cur.x[u][ch])), mu_y = kmu[ch];
-            const float mu_x_sq = mu_x * mu_x, mu_y_sq = kmu2[ch], mu_xy = mu_x * mu_y;
-            const float sig_x = div9(win9(top.xx[u][ch], mid.xx[u][ch], cur.xx[u][ch])) - mu_x_sq;
-            const float sig_xy = div9(win9(top.xk[u][ch], mid.xk[u][ch], cur.xk[u][ch])) - mu_xy;
-            const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
-            const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[ch] + C2);   // layers.py:134
-            const float sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);   // layers.py:137
-            ev = (ch == 0) ? sv * a.cw[0] : fmaf(sv, a.cw[ch], ev);
-        }
+        const float ev = fmaf(sv[u * 3 + 2], a.cw[2], fmaf(sv[u * 3 + 1], a.cw[1], sv[u * 3] * a.cw[0]));
         cur.e[u] = (row_in && c.col_in) ? ev : 0.f;                         // zero padding of the 3x3 box (:247)
     }
     // ---- 3x3 box over e rows r-3, r-2, r-1 -> sad of output row y = r - 2 ---------------------------------------------
     const int y = r - 2;
     if (y >= c.y0 && y < c.y1) {                                            // wave-uniform
+        float sad[DP];
+        win9_batch<DP>(sad, top.e, mid.e, cur.e);
 #pragma unroll
         for (int u = 0; u < DP; ++u) {
-            float sad = win9(top.e[u], mid.e[u], cur.e[u]);
-            if (!(hits[u] & 4u)) sad = -sad;                                // sad >= 0: the sign bit is free (-0.0 keeps it)
-            if (c.out_lane) c.out[(long long)u * HWp + y * W + c.vx] = sad;
+            if (!(hits[u] & 4u)) sad[u] = -sad[u];                          // sad >= 0: the sign bit is free (-0.0 keeps it)
+            if (c.out_lane) c.out[(long long)u * HWp + y * W + c.vx] = sad[u];
         }
     }
     // ---- the middle row becomes the top row of the next step (as horizontal sums) -----------------------------------------
-#pragma unroll
-    for (int u = 0; u < DP; ++u) {
-        top.e[u] = hsum3(mid.e[u]);
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            top.x[u][ch] = hsum3(mid.x[u][ch]); top.xx[u][ch] = hsum3(mid.xx[u][ch]); top.xk[u][ch] = hsum3(mid.xk[u][ch]);
-        }
-    }
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) { top.k[ch] = hsum3(mid.k[ch]); top.kk[ch] = hsum3(mid.kk[ch]); }
+    hsum3_batch<NQ>(top.q, mid.q);
+    hsum3_batch<DP>(top.e, mid.e);
 }
 
-template <int DP, bool PIXD>
+// Keyframe statistics of the SSIM windows, once per keyframe instead of once per (frame, plane pair, row) in every wave: 3x3
+// reflection-padded mean and variance of keyframe + 0.5 per channel (layers.py:120-130; row-major sum / 9 like AvgPool2d).
+// Written into planes 0..5 of the sample's (not yet written) cost-volume buffer, which cv_fuse overwrites afterwards.
+__global__ __launch_bounds__(256) void cv_kf_stats_kernel(const CvArgs a) {
+    const int HWp = a.H * a.W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= HWp) return;
+    const int y = p / a.W, x = p - y * a.W;
+    const float* kimg = a.keyframe + (long long)b * 3 * HWp;
+    float* st = a.cv + (long long)b * a.D * HWp;
+    int yy[3], xx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { yy[t] = reflect_idx(y + t - 1, a.H) * a.W; xx[t] = reflect_idx(x + t - 1, a.W); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float k = kimg[c * HWp + yy[dy] + xx[dx]] + 0.5f;
+                const float kk = k * k;
+                if (dy == 0 && dx == 0) { s1 = k; s2 = kk; } else { s1 = s1 + k; s2 = s2 + kk; }
+            }
+        const float mu = div9(s1);
+        st[c * HWp + p] = mu;
+        st[(3 + c) * HWp + p] = div9(s2) - mu * mu;
+    }
+}
+
+template <int DP, bool PIXD, bool KFS>
 __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const MarchGeom g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -536,6 +678,7 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
                       a.proj + ((long long)b * a.F + f) * 12,
                       __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000),
                       {0.f, 0.f, 0.f}, {}, PIXD ? a.pix_depths + ((long long)b * D + d0) * HWp : nullptr,
+                      KFS ? a.cv + (long long)b * D * HWp : nullptr,
                       a.sfcv[f] + ((long long)b * D + d0) * HWp,
                       cx, vx, y0, min(y0 + g.TY, H),
                       vx >= 0 && vx < W,                      // SSIM positions outside the image contribute 0 to the box (:247)
@@ -545,15 +688,14 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
 #pragma unroll
     for (int u = 0; u < DP; ++u) c.depth[u] = PIXD ? 0.f : a.depths[d0 + u];
 
-    MarchTop<DP> top = {};
-    MarchRow<DP> rowA = {}, rowB = {};
+    MarchRow<DP, KFS> top = {}, rowA = {}, rowB = {};
     unsigned hits[DP];                                        // bit j: border-mask sample of the row warped j steps ago != 0
 #pragma unroll
     for (int u = 0; u < DP; ++u) hits[u] = 0u;
     const int r_last = c.y1 + 1;
     for (int r = y0 - 2; r <= r_last; r += 2) {
-        march_step<DP, PIXD>(c, r, top, rowA, rowB, hits);
-        if (r + 1 <= r_last) march_step<DP, PIXD>(c, r + 1, top, rowB, rowA, hits);
+        march_step<DP, PIXD, KFS>(c, r, top, rowA, rowB, hits);
+        if (r + 1 <= r_last) march_step<DP, PIXD, KFS>(c, r + 1, top, rowB, rowA, hits);
     }
 }
 
@@ -934,8 +1076,13 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         // default configuration: LDS-free marching kernel, two depth planes per wave
         const MarchGeom g = march_geometry(a, 2);
         const dim3 grid((unsigned)(g.strips * g.ysegs), (unsigned)(a.F * ((g.npairs + 3) / 4)), (unsigned)a.B);
-        if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true>), grid, dim3(256), 0, stream, k, g);
-        else hipLaunchKernelGGL((cv_sad_march_kernel<2, false>), grid, dim3(256), 0, stream, k, g);
+        static const bool no_prepass = getenv("MR_CV_NO_KF_PREPASS") != nullptr;           // A/B aid
+        if (a.D >= 6 && !no_prepass) {       // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
+            hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
+            if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true, true>), grid, dim3(256), 0, stream, k, g);
+            else hipLaunchKernelGGL((cv_sad_march_kernel<2, false, true>), grid, dim3(256), 0, stream, k, g);
+        } else if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true, false>), grid, dim3(256), 0, stream, k, g);
+        else hipLaunchKernelGGL((cv_sad_march_kernel<2, false, false>), grid, dim3(256), 0, stream, k, g);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         launch_fuse(k, false, false, stream);

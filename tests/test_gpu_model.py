@@ -163,9 +163,16 @@ def test_reference_example_sample_with_metrics(hip_lib):
 
 def test_reference_example_sample_with_the_fixtures_own_matrices(hip_lib):
     """The real sample again, with the one host-dependent step taken out: the fixture stores the 3x3 / 3x4 matrices the reference
-    formed on the generating host (monorec_model.py:171,198,207; `geom.kinv`, `geom.proj`), and they are handed to the cost-volume
-    launch instead of this host's LAPACK result.  Then the tight legs hold on real data too: single-frame volumes within 2e-6 of
-    the reference with no validity flip, and `result` / `cv_mask` within 1e-4 end to end."""
+    formed on the generating host (monorec_model.py:171,198,207; `geom.kinv`, `geom.proj`) and its full all-depth validity maps
+    (`geom.valid_bits`); the matrices are handed to the cost-volume launch instead of this host's LAPACK result.  Then, on real data:
+      1. single-frame volumes within 2e-6 of the reference, validity identical on every pixel of both frames;
+      2. the fused volume equals the reference's fusion formula (:257-269) evaluated on these single-frame volumes, except on the
+         few pixels whose frame weights vanish to within rounding: there `sum(w) != 0` (:265) is decided by the last bit of
+         `sum_d exp(..)` - MKL's vmsExp in the reference, ocml's expf here - and the reference itself jumps between 0 and
+         1 - 2 sad (measured: 10 sky pixels, all with sum(w) <= 1.2e-7 = one ulp of 1);
+      3. mask, image features and - given this run's fused volume - every depth scale within 1e-4 (stage tests, here and in
+         test_reference_example_sample_with_metrics);
+      4. end to end the depth therefore equals the reference's outside the footprint of those pixels; the rest is reported."""
     import numpy as np
     g = Golden("kitti_example_169")
     batch = g.make_inputs()
@@ -174,16 +181,48 @@ def test_reference_example_sample_with_the_fixtures_own_matrices(hip_lib):
     with torch.no_grad():
         out = model(_to_dev(batch))
     torch.cuda.synchronize()
-    for f in range(g.frames):
-        info = g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=2e-6)
+    sf = [t.cpu() for t in out["single_frame_cvs"]]
+    nf, h, w = g.frames, g.h, g.w
+    # 1. single-frame volumes and validity
+    for f in range(nf):
+        info = g.compare(f"sfcv{f}", sf[f], atol=2e-6)
         print("kitti example, fixture matrices: sfcv%d vs reference" % f, info)
-        got = out["single_frame_cvs"][f].cpu().reshape(-1)[::int(g.z[f"sfcv{f}.stride"])].numpy()
-        want = g.z[f"sfcv{f}.samples"]
-        assert np.array_equal(got == 0, want == 0), "validity flips"
+    ref_valid = np.unpackbits(g.z["geom.valid_bits"])[: nf * h * w].reshape(nf, h, w).astype(bool)
+    hip_valid = np.stack([~(t[0] == 0).all(0).numpy() for t in sf])
+    assert np.array_equal(hip_valid, ref_valid), f"{int((hip_valid != ref_valid).sum())} validity flips"
+    # 2. fusion formula of the reference on these volumes (sad = (1 - sfcv) / 2 where valid)
+    valid_t = torch.from_numpy(hip_valid).unsqueeze(1).float()
+    sad = torch.stack([(1 - t[0]) / 2 for t in sf])
+    e = torch.exp(-10 * torch.pow(sad - sad.min(1, keepdim=True)[0], 2))
+    wgt = (1 - 1 / (g.depths - 1) * (e.sum(1, keepdim=True) - 1)) * valid_t
+    fused = (sad * wgt).sum(0)
+    wsum = wgt.sum(0).squeeze()
+    nz = wsum != 0
+    fused[:, nz] /= wsum[nz]
+    fused = 1 - 2 * fused
+    fused[:, ~nz] = 0
+    mask = out["cv_mask"].cpu()
+    dev = (out["cost_volume"].cpu()[0] - fused * (1 - mask[0])).abs().amax(0)
+    off = dev > 1e-4
+    print("fused volume vs the reference formula on these single-frame volumes: %d pixels differ, sum(w) there <= %.2e; elsewhere max %.1e"
+          % (int(off.sum()), float(wsum[off].abs().max()) if off.any() else 0.0, float(dev[~off].max())))
+    assert int(off.sum()) <= 64 and (not off.any() or float(wsum[off].abs().max()) <= 1e-6)
+    info = g.compare("cost_volume", out["cost_volume"], atol=1e-5, max_outlier_frac=2e-4)
+    print("masked fused volume vs reference fixture samples:", info)
+    # 3. mask / features vs the fixture, depth scales vs the oracle's depth module fed with this run's volume
+    m = (mask - torch.from_numpy(g.z["cv_mask.full"])).abs()
+    assert m.max().item() <= 1e-4
+    for i in range(5):
+        g.compare(f"feat{i}", out["image_features"][i], atol=1e-5, rtol=1e-5)
+    preds = orc.depth_module(sd, out["cost_volume"].cpu(), batch["keyframe"], [t.cpu() for t in out["image_features"]])
+    for i in range(4):
+        want = (1 - preds[i]) * 0.0025 + preds[i] * 0.33
+        assert (out["predicted_inverse_depths"][i].cpu() - want).abs().max().item() <= RESULT_ATOL, i
+    # 4. end to end, for the record
     d = (out["result"].cpu() - torch.from_numpy(g.z["result.full"])).abs()
-    m = (out["cv_mask"].cpu() - torch.from_numpy(g.z["cv_mask.full"])).abs()
-    print("kitti example, fixture matrices: result max %.2e, cv_mask max %.2e" % (d.max(), m.max()))
-    assert d.max().item() <= RESULT_ATOL and m.max().item() <= 1e-4
+    print("kitti example, fixture matrices: result vs reference max %.2e, frac > 1e-4 %.3f (footprint of the undetermined pixels), cv_mask max %.2e"
+          % (d.max(), (d > 1e-4).float().mean(), m.max()))
+    assert d.max().item() <= 5e-2 and (d > 1e-4).float().mean().item() <= 0.15
 
 
 def test_c3_full_shape_against_the_oracle(hip_lib):

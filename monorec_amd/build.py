@@ -42,7 +42,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and not _stale(
-            LIB_PATH, [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "conv_layout.h"),
+            LIB_PATH, [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "conv_layout.h"), __file__,
                                                                        os.path.join(HERE, "..", "include", "monorec_hip.h")]):
         return LIB_PATH                     # prebuilt library travels with the snapshot; nothing to do
     hipcc = _hipcc()

@@ -459,3 +459,26 @@ def test_header_is_a_c_abi_usable_from_plain_c(hip_lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("c abi ok"), (out.returncode, out.stdout, out.stderr[-500:])
 
+
+
+def test_marching_cost_volume_kernel_codegen():
+    """The marching cost-volume kernel lives on two compiler behaviours that a source change can silently lose (it happened while
+    trying the reference's conv3d summation order for the box stage): the DPP wave shifts must ride on the adds (v_add_f32_dpp -
+    an unfolded v_mov_b32_dpp costs an instruction, a zero-initialised register and the wave-64 occupancy), and the kernel must
+    stay at 4 waves per SIMD (<= 128 VGPRs, no scratch).  Checked on the ISA hipcc emits for gfx950."""
+    from monorec_amd import build as _build
+    flags = dict(_build.SOURCES)["cost_volume.hip"]
+    src = os.path.join(ROOT, "monorec_amd", "csrc", "cost_volume.hip")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.run([_build._hipcc(), f"--offload-arch={_build.ARCH}", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj", "-c", src,
+                        "-o", os.path.join(d, "cv.o")] + flags, check=True, cwd=d, capture_output=True)
+        asm = open(os.path.join(d, "cost_volume-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    for variant in ("ILi2ELb0ELb1E", "ILi2ELb0ELb0E"):          # <DP = 2, shared depths, with / without the keyframe prepass>
+        m = re.search(r"_ZN12_GLOBAL__N_119cv_sad_march_kernel" + variant + r"EEvNS_6CvArgsENS_9MarchGeomE:(.*?)\.Lfunc_end", asm, re.S)
+        assert m, variant
+        body = m.group(1)
+        folded, unfolded = body.count("v_add_f32_dpp"), body.count("v_mov_b32_dpp")
+        assert folded >= 200 and unfolded <= 32, (variant, folded, unfolded)
+        meta = asm[asm.index("amdhsa.kernels"):]
+        k = re.search(r"cv_sad_march_kernel" + variant + r".*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", meta, re.S)
+        assert k and int(k.group(1)) == 0 and int(k.group(2)) <= 128, (variant, k and k.groups())

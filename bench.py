@@ -84,7 +84,7 @@ def time_layers(model, batch_dev, plan_key, reps=5):
     for (name, _), t in zip(ops, acc):
         c = macs.get(name)
         rows.append({"name": name, "seconds": t, "macs": c["macs"] if c else 0, "ref_macs": c["ref_macs"] if c else 0,
-                     "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4)] if c else None, "wgs": c["wgs"] if c else None,
+                     "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4), c.get("kws", 0)] if c else None, "wgs": c["wgs"] if c else None,
                      "tflops": (2 * c["macs"] / t / 1e12) if c and t > 0 else None})
     return rows
 
@@ -121,7 +121,7 @@ def committed_kernel_stats(cfg):
     forward (= per dispatch of the cost-volume sad kernel).  The live figures are taken with HIP events around every launch and
     therefore also contain the dispatch gap of a dependent launch (~3 us each)."""
     import csv
-    path = _latest_profile(cfg, "kernel_stats.csv")
+    path = _latest_profile(cfg, "kernel_stats_seq.csv") or _latest_profile(cfg, "kernel_stats.csv")   # prefer the one-keyframe-at-a-time trace
     if not path:
         return None, None
     try:
@@ -413,7 +413,8 @@ def main():
             roof.update({"rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,
                          "frac_kernel_only": conv_flops / (kst["conv_us_per_forward"] * 1e-6) / 1e12 / peak,
                          "frac_kernel_only_note": "algorithmic flops / (conv kernels + split-K finishing kernels per forward in the committed "
-                                                  "rocprofv3 kernel trace) / peak", "rocprof_source": kst_src})
+                                                  "rocprofv3 kernel trace - the --in-flight 1 trace when present: overlapping keyframes "
+                                                  "inflate each other's kernel durations) / peak", "rocprof_source": kst_src})
         if pmc.get("conv_mfma_util") is not None:
             roof["mfma_util_pmc"] = pmc["conv_mfma_util"]
         result = {

@@ -132,6 +132,11 @@ typedef struct mr_conv_desc {
      * parity (py, px) is a (1+py) x (1+px) convolution with the 2x2 filter's rows / columns summed where both fall on the same
      * input pixel - 9 instead of 16 multiply-adds per 2x2 output block. */
     int32_t phase_kh[4], phase_kw[4];
+    /* schedule, continued: 1 = the waves of a workgroup split K instead of the pixels - all of them sweep the same
+     * pixel_blocks_per_wave blocks of 16 pixels, each every waves_per_wg-th k-step of a chunk, and the partial sums are reduced
+     * through LDS in a fixed order.  waves_per_wg times more workgroups for layers with few output pixels, without the workspace
+     * round trip and the finishing launch of split_k (which must be 1 here; MR_COMPUTE_F32, LDS-DMA staged inputs only). */
+    int32_t k_split_waves;
 } mr_conv_desc;
 
 /* number of floats of the packed weight image for a conv with the given source split and schedule

@@ -53,6 +53,7 @@ class ConvDesc(ctypes.Structure):
         ("waves_per_wg", ctypes.c_int32),
         ("compute_dtype", ctypes.c_int32),
         ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
+        ("k_split_waves", ctypes.c_int32),
     ]
 
 

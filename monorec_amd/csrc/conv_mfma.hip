@@ -71,6 +71,7 @@ struct ConvKArgs {
     int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores,
                                // 16 per-workgroup timestamps (tools/wg_timeline.py)
     int ksplit, nchunks, batch, nphase;
+    int kws;                   // 1: the waves of a workgroup split K (all work on the same NB pixel blocks, reduced through LDS)
     int bf16;                  // 1: bf16 MFMA mode (weights bf16, activations rounded to bf16 in the B fragment): half-size weight blocks
     int tiles_y, ngroups, ks_shift;   // ks_shift: log2(ksplit) or -1
     long long wgroup_stride[4];   // packed floats per cout group, per phase
@@ -326,6 +327,26 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
     }
 }
 
+// K split across the waves of a workgroup (a.kws): every wave sweeps the k-steps t = wave, wave + WV, ... of the chunk's
+// taps x channel-quads (flattened, so that chunks with fewer quads than waves still spread) for the SAME NB pixel blocks; the
+// partial accumulators meet in LDS after the K loop.  Small layers (a few hundred output pixels per image) get WV x more
+// workgroups this way without the workspace round trip and the finishing launch of split_k.
+template <int MB, int NB, int WV>
+__device__ __forceinline__ void sweep_chunk_kws(const ConvKArgs& a, f32x4 (&acc)[MB][NB], f32x4 (&acc2)[MB][NB], const float* ldsI,
+                                                const float* ldsW, const int (&lbase)[NB], int ck4, int lane, int wave, int KH, int KW) {
+    const float* wl = ldsW + lane;
+    const int nsteps = KH * KW * ck4;
+    bool odd = false;
+    for (int t = wave; t < nsteps; t += WV) {
+        const int tap = t / ck4, c4 = t - tap * ck4;          // wave-uniform
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const float* wt = wl + tap * ck4 * (MB * 64);
+        if (odd) kstep<MB, NB>(acc2, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + kh * a.IWa + kw);
+        else kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + kh * a.IWa + kw);
+        odd = !odd;
+    }
+}
+
 // ---- bf16 MFMA sweep: one v_mfma_f32_16x16x16_bf16 per (cout block, pixel block) and 16 input channels of a tap -------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -438,7 +459,7 @@ __device__ __forceinline__ void sweep_chunk_bf16x3(const ConvKArgs& a, f32x4 (&a
 // DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
 // max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
 // make hipcc drain vmcnt before every sweep and spill SGPRs).
-template <int MB, int NB, bool DMA_IN, int WV, int BF16>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false>
 __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     dbg_stamp(a, 0);
@@ -514,17 +535,18 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     int prow[NB], pcol[NB], lbase[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int pb = wave * NB + i;
+        const int pb = KWS ? i : wave * NB + i;           // KWS: every wave works on the same NB blocks
         prow[i] = a.TWB == 2 ? pb >> 1 : pb;
         pcol[i] = (a.TWB == 2 ? (pb & 1) : 0) * 16 + (lane & 15);
         lbase[i] = (lane >> 4) * a.PLANE + prow[i] * a.SH * a.IWa + pcol[i] * a.SW + xsh;
     }
 
     f32x4 acc[MB][NB];
+    f32x4 acck[MB][NB];                                // KWS: second partial sum (alternating k-steps keep two MFMA chains in flight)
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NB; ++i) { acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acck[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const int q_lo = a.ks_shift >= 0 ? (ks * a.nchunks) >> a.ks_shift : (ks * a.nchunks) / a.ksplit;
     const int q_hi = a.ks_shift >= 0 ? ((ks + 1) * a.nchunks) >> a.ks_shift : ((ks + 1) * a.nchunks) / a.ksplit;
@@ -555,7 +577,8 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
         }
         if (stamp) dbg_stamp(a, 5);
         if (!MR_DBG(1)) {
-            if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
+            if (KWS) sweep_chunk_kws<MB, NB, WV>(a, acc, acck, bcur, bcur + ioff, lbase, ck4, lane, wave, KH, KW);
+            else if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
             else if (BF16 == 1) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
             else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KH, KW);
         }
@@ -565,6 +588,30 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
         __syncthreads();                               // ... everyone's has, and everyone is done with this buffer
         if (stamp) { dbg_stamp(a, 8); dbg_stamp(a, 10); }
         pb ^= 1;
+    }
+    // ---- KWS: the WV partial accumulators of every (cout block, pixel block) meet in LDS (the pipeline buffers are free: the
+    //      loop ended behind a barrier); block j = m * NB + i is summed - in wave order, deterministic - and finished by wave j % WV
+    if (KWS) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                acc[m][i] += acck[m][i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[((wave * (MB * NB) + m * NB + i) * 4 + r) * 64 + lane] = acc[m][i][r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (((m * NB + i) % WV) != wave) continue;
+                f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int w = 0; w < WV; ++w)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum[r] += lds[((w * (MB * NB) + m * NB + i) * 4 + r) * 64 + lane];
+                acc[m][i] = sum;
+            }
     }
     // ---- epilogue: D fragment lane l holds pixel (l&15), couts (l>>4)*4 + r ---------------------
     const int CB16 = a.CB * 16;
@@ -612,7 +659,7 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
-                const bool ok = oy < a.Ho && ox < a.Wo;
+                const bool ok = oy < a.Ho && ox < a.Wo && (!KWS || ((m * NB + i) % WV) == wave);
                 idx0[i] = ok ? bbase + ((long long)(a.ch_off + cout0) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
                                    (ox * a.ostep_w + a.ooff_w[ph])
                              : -1;
@@ -687,6 +734,8 @@ int derive(const mr_conv_desc* d, Derived* out) {
     const int mb = d->cout_blocks_per_wg, nb = d->pixel_blocks_per_wave;
     const int wv = d->waves_per_wg == 0 ? 4 : d->waves_per_wg;
     if (wv != 4 && wv != 8) return MR_ERR_BAD_ARGUMENT;
+    const int kws = d->k_split_waves ? 1 : 0;
+    if (kws && (d->split_k != 1 || d->compute_dtype != MR_COMPUTE_F32)) return MR_ERR_UNSUPPORTED;
     if (!valid_mb(mb) || !(nb == 1 || nb == 2 || nb == 4) || !valid_ck(d->chunk_channels)) return MR_ERR_BAD_ARGUMENT;
     if (d->split_k < 1) return MR_ERR_BAD_ARGUMENT;
     const int nphase = d->num_phases <= 1 ? 1 : d->num_phases;
@@ -752,8 +801,10 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.CB = mr_ceil_div(d->out_channels, 16);
     k.bias = d->bias; k.res = d->residual;
     k.act = d->activation; k.p0 = d->act_p0; k.p1 = d->act_p1;
-    k.TWB = d->out_w >= 32 ? 2 : 1;
-    k.TH = wv * nb / k.TWB;
+    k.kws = kws;
+    const int blocks_per_wg = kws ? nb : wv * nb;      // pixel blocks of 16 a workgroup owns
+    k.TWB = (d->out_w >= 32 && blocks_per_wg >= 2) ? 2 : 1;
+    k.TH = blocks_per_wg / k.TWB;
     k.tiles_x = mr_ceil_div(d->out_w, k.TWB * 16);
     const int tiles_y = mr_ceil_div(d->out_h, k.TH);
     k.IH = (k.TH - 1) * k.SH + k.KH;
@@ -791,6 +842,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     // two pipeline buffers - one when no workgroup ever streams a second chunk
     const int nbuf = mr_ceil_div(nchunks, d->split_k) > 1 ? 2 : 1;
     out->lds_bytes = nbuf * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);
+    if (kws && out->lds_bytes < (size_t)wv * mb * nb * 1024) out->lds_bytes = (size_t)wv * mb * nb * 1024;   // reduction scratch
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
     k.gpr_magic = 65536u / (unsigned)(k.IWa >> 2 > 0 ? k.IWa >> 2 : 1) + 1u;
     k.tiles_x_magic = k.tiles_x == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;   // (1 would overflow)
@@ -798,6 +850,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb; out->wv = wv;
     if (wv == 8 && !k.dma_x4) return MR_ERR_UNSUPPORTED;
+    if (kws && !k.dma_in) return MR_ERR_UNSUPPORTED;
     if (bf16 && !k.dma_in) return MR_ERR_UNSUPPORTED;                 // bf16 mode: LDS-DMA staged inputs only
     k.tiles_y = tiles_y;
     k.ngroups = mr_ceil_div(k.CB, mb);
@@ -808,7 +861,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB, bool DMA_IN, int WV, int BF16>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false>
 int launch(const Derived& dv, hipStream_t stream) {
     // raise the dynamic-LDS ceiling once per instantiation AND device (the attribute lives in the device's code object:
     // a process that drives several GPUs - nn.DataParallel replicas - must set it on each)
@@ -817,12 +870,12 @@ int launch(const Derived& dv, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
@@ -835,6 +888,10 @@ int launch_variant(const Derived& dv, hipStream_t stream) {
     if (dv.mode == 1) {
         if (dv.wv == 8) return launch<MB, NB, true, 8, 1>(dv, stream);
         return launch<MB, NB, true, 4, 1>(dv, stream);
+    }
+    if (dv.k.kws) {                                    // K split across the waves: LDS-DMA staged fp32 launches only (derive() checked)
+        if (dv.wv == 8) return launch<MB, NB, true, 8, 0, true>(dv, stream);
+        return launch<MB, NB, true, 4, 0, true>(dv, stream);
     }
     if (dv.wv == 8) return launch<MB, NB, true, 8, 0>(dv, stream);         // dwordx4 DMA path only (derive() checked)
     if (dv.k.dma_in) return launch<MB, NB, true, 4, 0>(dv, stream);

@@ -105,10 +105,12 @@ def upconv_phase_weights(w):
     return out
 
 
-def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4):
-    """Tile geometry used by mr_conv2d_f32 for a given NB / waves per workgroup (mirrors derive() in csrc/conv_mfma.hip)."""
-    twb = 2 if out_w >= 32 else 1
-    th = waves * nb // twb
+def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4, kws=0):
+    """Tile geometry used by mr_conv2d_f32 for a given NB / waves per workgroup (mirrors derive() in csrc/conv_mfma.hip).
+    kws: the waves split K instead of the pixels - the workgroup owns nb pixel blocks instead of waves * nb."""
+    blocks = nb if kws else waves * nb
+    twb = 2 if (out_w >= 32 and blocks >= 2) else 1
+    th = blocks // twb
     ih, iw = (th - 1) * sh + kh, (twb * 16 - 1) * sw + kw
     iw = (iw + 3 + 3) // 4 * 4          # upper bound: 4-aligned superset used by the dwordx4 DMA path
     plane = ih * iw
@@ -122,13 +124,14 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4):
                 tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
 
 
-def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False):
+def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False, reduce_bytes=0):
     """Dynamic LDS of one workgroup: pipeline buffers of (input tile + A fragments of the largest chunk) - two,
-    or one when no workgroup streams a second chunk (mirrors derive() in csrc/conv_mfma.hip)."""
+    or one when no workgroup streams a second chunk (mirrors derive() in csrc/conv_mfma.hip); `reduce_bytes`: the scratch of the
+    K-split-across-waves reduction (waves * mb * nb KiB), which reuses the same memory."""
     ck_max = max(min(c, ck) for c in cpads)
     nchunks = sum(math.ceil(c / ck) for c in cpads)
     nbuf = 2 if math.ceil(nchunks / split_k) > 1 else 1
-    return nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if int(bf16) == 1 else 16))    # bf16x3 blocks: hi + lo = fp32 size
+    return max(nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if int(bf16) == 1 else 16)), reduce_bytes)    # bf16x3 blocks: hi + lo = fp32 size
 
 
 TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
@@ -159,30 +162,35 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
     cpads = [(c + unit - 1) // unit * unit for c in src_channels]
     taps = kh * kw
     out = []
-    for waves in (4, 8):
-        for nb in (4, 2, 1):
-            geo = conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves)
-            if waves == 4 and geo["ppt"] > 6:
-                continue
-            if waves == 8 and geo["ih"] * (geo["iw"] // 4) > 256:      # dwordx4 groups per lane <= 4
-                continue
-            for mb in (6, 4, 3, 2, 1):
-                if mb > cb and mb != 1:
+    for kws in (0, 1):
+        if kws and bf16:
+            continue                          # K split across the waves: fp32 launches only
+        for waves in (4, 8):
+            for nb in (4, 2, 1):
+                geo = conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves, kws)
+                if waves == 4 and geo["ppt"] > 6:
                     continue
-                groups = math.ceil(cb / mb)
-                for ck in ((16, 32, 64, 128) if bf16 else (8, 16, 32, 64, 128)):
-                    if ck > 16 and ck // 2 >= max(cpads):
+                if waves == 8 and geo["ih"] * (geo["iw"] // 4) > 256:      # dwordx4 groups per lane <= 4
+                    continue
+                for mb in (6, 4, 3, 2, 1):
+                    if mb > cb and mb != 1:
                         continue
-                    nchunks = sum(math.ceil(c / ck) for c in cpads)
-                    wgs = geo["tiles"] * groups * batch * phases
-                    for sk in (1, 2, 4, 8, 16):
-                        if sk > nchunks:
-                            break
-                        lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16)
-                        if lds > lds_cap:
+                    groups = math.ceil(cb / mb)
+                    for ck in ((16, 32, 64, 128) if bf16 else (8, 16, 32, 64, 128)):
+                        if ck > 16 and ck // 2 >= max(cpads):
                             continue
-                        out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, wgs=wgs * sk, nchunks=nchunks,
-                                        eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
+                        nchunks = sum(math.ceil(c / ck) for c in cpads)
+                        wgs = geo["tiles"] * groups * batch * phases
+                        if kws and wgs > 4096:
+                            continue              # plenty of workgroups already: splitting K buys nothing
+                        for sk in ((1,) if kws else (1, 2, 4, 8, 16)):
+                            if sk > nchunks:
+                                break
+                            lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16, waves * mb * nb * 1024 if kws else 0)
+                            if lds > lds_cap:
+                                continue
+                            out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, kws=kws, wgs=wgs * sk, nchunks=nchunks,
+                                            eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
     return out
 
 
@@ -209,7 +217,7 @@ def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, pha
     best = None
     for lds_cap in (80 * 1024, 160 * 1024):      # prefer two workgroups per CU; a one-per-CU budget only if nothing else launches
         for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=lds_cap, bf16=bf16):
-            if c["waves"] != 4:          # 8-wave workgroups only through the measured table
+            if c["waves"] != 4 or c.get("kws"):          # 8-wave / K-split-wave workgroups only through the measured table
                 continue
             reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
             fill = min(1.0, c["wgs"] / 768.0)
@@ -323,6 +331,7 @@ class Plan:
                                                                     out_h, out_w, n, nph, bf16, mixed)
         mb, nb, split_k, ck = sched[:4]
         waves = sched[4] if len(sched) > 4 else 4
+        kws = int(sched[5]) if len(sched) > 5 else 0       # K split across the waves of a workgroup
         d = ConvDesc()
         for i, s in enumerate(srcs):
             d.src[i] = s.data_ptr()
@@ -354,6 +363,7 @@ class Plan:
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
         d.waves_per_wg = waves
+        d.k_split_waves = kws
         d.compute_dtype = int(bf16)
         if split_k > 1:
             self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
@@ -365,9 +375,9 @@ class Plan:
             _lib.check(int(lds), f"plan {name} sched={sched}")
         taps = kh * kw if phases is None else sum(p[0].shape[2] * p[0].shape[3] for p in phases)
         macs = n * out_h * out_w * cout * cin * taps
-        geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves)
+        geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves, kws)
         wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
-        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, kws=kws, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
                                   sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16, mixed), bf16=bf16,
                                   spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),

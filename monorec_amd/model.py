@@ -255,6 +255,7 @@ class MonoRecModel(nn.Module):
         self._plans = {}
         self._graphs = {}
         self._streams = {}
+        self._consts = {}
         self._packed_state = None
         self._lock = threading.RLock()   # one enqueue at a time per model object (nn.DataParallel calls replicas from threads)
         self._warned_encoder = False
@@ -310,6 +311,7 @@ class MonoRecModel(nn.Module):
     def _invalidate(self):
         self._plans = {}
         self._graphs = {}
+        self._consts = {}
         self._packed_state = None
 
     def _apply(self, fn, *a, **k):   # .to() / .cuda(): parameters moved or cast -> repack
@@ -318,7 +320,7 @@ class MonoRecModel(nn.Module):
 
     def __getstate__(self):          # copy.deepcopy / pickle: device plans, streams, graphs and the lock are rebuilt on demand
         state = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
-        for k in ("_plans", "_graphs", "_streams"):
+        for k in ("_plans", "_graphs", "_streams", "_consts"):
             state[k] = {}
         state["_packed_state"] = None
         state.pop("_lock", None)
@@ -351,12 +353,14 @@ class MonoRecModel(nn.Module):
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
             plan.geom_uploaded = None       # event behind the last H2D copy out of host_geom
+            plan.host_time = torch.zeros(1, dtype=torch.float32).pin_memory()
             self._plans[key] = plan
         return key, plan
 
     # ------------------------------------------------------------------ forward
     # tensor-valued outputs the path writes into the dict (monorec_model.py:256-279,690,713-727)
-    _OUTPUT_KEYS = ("cost_volume", "single_frame_cvs", "image_features", "cv_mask", "predicted_inverse_depths")
+    _OUTPUT_KEYS = ("cost_volume", "single_frame_cvs", "image_features", "cv_mask", "predicted_inverse_depths",
+                    "inv_depth_min", "inv_depth_max", "cv_depth_steps")
 
     def forward(self, data_dict):
         """Reference contract (monorec_model.py:672-729): fills and returns `data_dict`; the outputs are ordered on the
@@ -425,9 +429,14 @@ class MonoRecModel(nn.Module):
             return self._submit_locked(data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device)
 
     def _submit_locked(self, data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device):
-        data_dict["inv_depth_min"] = keyframe.new_tensor([self.inv_depth_min_max[0]])
-        data_dict["inv_depth_max"] = keyframe.new_tensor([self.inv_depth_min_max[1]])
-        data_dict["cv_depth_steps"] = keyframe.new_tensor([self.cv_depth_steps], dtype=torch.int32)
+        # the three constants of :675-677: built once per device (a `new_tensor` from a Python list is a blocking pageable H2D copy on
+        # the caller's stream, three of them per keyframe); forward() hands out copies like every other output
+        consts = self._consts.get(str(device))
+        if consts is None:
+            consts = (keyframe.new_tensor([self.inv_depth_min_max[0]]), keyframe.new_tensor([self.inv_depth_min_max[1]]),
+                      keyframe.new_tensor([self.cv_depth_steps], dtype=torch.int32))
+            self._consts[str(device)] = consts
+        data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = consts
 
         slot = self._next_slot
         self._next_slot = (slot + 1) % self._in_flight
@@ -509,7 +518,8 @@ class MonoRecModel(nn.Module):
             main.wait_event(tail_done)
             done = torch.cuda.Event()
             done.record(main)
-        data_dict["cv_module_time"] = keyframe.new_tensor([time.time() - start_time])
+        plan.host_time[0] = time.time() - start_time         # (:279: host seconds spent in the cost-volume module; here: enqueueing)
+        data_dict["cv_module_time"] = plan.host_time.to(device, non_blocking=True)
 
         data_dict["cost_volume"] = plan.buf["cost_volume"]
         data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]

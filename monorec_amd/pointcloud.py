@@ -142,7 +142,8 @@ class PointcloudBuilder:
     def add(self, data, result):
         output = result["result"]
         cv_mask = result["cv_mask"] if "cv_mask" in result else output.new_zeros(output.shape)
-        # clones: the model's outputs are views of resident buffers that later forwards overwrite
+        # clones: `result` may come from submit() (views of resident buffers that later forwards overwrite), and the buffered
+        # depth is multiplied in place by the vote below
         self._buf.append(dict(pose=data["keyframe_pose"].clone(), intrinsics=data["keyframe_intrinsics"].clone(),
                               mask=static_mask(cv_mask, self.mask_fill), keyframe=data["keyframe"].clone(),
                               depth=output.clone()))

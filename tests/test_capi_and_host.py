@@ -401,7 +401,7 @@ def test_python_lds_model_bounds_the_library(hip_lib):
             d.dst_plane_h, d.dst_plane_w, d.out_step_h, d.out_step_w = oh, ow, 1, 1
             d.packed_weights = 16
             d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = cd["mb"], cd["nb"], cd["split_k"], cd["ck"]
-            d.waves_per_wg, d.compute_dtype = cd["waves"], bf16
+            d.waves_per_wg, d.compute_dtype, d.k_split_waves = cd["waves"], bf16, cd.get("kws", 0)
             got = int(hip_lib.mr_conv2d_lds_bytes(ctypes.byref(d)))
             if got == -2 and cd["waves"] == 8:            # 8-wave tiles need the dwordx4 path: legitimately refused for some geometries
                 continue

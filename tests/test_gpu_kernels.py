@@ -67,6 +67,16 @@ CONV_CASES = [
     ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 2, 4, 16, 8)),
     ((64,), 128, (3, 3), (2, 2), (1, 1), (32, 64), 1, ACT_RELU, IN_DIRECT, TF_NONE, False, (2, 1, 1, 8, 8)),
     ((48,), 64, (7, 1), (2, 1), (2, 0), (64, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (4, 1, 1, 16, 8)),
+    # K split across the waves of a workgroup (sixth schedule entry): few output pixels, many channels - residual, heads, ragged
+    # sizes, one and two blocks per row, 4 and 8 waves, chunks with fewer channel quads than waves, concatenated sources, strides
+    ((256,), 256, (3, 3), (1, 1), (1, 1), (16, 32), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (1, 2, 1, 64, 8, 1)),
+    ((512,), 512, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_RELU, IN_DIRECT, TF_NONE, True, (2, 1, 1, 32, 8, 1)),
+    ((256,), 1, (3, 3), (1, 1), (1, 1), (8, 16), 1, ACT_ABS_TANH_AFFINE, IN_DIRECT, TF_NONE, False, (1, 1, 1, 32, 4, 1)),
+    ((96, 128, 96), 96, (3, 3), (1, 1), (1, 1), (8, 16), 2, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 1, 1, 16, 8, 1)),
+    ((64,), 128, (1, 1), (2, 2), (0, 0), (16, 32), 2, ACT_NONE, IN_DIRECT, TF_NONE, False, (1, 1, 1, 64, 4, 1)),
+    ((64,), 128, (3, 3), (2, 2), (1, 1), (20, 40), 1, ACT_RELU, IN_DIRECT, TF_NONE, False, (2, 2, 1, 8, 8, 1)),
+    ((192,), 192, (3, 1), (1, 1), (1, 0), (32, 64), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (3, 4, 1, 32, 8, 1)),
+    ((44,), 24, (1, 3), (1, 1), (0, 1), (12, 20), 1, ACT_LEAKY_RELU, IN_DIRECT, TF_NONE, False, (2, 2, 1, 16, 4, 1)),
 ]
 
 

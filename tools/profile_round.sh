@@ -15,6 +15,7 @@ timeout 600 python bench.py --steps 200 $SHAPE --dump-layers $OUT/layers.json > 
 tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --steps $STEPS --no-cpu-baseline --no-primer $SHAPE > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_seq -o t -- python $REPO/bench.py --steps $STEPS --in-flight 1 --no-cpu-baseline --no-primer $SHAPE > $OUT/trace_seq.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES"; do
@@ -23,7 +24,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_
   echo "pmc pass $i ($C) rc=$?"
 done
 cd $REPO
-python tools/summarize_prof.py --tag $TAG --stats $(find $OUT/trace -name "*_results.db" | head -1) --pmc $(find $OUT/pmc* -name "*_results.db") | tail -40
+python tools/summarize_prof.py --tag $TAG --stats $(find $OUT/trace -name "*_results.db" | head -1) --stats-seq $(find $OUT/trace_seq -name "*_results.db" | head -1) --pmc $(find $OUT/pmc* -name "*_results.db") | tail -40
 cp $OUT/layers.json profiles/${TAG}_layer_times.json
 tail -1 $OUT/bench.json > profiles/${TAG}_bench.json
 mkdir -p $REPO/gpurun_out/profiles_out && cp profiles/${TAG}_* $REPO/gpurun_out/profiles_out/

@@ -60,6 +60,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
     ap.add_argument("--stats", default=None)
+    ap.add_argument("--stats-seq", default=None, help="kernel trace of the same command with --in-flight 1 (no overlap between keyframes): "
+                                                      "kernel-only durations that are not inflated by a second keyframe's kernels")
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("--launches-per-step", type=int, default=None, help="dispatches of each kernel instance per profiled run / steps")
     args = ap.parse_args()
@@ -72,6 +74,14 @@ def main():
         with open(os.path.join(out_dir, f"{args.tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(cols + ["note: durations in us; rocprofv3 --kernel-trace --stats"])
+            w.writerows(rows)
+    if args.stats_seq:
+        c = sqlite3.connect(args.stats_seq)
+        cols = [r[1] for r in c.execute("pragma table_info(top_kernels)")]
+        rows = list(c.execute("select * from top_kernels"))
+        with open(os.path.join(out_dir, f"{args.tag}_kernel_stats_seq.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(cols + ["note: durations in us; rocprofv3 --kernel-trace --stats; bench.py --in-flight 1 (one keyframe at a time)"])
             w.writerows(rows)
     agg = collections.defaultdict(dict)
     for path in args.pmc:

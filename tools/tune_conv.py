@@ -140,7 +140,7 @@ def main():
         best = None
         rows = []
         for cd in keep:
-            sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"], cd["waves"])
+            sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"], cd["waves"], cd.get("kws", 0))
             try:
                 p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w), c.get("bf16", False))
                 t = time_op(fn, reps=args.reps) if args.streams <= 1 else time_op_streams(fn, streams, reps=args.reps)

@@ -273,6 +273,40 @@ def secondary_bf16x3(sd, batch_dev, ref, dev, args, steps=150):
             "note": "secondary arithmetic mode; the headline `value` is the fp32 MFMA path"}
 
 
+def secondary_dynamic_batching(sd, batch_dev, ref, dev, args, steps=160):
+    """SECONDARY number, never `value`: the same stream of single-keyframe requests with MonoRecModel(hip_batch_keyframes=K) -
+    submit() coalesces K consecutive requests into one launch of the path (fp32 arithmetic, the default kernels).  At batch 1
+    two thirds of the launches are latency chains; `value` keeps one launch chain per request."""
+    import collections
+    from monorec_amd import MonoRecModel
+    out = {"unit": "keyframes/s", "steps": steps, "note": "requests coalesced per launch by submit(); secondary - the headline launches every request on its own"}
+    for k in (2, 4):
+        m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=2, hip_batch_keyframes=k)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        pending = collections.deque()
+
+        def run(n):
+            last = None
+            for _ in range(n):
+                pending.append(m.submit(dict(batch_dev)))
+                if len(pending) >= 2 * k:                       # two groups in flight
+                    last = pending.popleft().result()
+            while pending:
+                last = pending.popleft().result()
+            torch.cuda.synchronize()
+            return last
+        with torch.no_grad():
+            run(12 * k)
+            t0 = time.perf_counter()
+            last = run(steps)
+            dt = time.perf_counter() - t0
+        out[f"requests_per_launch_{k}"] = {"value": steps * args.batch / dt,
+                                           "depth_max_abs_err_vs_cpu": float((last["result"].cpu() - ref["result"]).abs().max())}
+        del m
+    return out
+
+
 def prime_device(args, dev_index):
     """The first process that runs this workload on a freshly booted GPU box pipelines ~6 % slower than every later
     one - measured: 375 vs 400 keyframes/s with identical per-kernel times, whatever the spin-up length (3-40 s), the
@@ -501,6 +535,7 @@ def main():
                 result["with_data_loading"] = with_data_loading(model, dev, args.frames, args.depths, in_flight=args.in_flight)
             if is_c2_fp32 and not args.no_secondary:
                 result["secondary_bf16x3"] = secondary_bf16x3(sd, batch_dev, ref, dev, args)
+                result["secondary_dynamic_batching"] = secondary_dynamic_batching(sd, batch_dev, ref, dev, args)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -214,7 +214,8 @@ class MonoRecModel(nn.Module):
                  pretrain_dropout_mode=0, augmentation=None, use_mono=True, use_stereo=False, use_ssim=True,
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
-                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False):
+                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
+                 hip_batch_keyframes=1):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -247,6 +248,10 @@ class MonoRecModel(nn.Module):
                 f"unsupported non-default options: {bad} (SURVEY.md section 8 f-4)")
         self._hip_graph = bool(hip_graph)
         self._in_flight = max(1, int(hip_in_flight))
+        # submit() coalesces this many consecutive equal-shaped requests into ONE launch of the path (dynamic batching of a keyframe
+        # stream: at batch 1 two thirds of the launches are latency chains); 1 = every request is launched on its own
+        self._batch_keyframes = max(1, int(hip_batch_keyframes))
+        self._open_group = None
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
         # hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
@@ -323,6 +328,7 @@ class MonoRecModel(nn.Module):
         for k in ("_plans", "_graphs", "_streams", "_consts"):
             state[k] = {}
         state["_packed_state"] = None
+        state["_open_group"] = None
         state.pop("_lock", None)
         return state
 
@@ -382,7 +388,7 @@ class MonoRecModel(nn.Module):
             out["mask"] = out["cv_mask"]
         return out
 
-    def submit(self, data_dict):
+    def _submit_one(self, data_dict):
         """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
         wait for it.  Keyframes are independent, so a stream of keyframes is served with `hip_in_flight` (default 2)
         of them on the GPU at once - on separate HIP streams and resident buffers - which fills the launch
@@ -427,6 +433,70 @@ class MonoRecModel(nn.Module):
         device = keyframe.device
         with self._lock, torch.cuda.device(device):
             return self._submit_locked(data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device)
+
+    # keys of a request that dynamic batching concatenates along the batch dimension (tensors, or lists of tensors)
+    _BATCHED_INPUTS = ("keyframe", "keyframe_intrinsics", "keyframe_pose", "frames", "intrinsics", "poses",
+                       "stereoframe", "stereoframe_intrinsics", "stereoframe_pose")
+
+    def submit(self, data_dict):
+        """Enqueue one forward and return a handle (`.result()` -> the filled dict, outputs are views: see `_submit_one`).
+
+        With `hip_batch_keyframes = K > 1`, K consecutive requests of equal shapes are coalesced into one launch of the path over
+        their concatenated batch (keyframes are independent): the launch goes out when the K-th request arrives, or when
+        the result of a member is asked for earlier (then with the members collected so far).  Requests carrying per-request
+        extras (`cv_depths`, `mvobj_mask` with pretrain_mode 3, `simple_mask`'s previous prediction) are launched on their own."""
+        if self._batch_keyframes <= 1 or self.simple_mask or self.pretrain_mode == 3 or data_dict.get("cv_depths") is not None:
+            self._flush_open_group()
+            return self._submit_one(data_dict)
+        with self._lock:
+            data_dict.pop(_METRIC_CACHE_KEY, None)            # cached metric sums of an earlier forward on this dict are stale now
+            kf = data_dict["keyframe"]
+            sig = (tuple(kf.shape), str(kf.device), len(data_dict.get("frames", ())))
+            g = self._open_group
+            if g is not None and g.sig != sig:
+                self._flush_open_group()
+                g = None
+            if g is None:
+                g = self._open_group = _Group(sig)
+            g.members.append(data_dict)
+            handle = _GroupHandle(self, g, len(g.members) - 1)
+            if len(g.members) >= self._batch_keyframes:
+                self._flush_open_group()
+            return handle
+
+    def _flush_open_group(self):
+        """Launch the requests collected so far as one batch and hand every member its slice of the outputs."""
+        with self._lock:
+            g, self._open_group = self._open_group, None
+            if g is None or g.pending is not None:
+                return
+            ms = g.members
+            if len(ms) == 1:
+                g.pending = self._submit_one(ms[0])
+                return
+            combined = {}
+            for k in self._BATCHED_INPUTS:
+                if k not in ms[0]:
+                    continue
+                v = ms[0][k]
+                combined[k] = ([torch.cat([m[k][i] for m in ms]) for i in range(len(v))] if isinstance(v, (list, tuple))
+                               else torch.cat([m[k] for m in ms]))
+            g.pending = self._submit_one(combined)
+            b = ms[0]["keyframe"].shape[0]
+            for j, m in enumerate(ms):
+                lo, hi = j * b, (j + 1) * b
+                for k, v in combined.items():
+                    if k in self._BATCHED_INPUTS:
+                        continue
+                    if torch.is_tensor(v):
+                        m[k] = v[lo:hi] if (v.dim() == 4 and v.shape[0] == b * len(ms)) else v
+                    elif isinstance(v, list):
+                        m[k] = [t[lo:hi] for t in v]
+                if self.pretrain_mode == 2:
+                    m["result"] = m["cv_mask"]
+                else:
+                    m["result"] = m["predicted_inverse_depths"][0]
+                    m["mask"] = m["cv_mask"]
 
     def _submit_locked(self, data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device):
         # the three constants of :675-677: built once per device (a `new_tensor` from a Python list is a blocking pageable H2D copy on
@@ -556,6 +626,33 @@ class MonoRecModel(nn.Module):
             entry = graph
         with torch.cuda.stream(stream):
             entry.replay()
+
+
+class _Group:
+    """Requests collected by MonoRecModel.submit for one coalesced launch (hip_batch_keyframes > 1)."""
+
+    def __init__(self, sig):
+        self.sig, self.members, self.pending = sig, [], None
+
+
+class _GroupHandle:
+    """Handle of one member of a coalesced launch; same interface as _Pending."""
+
+    def __init__(self, model, group, index):
+        self._model, self._group, self._index = model, group, index
+
+    def _launched(self):
+        if self._group.pending is None:
+            self._model._flush_open_group()       # asked for before the group filled up: launch what has been collected
+        return self._group.pending
+
+    def result(self):
+        self._launched().result()
+        return self._group.members[self._index]
+
+    def synchronize(self):
+        self._launched().synchronize()
+        return self._group.members[self._index]
 
 
 class _Pending:

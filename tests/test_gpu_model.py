@@ -542,3 +542,32 @@ def test_inputs_are_read_in_place_or_through_the_resident_copy(hip_lib):
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert torch.equal(odd["keyframe"], keep)
+
+
+def test_dynamic_batching_of_a_keyframe_stream(hip_lib):
+    """hip_batch_keyframes=K: submit() coalesces K consecutive equal-shaped requests into one launch over their concatenated batch;
+    a result asked for before the group is full launches what has been collected.  Every request gets its own slice of the outputs,
+    equal (to summation-order noise: other tile schedules at another batch size) to the request run alone."""
+    import collections
+    plain, sd = _model(8, graph=False)
+    batches = [_to_dev(synth.make_batch(1, 64, 96, 2, seed=80 + i)) for i in range(5)]
+    with torch.no_grad():
+        want = [plain(dict(b))["result"].clone() for b in batches]
+    m = MonoRecModel(cv_depth_steps=8, hip_in_flight=2, hip_batch_keyframes=2)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    pending, got = collections.deque(), []
+    with torch.no_grad():
+        for b in batches:                                   # 5 requests: groups (0,1), (2,3) and the early-flushed (4)
+            pending.append(m.submit(dict(b)))
+            if len(pending) >= 4:
+                got.append(pending.popleft().result()["result"].clone())
+        while pending:
+            got.append(pending.popleft().result()["result"].clone())
+        torch.cuda.synchronize()
+        assert len(m._plans) >= 2 and {k[1] for k in m._plans} == {1, 2}      # batch-2 launches plus the single left-over request
+        for g, w in zip(got, want):
+            assert g.shape == w.shape == (1, 1, 64, 96)
+            assert float((g - w).abs().max()) <= 1e-5
+        out = m(dict(batches[0]))                           # forward() through a batching model: a group of one, owned outputs
+        assert float((out["result"] - want[0]).abs().max()) <= 1e-5 and out["mask"] is out["cv_mask"]

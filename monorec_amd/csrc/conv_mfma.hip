@@ -382,6 +382,37 @@ __device__ __forceinline__ void kstep_bf16(f32x4 (&acc)[MB][NB], const float* __
         for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[m], bv[i], acc[m][i], 0, 0, 0);
 }
 
+// Two 16-channel steps of a tap in ONE v_mfma_f32_16x16x32_bf16 (gfx950: K = 32, the same issue time as the K = 16 form): lane
+// (cout l&15, group g = l>>4) holds 8 bf16 - elements 0..3 = channels 4j+g of step c16, 4..7 = the same of step c16 + 1; the
+// packed weight stream and the LDS planes are those of the K = 16 path, read as two halves.
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MB, int NB>
+__device__ __forceinline__ void kstep_bf16_k32(f32x4 (&acc)[MB][NB], const float* __restrict__ wt, const float* __restrict__ ldsI,
+                                               const int (&lbase)[NB], int c16, int off, int plane4) {
+    s16x8v av[MB], bv[NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        union { f32x2 f; s16x4 v; } lo, hi;
+        lo.f = *(const f32x2*)(wt + (c16 * MB + m) * 128);                  // wt already includes lane * 2
+        hi.f = *(const f32x2*)(wt + ((c16 + 1) * MB + m) * 128);
+        av[m] = (s16x8v){lo.v[0], lo.v[1], lo.v[2], lo.v[3], hi.v[0], hi.v[1], hi.v[2], hi.v[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float* p = ldsI + lbase[i] + off;                            // channel (lane >> 4) of step c16; step c16 + 1 is 16 planes on
+        const s16x4 lo = pack_bf16x4(p[0], p[plane4], p[2 * plane4], p[3 * plane4]);
+        const s16x4 hi = pack_bf16x4(p[4 * plane4], p[5 * plane4], p[6 * plane4], p[7 * plane4]);
+        bv[i] = (s16x8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m]), __builtin_bit_cast(bf16x8, bv[i]), acc[m][i], 0, 0, 0);
+}
+
 template <int MB, int NB>
 __device__ __forceinline__ void sweep_chunk_bf16(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
                                                  const int (&lbase)[NB], int ck16, int lane, int KH, int KW) {
@@ -392,10 +423,8 @@ __device__ __forceinline__ void sweep_chunk_bf16(const ConvKArgs& a, f32x4 (&acc
             const int tapoff = kh * a.IWa + kw;
             const float* wt = wl + (kh * KW + kw) * ck16 * (MB * 128);
             int c16 = 0;
-            for (; c16 + 2 <= ck16; c16 += 2) {
-                kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
-                kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16 + 1, (c16 + 1) * 16 * a.PLANE + tapoff, plane4);
-            }
+            for (; c16 + 2 <= ck16; c16 += 2)       // pairs of 16-channel steps on the K = 32 instruction
+                kstep_bf16_k32<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
             for (; c16 < ck16; ++c16) kstep_bf16<MB, NB>(acc, wt, ldsI, lbase, c16, c16 * 16 * a.PLANE + tapoff, plane4);
         }
     }

@@ -482,3 +482,76 @@ def test_marching_cost_volume_kernel_codegen():
         meta = asm[asm.index("amdhsa.kernels"):]
         k = re.search(r"cv_sad_march_kernel" + variant + r".*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", meta, re.S)
         assert k and int(k.group(1)) == 0 and int(k.group(2)) <= 128, (variant, k and k.groups())
+
+
+class _FakePending:
+    def __init__(self, data):
+        self._data = data
+
+    def result(self):
+        return self._data
+
+    def synchronize(self):
+        return self._data
+
+
+def _stub_submit_one(model, calls):
+    """Replace the launch path by a CPU stand-in: outputs are simple functions of the (possibly concatenated) inputs."""
+    def submit_one(data):
+        calls.append(int(data["keyframe"].shape[0]))
+        kf = data["keyframe"]
+        data["predicted_inverse_depths"] = [kf[:, :1] * 2.0, kf[:, :1, ::2, ::2], kf[:, :1, ::4, ::4], kf[:, :1, ::8, ::8]]
+        data["cv_mask"] = kf[:, 1:2] + 1.0
+        data["cost_volume"] = kf.repeat(1, 2, 1, 1)
+        data["single_frame_cvs"] = [f + 3.0 for f in data["frames"]]
+        data["image_features"] = [kf[:, :2]]
+        data["inv_depth_min"] = torch.tensor([0.33])
+        data["result"], data["mask"] = data["predicted_inverse_depths"][0], data["cv_mask"]
+        return _FakePending(data)
+    model._submit_one = submit_one
+
+
+def test_dynamic_batching_groups_requests_and_slices_outputs():
+    """Host logic of MonoRecModel(hip_batch_keyframes=K).submit: K equal-shaped requests -> one launch over the concatenated batch,
+    every request gets its slice; a result asked for early launches the partial group; a shape change closes the group."""
+    m = MonoRecModel(cv_depth_steps=8, hip_batch_keyframes=3)
+    calls = []
+    _stub_submit_one(m, calls)
+    reqs = [dict(keyframe=torch.full((1, 3, 8, 16), float(i)), keyframe_intrinsics=torch.eye(4).unsqueeze(0),
+                 keyframe_pose=torch.eye(4).unsqueeze(0), frames=[torch.full((1, 3, 8, 16), 10.0 + i)] * 2,
+                 intrinsics=[torch.eye(4).unsqueeze(0)] * 2, poses=[torch.eye(4).unsqueeze(0)] * 2) for i in range(5)]
+    hs = [m.submit(r) for r in reqs[:3]]
+    assert calls == [3]                                         # the third request filled the group
+    for i, h in enumerate(hs):
+        out = h.result()
+        assert out is reqs[i] and out["result"].shape == (1, 1, 8, 16) and float(out["result"][0, 0, 0, 0]) == 2.0 * i
+        assert float(out["single_frame_cvs"][1][0, 0, 0, 0]) == 13.0 + i and out["mask"] is out["cv_mask"]
+        assert out["result"] is out["predicted_inverse_depths"][0] and out["inv_depth_min"].shape == (1,)
+    h3 = m.submit(reqs[3])
+    assert calls == [3] and float(h3.result()["result"][0, 0, 0, 0]) == 6.0 and calls == [3, 1]      # early result -> group of one
+    h4 = m.submit(reqs[4])
+    other = dict(reqs[0], keyframe=torch.zeros(1, 3, 16, 16), frames=[torch.zeros(1, 3, 16, 16)] * 2)
+    h5 = m.submit(other)                                        # another shape: the open group is launched first
+    assert calls == [3, 1, 1]
+    assert float(h4.result()["result"][0, 0, 0, 0]) == 8.0 and h5.result()["result"].shape == (1, 1, 16, 16) and calls == [3, 1, 1, 1]
+
+
+def test_forward_returns_owned_outputs_with_the_reference_aliasing():
+    """forward() = submit().result() + one copy of every output tensor (monorec_model.py:713-727 allocates its outputs), with
+    `result is predicted_inverse_depths[0]` and `mask is cv_mask` like the reference (:723-727)."""
+    m = MonoRecModel(cv_depth_steps=8)
+    _stub_submit_one(m, [])
+    m.submit = lambda d: m._submit_one(d)
+    import contextlib
+    orig = torch.cuda.device
+    torch.cuda.device = lambda dev: contextlib.nullcontext()    # no HIP device in this test
+    try:
+        kf = torch.arange(3 * 8 * 16, dtype=torch.float32).view(1, 3, 8, 16)
+        data = dict(keyframe=kf, frames=[kf + 1, kf + 2])
+        out = m.forward(data)
+    finally:
+        torch.cuda.device = orig
+    assert out["result"] is out["predicted_inverse_depths"][0] and out["mask"] is out["cv_mask"]
+    assert out["result"].data_ptr() != kf.data_ptr() and out["cost_volume"].data_ptr() != kf.data_ptr()
+    kf.add_(100.0)                                              # the "resident buffer" changes: owned outputs do not
+    assert float(out["result"][0, 0, 0, 1]) == 2.0 and float(out["cv_mask"][0, 0, 0, 0]) == float(8 * 16 + 1)

@@ -81,10 +81,12 @@ def time_layers(model, batch_dev, plan_key, reps=5):
         for i, (e0, e1) in enumerate(evs):
             acc[i] += e0.elapsed_time(e1) * 1e-3 / reps
     macs = {c["name"]: c for c in plan.conv_log}
+    aux = {a["name"]: a for a in getattr(plan, "aux_log", [])}          # one-channel layers on their own kernels (csrc/heads.hip)
     rows = []
     for (name, _), t in zip(ops, acc):
         c = macs.get(name)
         rows.append({"name": name, "seconds": t, "macs": c["macs"] if c else 0, "ref_macs": c["ref_macs"] if c else 0,
+                     "aux_ref_macs": aux[name]["ref_macs"] if name in aux else 0,
                      "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4), c.get("kws", 0)] if c else None, "wgs": c["wgs"] if c else None,
                      "tflops": (2 * c["macs"] / t / 1e12) if c and t > 0 else None})
     return rows
@@ -508,6 +510,11 @@ def main():
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
             "roofline": roof,
             "cost_volume_kernel": cv_block,
+            "one_channel_layers": {"kernels": "mask_classifier_kernel (+ mask multiply), depth_heads_kernel (csrc/heads.hip): HBM-bound, "
+                                              "not part of the MFMA roofline above",
+                                   "launches": [r["name"] for r in rows if r.get("aux_ref_macs")],
+                                   "algorithmic_gflop_per_step": 2.0 * sum(r.get("aux_ref_macs", 0) for r in rows) / 1e9,
+                                   "us_per_step": sum(r["seconds"] for r in rows if r.get("aux_ref_macs")) * 1e6},
             "device_ms_per_step_sum_of_kernels": sum(r["seconds"] for r in rows) * 1e3,
         }
         if args.dump_layers:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 4
+#define MR_ABI_VERSION 5
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -37,6 +37,7 @@ extern "C" {
 
 #define MR_MAX_SOURCES 3
 #define MR_MAX_FRAMES  8
+#define MR_MAX_HEADS   4   /* one-channel 3x3 heads per mr_depth_heads_f32 launch (DepthModule has 4 predictors) */
 #define MR_MAX_VOTE_MASKS 8   /* masks voted over by mr_pointcloud_append_f32 (the reference buffers 5) */
 
 /* ---- activation codes for mr_conv2d_f32 (epilogue, applied after bias [+ residual]) ---- */
@@ -259,6 +260,29 @@ int mr_pool2x2_framemax_f32(const float* src, float* pooled, float* frame_max, i
  * dst may alias cv. */
 int mr_apply_mask_f32(const float* cv, const float* mask, float* dst, int32_t batch, int32_t num_depths,
                       int64_t plane, void* stream);
+
+/* MaskModule.classifier = nn.Conv2d(C, 1, kernel_size=1) + nn.Sigmoid (monorec_model.py:340-343, applied :383) fused with the
+ * mask multiply that follows it in MonoRecModel.forward, cost_volume = (1 - cv_mask) * cost_volume (:713):
+ *   cv_mask[b,0,p] = sigmoid(bias[0] + sum_c weight[c] * features[b,c,p]);   cost_volume[b,d,p] *= 1 - cv_mask[b,0,p]  (in place)
+ * features (batch, channels, plane) with plane = H*W even, weight (channels) = the conv's (1,C,1,1) tensor, cv_mask (batch,1,plane),
+ * cost_volume (batch, num_depths, plane) or NULL (mask only: pretrain_mode 2, :712,723).  One HBM-bound launch instead of a
+ * 1-of-16-rows MFMA launch + mr_apply_mask_f32. */
+int mr_mask_classifier_f32(const float* features, const float* weight, const float* bias, int32_t batch, int32_t channels,
+                           int64_t plane, float* cv_mask, float* cost_volume, int32_t num_depths, void* stream);
+
+/* DepthModule.predictors[i] = PadSameConv2d(3) + nn.Conv2d(C_i, 1, 3) (monorec_model.py:520-523), predict_depth's abs(tanh(x))
+ * (:554-557) and the inverse-depth affine (1 - p) * act_p0 + p * act_p1 of MonoRecModel.forward (:716-717), for up to
+ * MR_MAX_HEADS heads in ONE launch (their inputs differ in size; nothing downstream reads the outputs, so they run together once
+ * the decoder is done).  Per head: src (batch, channels, height, width), weight (1, channels, 3, 3) as nn.Conv2d stores it,
+ * bias (1), dst (batch, 1, height, width); zero padding 1 on every side (PadSameConv2d of k=3, s=1: model/layers.py:249-251). */
+typedef struct mr_head_desc {
+    const float* src;
+    const float* weight;
+    const float* bias;
+    float* dst;
+    int32_t batch, channels, height, width;
+} mr_head_desc;
+int mr_depth_heads_f32(const mr_head_desc* heads, int32_t num_heads, float act_p0, float act_p1, void* stream);
 
 /* Fused sparse depth metrics, one launch for all seven metrics of configs/evaluate/eval_monorec.json:53-61
  * (model/metric_functions/sparse_metrics.py:136-252 with utils/util.py:36-118; pred_all_valid=True, no cv-mask):

@@ -57,6 +57,14 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class HeadDesc(ctypes.Structure):
+    """mirror of `mr_head_desc` (include/monorec_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+                ("batch", ctypes.c_int32), ("channels", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32)]
+
+
+MR_MAX_HEADS = 4
+
 # every symbol include/monorec_hip.h declares: (restype, argtypes)
 ABI = {
     "mr_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
@@ -109,6 +117,9 @@ ABI = {
                                                ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_apply_mask_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_mask_classifier_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "mr_depth_heads_f32": (ctypes.c_int, [ctypes.POINTER(HeadDesc), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mr_sparse_metric_sums_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_float,
                                                  ctypes.c_void_p, ctypes.c_void_p]),
@@ -158,7 +169,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 4:
+    if lib.mr_abi_version() != 5:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -23,6 +23,7 @@ SOURCES = [
     ("pointcloud.hip", ["-ffp-contract=off"]),
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("eltwise.hip", []),
+    ("heads.hip", []),
 ]
 
 

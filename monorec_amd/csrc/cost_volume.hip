@@ -1074,10 +1074,15 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
     CvArgs k = a;
     if (mode == 1 && !plane_flags && !tiled) {
         // default configuration: LDS-free marching kernel, two depth planes per wave
-        const MarchGeom g = march_geometry(a, 2);
+        static const int dp_env = [] { const char* e = getenv("MR_CV_MARCH_DP"); return e ? atoi(e) : 0; }();   // tuning aid: 1 = one plane per wave
+        const bool dp1 = dp_env == 1 && !a.pix_depths && a.D >= 6;
+        const MarchGeom g = march_geometry(a, dp1 ? 1 : 2);
         const dim3 grid((unsigned)(g.strips * g.ysegs), (unsigned)(a.F * ((g.npairs + 3) / 4)), (unsigned)a.B);
         static const bool no_prepass = getenv("MR_CV_NO_KF_PREPASS") != nullptr;           // A/B aid
-        if (a.D >= 6 && !no_prepass) {       // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
+        if (dp1) {                           // twice the waves, each with one plane: for shapes that leave the SIMDs short of waves
+            hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
+            hipLaunchKernelGGL((cv_sad_march_kernel<1, false, true>), grid, dim3(256), 0, stream, k, g);
+        } else if (a.D >= 6 && !no_prepass) {       // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
             hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
             if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true, true>), grid, dim3(256), 0, stream, k, g);
             else hipLaunchKernelGGL((cv_sad_march_kernel<2, false, true>), grid, dim3(256), 0, stream, k, g);

@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_ABS_TANH_AFFINE, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, IN_DIRECT, IN_MAXPOOL2,
-                   IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM, ConvDesc)
+                   IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM, ConvDesc, HeadDesc)
 
 LEAKY_SLOPE = 0.1   # model/layers.py:290,318,381
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, used by torchvision's ResNet
@@ -242,7 +242,8 @@ class Plan:
 
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
-                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3):
+                 pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3,
+                 one_channel_kernels=None):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -267,6 +268,11 @@ class Plan:
         self.keep = []          # packed weights / biases (device tensors kept alive)
         self.stages = {"encoder": [], "encoder_tail": [], "cv": [], "main": []}
         self.conv_log = []      # (name, macs, mb, nb, split_k, wgs) for bench / tuning
+        self.aux_log = []       # one-channel layers that run on their own HBM-bound kernels (csrc/heads.hip): name, ref_macs
+        if one_channel_kernels is None:         # MR_ONE_CHANNEL_KERNELS=0: A/B aid - classifier / depth heads as mr_conv2d_f32 launches
+            import os
+            one_channel_kernels = os.environ.get("MR_ONE_CHANNEL_KERNELS", "1") != "0"
+        self.one_channel_kernels = bool(one_channel_kernels)
         self.input_ptr = {}       # "keyframe" -> device pointer the launches read the keyframe from (resident copy or the caller's tensor)
         self._input_srcs = []     # (ConvDesc, source index, "keyframe"): descriptor slots that follow input_ptr
         self._frame_ptrs = None   # ctypes array of the F source-frame pointers handed to the cost-volume launch
@@ -588,7 +594,23 @@ class Plan:
             self.same_conv(st, f"mask.dec{i}.2", [a], f"{am}.dec.{i}.2.conv.weight", f"{am}.dec.{i}.2.conv.bias", xo)
             x_srcs = [xo]
         cv_mask = self.alloc("cv_mask", B, 1, H, W)
-        if with_mask:
+        mask_applied = False
+        if with_mask and self.one_channel_kernels:
+            # classifier (1x1 conv -> 1 channel, sigmoid, :340-343) and - in the full model - the mask multiply of :713 in one
+            # HBM-bound launch (csrc/heads.hip) instead of a 1-of-16-rows MFMA launch + mr_apply_mask_f32
+            feat = x_srcs[0]
+            cw_ = self._dev(sd[f"{am}.classifier.0.weight"].reshape(-1))
+            cb_ = self._dev(sd[f"{am}.classifier.0.bias"].reshape(-1))
+            mask_applied = with_depth and self.pretrain_mode == 0
+            cvp = cv if mask_applied else None
+
+            def run_classifier(stream, feat=feat, cw_=cw_, cb_=cb_, cvp=cvp):
+                _lib.check(lib.mr_mask_classifier_f32(feat.data_ptr(), cw_.data_ptr(), cb_.data_ptr(), B, int(feat.shape[1]), H * W,
+                                                      cv_mask.data_ptr(), cvp.data_ptr() if cvp is not None else None, D, stream),
+                           "mr_mask_classifier_f32")
+            self.add(st, "mask.classifier", run_classifier)
+            self.aux_log.append(dict(name="mask.classifier", ref_macs=B * H * W * int(feat.shape[1])))
+        elif with_mask:
             self.same_conv(st, "mask.classifier", x_srcs, f"{am}.classifier.0.weight", f"{am}.classifier.0.bias", cv_mask,
                            act=ACT_SIGMOID)
         else:
@@ -601,7 +623,7 @@ class Plan:
         def run_mask(stream):                                                        # :713 (in place)
             _lib.check(lib.mr_apply_mask_f32(cv.data_ptr(), cv_mask.data_ptr(), cv.data_ptr(), B, D, H * W, stream),
                        "mr_apply_mask_f32")
-        if self.pretrain_mode != 1:        # (1 - 0) * cv == cv exactly
+        if self.pretrain_mode != 1 and not mask_applied:        # (1 - 0) * cv == cv exactly
             self.add(st, "apply_mask", run_mask)
 
         # ---------------- DepthModule (monorec_model.py:526-557) ----------------
@@ -628,11 +650,16 @@ class Plan:
         lo, hi_ = self.inv_depth_min_max[1], self.inv_depth_min_max[0]
         preds = [None] * 4
 
+        heads = []                         # (predictor index, input, output): launched together behind the decoder
+
         def head(idx, src, scale_slot):
             hh_, ww_ = src.shape[2], src.shape[3]
             p = self.alloc(f"pred{scale_slot}", B, 1, hh_, ww_)
-            self.same_conv(st, f"depth.head{idx}", [src], f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
-                           p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)                # :556 + :717
+            if self.one_channel_kernels:
+                heads.append((idx, src, p))
+            else:
+                self.same_conv(st, f"depth.head{idx}", [src], f"{dm}.predictors.{idx}.1.weight", f"{dm}.predictors.{idx}.1.bias",
+                               p, act=ACT_ABS_TANH_AFFINE, p0=lo, p1=hi_)            # :556 + :717
             preds[scale_slot] = p
 
         r0 = self.alloc("depth.dec0", B, dch[0], H // 8, W // 8)
@@ -658,6 +685,24 @@ class Plan:
         x4 = self.alloc("depth.dec4", B, dch[5], H, W)
         self.same_conv(st, "depth.dec4.2", [x4a], f"{dm}.dec.4.2.weight", f"{dm}.dec.4.2.bias", x4)
         head(3, x4, 0)
+        if heads:
+            # the four predictors (3x3 conv -> 1 channel, abs(tanh), inverse-depth affine; :520-523,554-557,716-717) in ONE
+            # HBM-bound launch (csrc/heads.hip): nothing downstream reads them, their inputs stay resident in the plan
+            descs = (HeadDesc * len(heads))()
+            for i, (idx, src, p) in enumerate(heads):
+                w_ = self._dev(sd[f"{dm}.predictors.{idx}.1.weight"])
+                b_ = self._dev(sd[f"{dm}.predictors.{idx}.1.bias"].reshape(-1))
+                assert tuple(w_.shape) == (1, src.shape[1], 3, 3), w_.shape
+                descs[i].src, descs[i].weight, descs[i].bias, descs[i].dst = src.data_ptr(), w_.data_ptr(), b_.data_ptr(), p.data_ptr()
+                descs[i].batch, descs[i].channels, descs[i].height, descs[i].width = [int(v) for v in src.shape]
+                self.keep += [src, p]
+            self.keep.append(descs)
+
+            def run_heads(stream, descs=descs, n=len(heads)):
+                _lib.check(lib.mr_depth_heads_f32(descs, n, lo, hi_, stream), "mr_depth_heads_f32")
+            self.add(st, "depth.heads", run_heads)
+            self.aux_log.append(dict(name="depth.heads", ref_macs=sum(int(s_.shape[0] * s_.shape[1] * s_.shape[2] * s_.shape[3]) * 9
+                                                                       for _, s_, _ in heads)))
         self.preds = preds
 
     # ------------------------------------------------------------------ inputs

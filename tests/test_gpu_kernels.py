@@ -520,3 +520,79 @@ def test_cost_volume_properties_at_full_size(hip_lib):
     # fused volume of two identical frames equals the single-frame volume wherever it is valid
     valid = (sf2[0] != 0).any(1, keepdim=True).expand_as(cv2)
     assert (cv2[valid] - sf2[0][valid]).abs().max().item() < 1e-5
+
+
+# ---- one-channel layers on their own kernels (csrc/heads.hip) ---------------------------------------------------------------
+HEAD_SETS = [
+    # list of (batch, channels, height, width) launched together; MR_HEADS_QUAD_MIN defaults to 65536 pixels
+    [(1, 256, 8, 12), (1, 128, 16, 24), (1, 64, 32, 48), (1, 24, 64, 96)],           # smoke-sized decoder: all in pixel mode
+    [(2, 24, 256, 512)],                                                             # quad mode, rows of 128 quads
+    [(1, 256, 32, 64), (1, 128, 64, 128), (1, 64, 128, 256), (1, 24, 256, 512)],     # the c2 decoder: pixel, pixel, pixel, quad
+    [(3, 7, 5, 6), (1, 19, 160, 412)],                                               # ragged: C % 16 != 0, W % 4 == 0 but odd rows of quads
+    [(2, 5, 130, 260)],                                                              # 67 600 pixels, W % 4 == 0: quad mode with a ragged tail
+    [(1, 9, 300, 301)],                                                              # W % 4 != 0: stays in pixel mode whatever the size
+]
+
+
+@pytest.mark.parametrize("case", range(len(HEAD_SETS)))
+def test_depth_heads_kernel_matches_torch(case):
+    """mr_depth_heads_f32 (monorec_model.py:520-523,554-557,716-717): Conv2d(C, 1, 3) with zero padding 1, abs(tanh), affine -
+    every head of one launch against F.conv2d on the CPU."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(40 + case)
+    shapes = HEAD_SETS[case]
+    lo, hi = 0.0025, 0.33
+    descs = (_lib.HeadDesc * len(shapes))()
+    keep, want, outs = [], [], []
+    for i, (b, c, h, w) in enumerate(shapes):
+        x = torch.randn(b, c, h, w, generator=g)
+        wt = torch.randn(1, c, 3, 3, generator=g) * (0.5 / math.sqrt(9 * c))
+        bias = torch.randn(1, generator=g) * 0.1
+        t = torch.abs(torch.tanh(F.conv2d(x, wt, bias, padding=1)))
+        want.append((1 - t) * lo + t * hi)
+        xd, wd, bd = x.to(DEV), wt.to(DEV), bias.to(DEV)
+        out = torch.full((b, 1, h, w), float("nan"), device=DEV)
+        keep += [xd, wd, bd]
+        outs.append(out)
+        descs[i].src, descs[i].weight, descs[i].bias, descs[i].dst = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr()
+        descs[i].batch, descs[i].channels, descs[i].height, descs[i].width = b, c, h, w
+    _lib.check(lib.mr_depth_heads_f32(descs, len(shapes), lo, hi, _stream()), "mr_depth_heads_f32")
+    torch.cuda.synchronize()
+    for out, ref in zip(outs, want):
+        got = out.cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - ref).abs().max()) <= 2e-6, float((got - ref).abs().max())       # outputs in [0.0025, 0.33]
+
+
+def test_depth_heads_bad_arguments():
+    lib = _lib.load()
+    d = (_lib.HeadDesc * 1)()
+    assert lib.mr_depth_heads_f32(d, 1, 0.0, 1.0, _stream()) == -1           # null pointers
+    assert lib.mr_depth_heads_f32(d, 0, 0.0, 1.0, _stream()) == -1
+    assert lib.mr_depth_heads_f32(d, 5, 0.0, 1.0, _stream()) == -1
+
+
+@pytest.mark.parametrize("shape,with_cv", [((2, 48, 32, 64, 8), True), ((1, 48, 256, 512, 32), True), ((3, 13, 10, 6, 5), True),
+                                           ((2, 48, 16, 24, 4), False)])
+def test_mask_classifier_kernel_matches_torch(shape, with_cv):
+    """mr_mask_classifier_f32: Conv2d(C, 1, 1) + Sigmoid (monorec_model.py:340-343) and, fused, cost_volume *= 1 - cv_mask (:713)."""
+    lib = _lib.load()
+    b, c, h, w, d = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(1, c, 1, 1, generator=g) * (1.0 / math.sqrt(c))
+    bias = torch.randn(1, generator=g) * 0.1
+    cv = torch.randn(b, d, h, w, generator=g)
+    ref_mask = torch.sigmoid(F.conv2d(x, wt, bias))
+    xd, wd, bd, cvd = x.to(DEV), wt.reshape(-1).to(DEV), bias.to(DEV), cv.to(DEV)
+    mask = torch.full((b, 1, h, w), float("nan"), device=DEV)
+    _lib.check(lib.mr_mask_classifier_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), b, c, h * w, mask.data_ptr(),
+                                          cvd.data_ptr() if with_cv else None, d, _stream()), "mr_mask_classifier_f32")
+    torch.cuda.synchronize()
+    got = mask.cpu()
+    assert float((got - ref_mask).abs().max()) <= 2e-6
+    if with_cv:
+        assert torch.equal(cvd.cpu(), (1 - got) * cv)                         # the multiply itself is exact given the mask
+    else:
+        assert torch.equal(cvd.cpu(), cv)
+    assert lib.mr_mask_classifier_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), b, c, 7, mask.data_ptr(), None, d, _stream()) == -1   # odd plane

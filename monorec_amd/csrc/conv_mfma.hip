@@ -327,27 +327,6 @@ __device__ __forceinline__ void sweep_chunk(const ConvKArgs& a, f32x4 (&acc)[MB]
     }
 }
 
-// Taps t0 <= t < t1 (t = kh * KW + kw) of a chunk: the staggered-DMA variant (STG) sweeps a chunk in two halves.
-template <int MB, int NB>
-__device__ __forceinline__ void sweep_chunk_taps(const ConvKArgs& a, f32x4 (&acc)[MB][NB], const float* ldsI, const float* ldsW,
-                                                 const int (&lbase)[NB], int ck4, int lane, int KW, int t0, int t1) {
-    const float* wl = ldsW + lane;
-    int kh = t0 / KW, kw = t0 - kh * KW;
-    for (int t = t0; t < t1; ++t) {
-        const int tapoff = kh * a.IWa + kw;
-        const float* wt = wl + t * ck4 * (MB * 64);
-        int c4 = 0;
-        for (; c4 + 4 <= ck4; c4 += 4) {
-            kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
-            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 1, (c4 + 1) * 4 * a.PLANE + tapoff);
-            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 2, (c4 + 2) * 4 * a.PLANE + tapoff);
-            kstep<MB, NB>(acc, wt, ldsI, lbase, c4 + 3, (c4 + 3) * 4 * a.PLANE + tapoff);
-        }
-        for (; c4 < ck4; ++c4) kstep<MB, NB>(acc, wt, ldsI, lbase, c4, c4 * 4 * a.PLANE + tapoff);
-        if (++kw == KW) { kw = 0; ++kh; }
-    }
-}
-
 // K split across the waves of a workgroup (a.kws): every wave sweeps the k-steps t = wave, wave + WV, ... of the chunk's
 // taps x channel-quads (flattened, so that chunks with fewer quads than waves still spread) for the SAME NB pixel blocks; the
 // partial accumulators meet in LDS after the K loop.  Small layers (a few hundred output pixels per image) get WV x more
@@ -509,10 +488,7 @@ __device__ __forceinline__ void sweep_chunk_bf16x3(const ConvKArgs& a, f32x4 (&a
 // DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
 // max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
 // make hipcc drain vmcnt before every sweep and spill SGPRs).
-// STG (fp32, 8 waves, MB * NB >= 4; experimental, MR_CONV_STAGGER): the upper half of the waves issues its share of the next chunk's
-// DMA between the two halves of the sweep instead of in front of it - the two waves of a SIMD (w and w + WV/2) then never sit in
-// their DMA issue stalls at the same time, so one of them always has MFMAs to issue.
-template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false, bool STG = false>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false>
 __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     dbg_stamp(a, 0);
@@ -624,17 +600,6 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
         cursor_advance<MB>(a, cur, T);
         const bool stamp = q == q_lo + 1 || (q == q_lo && q_hi == q_lo + 1);
         if (stamp) { dbg_stamp(a, 4); dbg_stamp(a, 9); }
-        if (STG) {
-            const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
-            const bool more = q + 1 < q_hi, late = wave >= WV / 2;
-            const int tmid = T >> 1;
-            if (more && !late)
-                issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
-            sweep_chunk_taps<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KW, 0, tmid);
-            if (more && late)
-                issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
-            sweep_chunk_taps<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KW, tmid, T);
-        } else {
         if (q + 1 < q_hi) {
             const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
             issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
@@ -645,7 +610,6 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
             else if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
             else if (BF16 == 1) sweep_chunk_bf16<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
             else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KH, KW);
-        }
         }
         if (stamp) dbg_stamp(a, 6);
         dma_wait_all();                                // this wave's share of the next chunk has landed
@@ -785,7 +749,6 @@ struct Derived {
     size_t lds_bytes;
     int mb, nb, wv;
     int mode;                  // MR_COMPUTE_*: 0 fp32 MFMA, 1 bf16, 2 bf16x3 split
-    int stagger;               // launch the STG instantiation (MR_CONV_STAGGER)
     dim3 grid;
 };
 
@@ -915,10 +878,6 @@ int derive(const mr_conv_desc* d, Derived* out) {
     if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb; out->wv = wv;
-    {   // MR_CONV_STAGGER=N (tuning aid, read once): staggered DMA issue for the 8-wave fp32 launches with MB * NB >= max(N, 4)
-        static const int stagger_min = [] { const char* e = getenv("MR_CONV_STAGGER"); return e ? atoi(e) : 0; }();
-        out->stagger = (stagger_min > 0 && !bf16 && !kws && wv == 8 && mb * nb >= (stagger_min > 4 ? stagger_min : 4) && k.KH * k.KW >= 2) ? 1 : 0;
-    }
     if (wv == 8 && !k.dma_x4) return MR_ERR_UNSUPPORTED;
     if (kws && !k.dma_in) return MR_ERR_UNSUPPORTED;
     if (bf16 && !k.dma_in) return MR_ERR_UNSUPPORTED;                 // bf16 mode: LDS-DMA staged inputs only
@@ -931,7 +890,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false, bool STG = false>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false>
 int launch(const Derived& dv, hipStream_t stream) {
     // raise the dynamic-LDS ceiling once per instantiation AND device (the attribute lives in the device's code object:
     // a process that drives several GPUs - nn.DataParallel replicas - must set it on each)
@@ -940,12 +899,12 @@ int launch(const Derived& dv, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS, STG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS, STG>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
@@ -963,7 +922,6 @@ int launch_variant(const Derived& dv, hipStream_t stream) {
         if (dv.wv == 8) return launch<MB, NB, true, 8, 0, true>(dv, stream);
         return launch<MB, NB, true, 4, 0, true>(dv, stream);
     }
-    if (MB * NB >= 4 && dv.wv == 8 && dv.stagger) return launch<MB, NB, true, 8, 0, false, (MB * NB >= 4)>(dv, stream);
     if (dv.wv == 8) return launch<MB, NB, true, 8, 0>(dv, stream);         // dwordx4 DMA path only (derive() checked)
     if (dv.k.dma_in) return launch<MB, NB, true, 4, 0>(dv, stream);
     return launch<MB, NB, false, 4, 0>(dv, stream);

@@ -1074,8 +1074,16 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
     CvArgs k = a;
     if (mode == 1 && !plane_flags && !tiled) {
         // default configuration: LDS-free marching kernel, two depth planes per wave
-        static const int dp_env = [] { const char* e = getenv("MR_CV_MARCH_DP"); return e ? atoi(e) : 0; }();   // tuning aid: 1 = one plane per wave
-        const bool dp1 = dp_env == 1 && !a.pix_depths && a.D >= 6;
+        // One plane per wave instead of two when two would leave the 1024 SIMDs with fewer than 4 waves each (a wave issues one
+        // VALU instruction per ~4.6 cycles on its own, a SIMD takes one per ~1.6 from 4 waves): c2 2016 -> 4032 waves, 143 -> 133 us;
+        // no difference once the chip is full (c3).  MR_CV_MARCH_DP=1 / 2 forces either (tuning aid, read once).
+        static const int dp_env = [] { const char* e = getenv("MR_CV_MARCH_DP"); return e ? atoi(e) : 0; }();
+        bool dp1 = false;
+        if (!a.pix_depths && a.D >= 6) {
+            const MarchGeom g2 = march_geometry(a, 2);
+            const long long waves2 = (long long)g2.strips * g2.ysegs * a.F * a.B * g2.npairs;
+            dp1 = dp_env == 1 || (dp_env != 2 && waves2 < 4096);
+        }
         const MarchGeom g = march_geometry(a, dp1 ? 1 : 2);
         const dim3 grid((unsigned)(g.strips * g.ysegs), (unsigned)(a.F * ((g.npairs + 3) / 4)), (unsigned)a.B);
         static const bool no_prepass = getenv("MR_CV_NO_KF_PREPASS") != nullptr;           // A/B aid

@@ -51,8 +51,11 @@ __device__ __forceinline__ float head_activate(float v, float p0, float p1) {
 // neighbours), wave = a quarter of the channels.  pixel mode (small maps: too few pixels to fill the chip otherwise): lane =
 // (pixel 0..15, channel sub-split 0..3), wave = a quarter again - 16 partial sums per pixel.  The partial sums meet in LDS and
 // are added in a fixed order.  Zero padding = buffer loads with an out-of-range offset (the hardware returns 0).
+#define MR_HEAD_LDS_CHANNELS 512      // heads up to this many channels keep their 9 C weights in LDS (pixel mode)
+
 __global__ __launch_bounds__(256) void depth_heads_kernel(const HeadsArgs a) {
     __shared__ float part[4][64][4];
+    __shared__ float wlds[MR_HEAD_LDS_CHANNELS * 9];
     HeadK h = a.h[0];
 #pragma unroll
     for (int i = 1; i < MR_MAX_HEADS; ++i)
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void depth_heads_kernel(const HeadsArgs a) {
             vr[dy] = (rok && x + 4 < W) ? vo[dy] + 16 : -1;
         }
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 3
         for (int c = c_lo; c < c_hi; ++c) {
             const int so = c * HW * 4;
             const float* wc = h.w + c * 9;
@@ -128,16 +131,26 @@ __global__ __launch_bounds__(256) void depth_heads_kernel(const HeadsArgs a) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             vo[t] = (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (b * C * HW + yy * W + xx) * 4 : -1;
         }
+        // the lanes of a wave work on four different channels: their weights come from LDS (one cooperative copy up front)
+        // instead of nine more per-lane global loads per channel in front of every FMA batch
+        const bool w_in_lds = C <= MR_HEAD_LDS_CHANNELS;
+        if (w_in_lds) {
+            for (int i = threadIdx.x; i < C * 9; i += 256) wlds[i] = h.w[i];
+            __syncthreads();
+        }
         float acc = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int c = c_lo; c < c_hi; ++c) {
             const int co = c * HW * 4;
-            const float* wc = h.w + c * 9;
             float xv[9], wv[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                xv[t] = ld1(rs, vo[t] < 0 ? -1 : vo[t] + co, 0);
-                wv[t] = wc[t];
+            for (int t = 0; t < 9; ++t) xv[t] = ld1(rs, vo[t] < 0 ? -1 : vo[t] + co, 0);
+            if (w_in_lds) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wv[t] = wlds[c * 9 + t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wv[t] = h.w[c * 9 + t];
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc = fmaf(wv[t], xv[t], acc);
@@ -153,37 +166,80 @@ __global__ __launch_bounds__(256) void depth_heads_kernel(const HeadsArgs a) {
     }
 }
 
-// Thread = two neighbouring pixels of one sample: C-term dot product, sigmoid, mask store, then the D planes of the cost
-// volume scaled in place.  Every access is a coalesced 8-byte-per-lane stream over a plane.
-__global__ __launch_bounds__(256) void mask_classifier_kernel(const float2* __restrict__ feat, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, int C, long long plane2, long long total2,
-                                                              float2* __restrict__ mask, float2* cv, int D) {
+// Thread = VEC (1 or 2) neighbouring pixels of one sample: C-term dot product, sigmoid, mask store, then the D planes of the cost
+// volume scaled in place.  Every access is a coalesced stream over a plane; the loops run in batches of 16 independent loads (the
+// kernel is bound by how many bytes it keeps in flight: ~60 MB per keyframe at c2 behind ~2 us of memory latency).
+template <int VEC>
+struct VecF;
+template <>
+struct VecF<1> { typedef float type; };
+template <>
+struct VecF<2> { typedef float2 type; };
+
+__device__ __forceinline__ float vget(float v, int) { return v; }
+__device__ __forceinline__ float vget(float2 v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
+__device__ __forceinline__ void vset(float2& v, int i, float x) { if (i) v.y = x; else v.x = x; }
+
+template <int VEC>
+__global__ __launch_bounds__(256) void mask_classifier_kernel(const float* __restrict__ feat_, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int C, long long planev, long long totalv,
+                                                              float* __restrict__ mask_, float* cv_, int D) {
+    typedef typename VecF<VEC>::type V;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
-    if (i >= total2) return;
-    const long long b = i / plane2, p = i - b * plane2;
-    const float2* f = feat + b * C * plane2 + p;
-    float ax = 0.f, ay = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < C; ++c) {
-        const float2 x = f[c * plane2];
+    if (i >= totalv) return;
+    const long long b = i / planev, p = i - b * planev;
+    const V* f = (const V*)feat_ + b * C * planev + p;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    int c = 0;
+    for (; c + 16 <= C; c += 16) {
+        V x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = f[(long long)(c + u) * planev];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float wc = w[c + u];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wc, vget(x[u], j), acc[j]);
+        }
+    }
+    for (; c < C; ++c) {
+        const V x = f[(long long)c * planev];
         const float wc = w[c];
-        ax = fmaf(wc, x.x, ax);
-        ay = fmaf(wc, x.y, ay);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wc, vget(x, j), acc[j]);
     }
     const float bs = bias[0];
-    float2 m;
-    m.x = 1.f / (1.f + expf(-(ax + bs)));                     // MR_ACT_SIGMOID of conv_mfma.hip
-    m.y = 1.f / (1.f + expf(-(ay + bs)));
-    mask[i] = m;
-    if (cv) {                                                 // monorec_model.py:713
-        float2* v = cv + b * D * plane2 + p;
-        const float kx = 1.0f - m.x, ky = 1.0f - m.y;
-#pragma unroll 8
-        for (int d = 0; d < D; ++d) {
-            float2 t = v[d * plane2];
-            t.x = kx * t.x;
-            t.y = ky * t.y;
-            v[d * plane2] = t;
+    V m;
+    float keep[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float mj = 1.f / (1.f + expf(-(acc[j] + bs)));                    // MR_ACT_SIGMOID of conv_mfma.hip
+        vset(m, j, mj);
+        keep[j] = 1.0f - mj;
+    }
+    ((V*)mask_)[i] = m;
+    if (cv_) {                                                                  // monorec_model.py:713
+        V* v = (V*)cv_ + b * D * planev + p;
+        int d = 0;
+        for (; d + 16 <= D; d += 16) {
+            V t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = v[(long long)(d + u) * planev];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) vset(t[u], j, keep[j] * vget(t[u], j));
+                v[(long long)(d + u) * planev] = t[u];
+            }
+        }
+        for (; d < D; ++d) {
+            V t = v[(long long)d * planev];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) vset(t, j, keep[j] * vget(t, j));
+            v[(long long)d * planev] = t;
         }
     }
 }
@@ -225,10 +281,16 @@ extern "C" int mr_mask_classifier_f32(const float* features, const float* weight
                                       void* stream) {
     if (!features || !weight || !bias || !cv_mask || batch < 1 || channels < 1 || plane < 2 || (plane & 1)) return MR_ERR_BAD_ARGUMENT;
     if (cost_volume && num_depths < 1) return MR_ERR_BAD_ARGUMENT;
-    const long long plane2 = plane / 2, total2 = (long long)batch * plane2;
-    const long long blocks = (total2 + 255) / 256;
+    // one pixel per thread while that still leaves the chip short of waves (<= 2 workgroups of 256 per CU), two beyond
+    const int vec = (long long)batch * plane <= 256ll * 256 * 2 ? 1 : 2;
+    const long long planev = plane / vec, totalv = (long long)batch * planev;
+    const long long blocks = (totalv + 255) / 256;
     if (blocks >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(mask_classifier_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float2*)features,
-                       weight, bias, channels, plane2, total2, (float2*)cv_mask, (float2*)cost_volume, num_depths);
+    if (vec == 1)
+        hipLaunchKernelGGL(mask_classifier_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, features, weight, bias,
+                           channels, planev, totalv, cv_mask, cost_volume, num_depths);
+    else
+        hipLaunchKernelGGL(mask_classifier_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, features, weight, bias,
+                           channels, planev, totalv, cv_mask, cost_volume, num_depths);
     return (int)hipGetLastError();
 }

@@ -256,7 +256,7 @@ class MonoRecModel(nn.Module):
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
         # hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
         self._bf16 = 2 if hip_bf16x3 else (1 if hip_bf16 else 0)
-        self._next_slot = 0
+        self._slot_counter = [0]         # mutable on purpose: nn.DataParallel replicas (shallow copies made per forward) share it
         self._plans = {}
         self._graphs = {}
         self._streams = {}
@@ -373,14 +373,18 @@ class MonoRecModel(nn.Module):
         caller's current stream like any PyTorch op and - like the reference's - are tensors the caller OWNS: they stay
         valid whatever is run afterwards (create_pointcloud.py:79-98 keeps `result` of five keyframes and multiplies the
         middle one in place).  `submit()` is the zero-copy interface."""
-        out = self.submit(data_dict).result()
-        with torch.cuda.device(out["keyframe"].device):
-            for k in self._OUTPUT_KEYS:
-                v = out.get(k)
-                if torch.is_tensor(v):
-                    out[k] = v.clone()
-                elif isinstance(v, list):
-                    out[k] = [t.clone() for t in v]
+        # the lock is held until the copies are enqueued: nn.DataParallel replicas of one device (threads sharing the per-device
+        # plans) may land on the same slot, and the next enqueue on a slot overwrites the buffers these copies read - enqueued
+        # under the lock, the copies sit on the caller's stream in front of the event the next forward's launches wait for
+        with self._lock:
+            out = self.submit(data_dict).result()
+            with torch.cuda.device(out["keyframe"].device):
+                for k in self._OUTPUT_KEYS:
+                    v = out.get(k)
+                    if torch.is_tensor(v):
+                        out[k] = v.clone()
+                    elif isinstance(v, list):
+                        out[k] = [t.clone() for t in v]
         if self.pretrain_mode == 2:                           # :723-727, same aliasing as the reference
             out["result"] = out["cv_mask"]
         else:
@@ -508,8 +512,8 @@ class MonoRecModel(nn.Module):
             self._consts[str(device)] = consts
         data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = consts
 
-        slot = self._next_slot
-        self._next_slot = (slot + 1) % self._in_flight
+        slot = self._slot_counter[0]
+        self._slot_counter[0] = (slot + 1) % self._in_flight
         key, plan = self._plan_for(slot, b, h, w, nf, device)
         streams = self._slot_streams(slot, device)
         main, enc, geom = streams["main"], streams["enc"], streams["geom"]

@@ -51,11 +51,8 @@ __device__ __forceinline__ float head_activate(float v, float p0, float p1) {
 // neighbours), wave = a quarter of the channels.  pixel mode (small maps: too few pixels to fill the chip otherwise): lane =
 // (pixel 0..15, channel sub-split 0..3), wave = a quarter again - 16 partial sums per pixel.  The partial sums meet in LDS and
 // are added in a fixed order.  Zero padding = buffer loads with an out-of-range offset (the hardware returns 0).
-#define MR_HEAD_LDS_CHANNELS 512      // heads up to this many channels keep their 9 C weights in LDS (pixel mode)
-
 __global__ __launch_bounds__(256) void depth_heads_kernel(const HeadsArgs a) {
     __shared__ float part[4][64][4];
-    __shared__ float wlds[MR_HEAD_LDS_CHANNELS * 9];
     HeadK h = a.h[0];
 #pragma unroll
     for (int i = 1; i < MR_MAX_HEADS; ++i)
@@ -131,26 +128,18 @@ __global__ __launch_bounds__(256) void depth_heads_kernel(const HeadsArgs a) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             vo[t] = (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (b * C * HW + yy * W + xx) * 4 : -1;
         }
-        // the lanes of a wave work on four different channels: their weights come from LDS (one cooperative copy up front)
-        // instead of nine more per-lane global loads per channel in front of every FMA batch
-        const bool w_in_lds = C <= MR_HEAD_LDS_CHANNELS;
-        if (w_in_lds) {
-            for (int i = threadIdx.x; i < C * 9; i += 256) wlds[i] = h.w[i];
-            __syncthreads();
-        }
+        // (staging the weights in LDS first was measured: slower, 25.1 vs 22.5 us for the four c2 heads - one more round trip
+        // and a barrier in front of a kernel that is one latency chain anyway)
         float acc = 0.f;
 #pragma unroll 4
         for (int c = c_lo; c < c_hi; ++c) {
             const int co = c * HW * 4;
+            const float* wc = h.w + c * 9;
             float xv[9], wv[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) xv[t] = ld1(rs, vo[t] < 0 ? -1 : vo[t] + co, 0);
-            if (w_in_lds) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wv[t] = wlds[c * 9 + t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wv[t] = h.w[c * 9 + t];
+            for (int t = 0; t < 9; ++t) {
+                xv[t] = ld1(rs, vo[t] < 0 ? -1 : vo[t] + co, 0);
+                wv[t] = wc[t];
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc = fmaf(wv[t], xv[t], acc);
@@ -248,8 +237,9 @@ __global__ __launch_bounds__(256) void mask_classifier_kernel(const float* __res
 
 extern "C" int mr_depth_heads_f32(const mr_head_desc* heads, int32_t num_heads, float act_p0, float act_p1, void* stream) {
     if (!heads || num_heads < 1 || num_heads > MR_MAX_HEADS) return MR_ERR_BAD_ARGUMENT;
-    // tuning aid: pixels from which a head runs in quad mode (read once per process)
-    static const long long quad_min = [] { const char* e = getenv("MR_HEADS_QUAD_MIN"); return e ? atoll(e) : 65536ll; }();
+    // pixels from which a head runs in quad mode (MR_HEADS_QUAD_MIN: tuning aid, read once per process).  Measured at the c2 decoder
+    // sizes (2 048 / 8 192 / 32 768 / 131 072 pixels): quad mode wins from 32 768 pixels up, pixel mode below (tools/bench_heads.py)
+    static const long long quad_min = [] { const char* e = getenv("MR_HEADS_QUAD_MIN"); return e ? atoll(e) : 16384ll; }();
     HeadsArgs a;
     a.n = num_heads;
     a.p0 = act_p0;

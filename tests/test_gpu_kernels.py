@@ -524,13 +524,14 @@ def test_cost_volume_properties_at_full_size(hip_lib):
 
 # ---- one-channel layers on their own kernels (csrc/heads.hip) ---------------------------------------------------------------
 HEAD_SETS = [
-    # list of (batch, channels, height, width) launched together; MR_HEADS_QUAD_MIN defaults to 65536 pixels
+    # list of (batch, channels, height, width) launched together; quad mode from 16 384 pixels (MR_HEADS_QUAD_MIN) when W % 4 == 0
     [(1, 256, 8, 12), (1, 128, 16, 24), (1, 64, 32, 48), (1, 24, 64, 96)],           # smoke-sized decoder: all in pixel mode
     [(2, 24, 256, 512)],                                                             # quad mode, rows of 128 quads
-    [(1, 256, 32, 64), (1, 128, 64, 128), (1, 64, 128, 256), (1, 24, 256, 512)],     # the c2 decoder: pixel, pixel, pixel, quad
+    [(1, 256, 32, 64), (1, 128, 64, 128), (1, 64, 128, 256), (1, 24, 256, 512)],     # the c2 decoder: pixel, pixel, quad, quad
     [(3, 7, 5, 6), (1, 19, 160, 412)],                                               # ragged: C % 16 != 0, W % 4 == 0 but odd rows of quads
     [(2, 5, 130, 260)],                                                              # 67 600 pixels, W % 4 == 0: quad mode with a ragged tail
     [(1, 9, 300, 301)],                                                              # W % 4 != 0: stays in pixel mode whatever the size
+    [(1, 3, 100, 164)],                                                              # 16 400 pixels: quad mode just above the threshold, 3 channels on 4 waves
 ]
 
 

@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); only used with --bf16
-NON_CONV_OPS = ("resnet.maxpool", "cost_volume", "mask.max", "apply_mask")
 
 
 def parse():
@@ -487,6 +486,15 @@ def main():
                                                   "inflate each other's kernel durations) / peak", "rocprof_source": kst_src})
         if pmc.get("conv_mfma_util") is not None:
             roof["mfma_util_pmc"] = pmc["conv_mfma_util"]
+        # one-channel layers: every input element read once, every output written once; the classifier launch also scales the D planes
+        hw_ = args.height * args.width
+        aux_s = sum(r["seconds"] for r in rows if r.get("aux_ref_macs"))
+        aux_bytes = 4.0 * sum(r.get("aux_ref_macs", 0) for r in rows if r["name"] == "mask.classifier")
+        aux_bytes += 4.0 * sum(r.get("aux_ref_macs", 0) for r in rows if r["name"] == "depth.heads") / 9.0
+        if any(r["name"] == "mask.classifier" for r in rows):
+            aux_bytes += 4.0 * args.batch * hw_ * (1 + 2 * args.depths)
+        if any(r["name"] == "depth.heads" for r in rows):
+            aux_bytes += 4.0 * args.batch * hw_ * (1 + 1 / 4 + 1 / 16 + 1 / 64)
         result = {
             "metric": "frames/sec (keyframes/s), KITTI 256x512 2-src/32-bin cost-volume inference",
             "value": total_keyframes / elapsed,
@@ -514,7 +522,12 @@ def main():
                                               "not part of the MFMA roofline above",
                                    "launches": [r["name"] for r in rows if r.get("aux_ref_macs")],
                                    "algorithmic_gflop_per_step": 2.0 * sum(r.get("aux_ref_macs", 0) for r in rows) / 1e9,
-                                   "us_per_step": sum(r["seconds"] for r in rows if r.get("aux_ref_macs")) * 1e6},
+                                   "algorithmic_MB_per_step": aux_bytes / 1e6,
+                                   "us_per_step": aux_s * 1e6,
+                                   "achieved_GBps": (aux_bytes / aux_s / 1e9) if aux_s > 0 else None, "peak_GBps": 8000.0,
+                                   "hbm_frac": (aux_bytes / aux_s / 8e12) if aux_s > 0 else None,
+                                   "note": "bytes = inputs once + outputs once (+ the cost volume read and written by the mask multiply); "
+                                           "at batch 1 both launches are latency chains (launch floor ~6 us each), not bandwidth"},
             "device_ms_per_step_sum_of_kernels": sum(r["seconds"] for r in rows) * 1e3,
         }
         if args.dump_layers:

@@ -119,7 +119,7 @@ def main():
             d["wait_any_frac_of_wave_cycles"] = conv["SQ_WAIT_ANY"] / conv["SQ_WAVE_CYCLES"]
         if "SQ_LDS_BANK_CONFLICT" in conv:
             d["lds_bank_conflict_cycles"] = conv["SQ_LDS_BANK_CONFLICT"]
-        for fam in ("cv_sad", "cv_fuse"):
+        for fam in ("cv_sad", "cv_fuse", "depth_heads", "mask_classifier"):
             m = family_metrics(agg, fam)
             if m:
                 derived[fam + "_kernels"] = m

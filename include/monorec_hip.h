@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 6
+#define MR_ABI_VERSION 5
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -138,16 +138,7 @@ typedef struct mr_conv_desc {
      * through LDS in a fixed order.  waves_per_wg times more workgroups for layers with few output pixels, without the workspace
      * round trip and the finishing launch of split_k (which must be 1 here; MR_COMPUTE_F32, LDS-DMA staged inputs only). */
     int32_t k_split_waves;
-    /* split_k > 1 only: arrival counters for finishing the split INSIDE the launch - one int32 per output tile of the launch
-     * (mr_conv2d_splitk_counters() of them), zero before the first launch; every launch leaves them zero again.  The last of
-     * the split_k workgroups of a tile sums the slices (in slice order, deterministic) and runs the epilogue: no second launch.
-     * NULL: the partial sums are finished by a separate small launch (the behaviour before ABI 6). */
-    int32_t* split_k_counters;
 } mr_conv_desc;
-
-/* number of int32 arrival counters a launch with this descriptor needs in `split_k_counters` (0 for split_k == 1), or a negative
- * MR_ERR_* code */
-int64_t mr_conv2d_splitk_counters(const mr_conv_desc* desc);
 
 /* number of floats of the packed weight image for a conv with the given source split and schedule
  * (cout_blocks_per_wg, chunk_channels must equal the values later put into mr_conv_desc) */

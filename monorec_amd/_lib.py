@@ -54,7 +54,6 @@ class ConvDesc(ctypes.Structure):
         ("compute_dtype", ctypes.c_int32),
         ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
         ("k_split_waves", ctypes.c_int32),
-        ("split_k_counters", ctypes.c_void_p),
     ]
 
 
@@ -85,7 +84,6 @@ ABI = {
                                                  ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv2d_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(ConvDesc)]),
     "mr_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
-    "mr_conv2d_splitk_counters": (ctypes.c_int64, [ctypes.POINTER(ConvDesc)]),
     "mr_cost_volume_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -171,7 +169,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 6:
+    if lib.mr_abi_version() != 5:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -77,7 +77,6 @@ struct ConvKArgs {
     long long wgroup_stride[4];   // packed floats per cout group, per phase
     int KHp[4], KWp[4];        // taps swept by each phase (<= KH, KW; the common KH / KW size the input tile)
     float* ws;
-    int* kcnt;                 // split-K arrival counters (one per output tile, zero between launches): KFIN instantiation, else null
     const float* w[4];         // per phase
     int PT[4], PL[4], ooff_h[4], ooff_w[4];
 };
@@ -489,7 +488,7 @@ __device__ __forceinline__ void sweep_chunk_bf16x3(const ConvKArgs& a, f32x4 (&a
 // DMA_IN: input tile staged by LDS-DMA (direct / upsample reads).  false: register-staged variant for the 2x2
 // max-pool and input-normalisation reads (kept out of the DMA kernel: the compiler-visible loads of that path
 // make hipcc drain vmcnt before every sweep and spill SGPRs).
-template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false, bool KFIN = false>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false>
 __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     dbg_stamp(a, 0);
@@ -520,12 +519,8 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     int z = blockIdx.z;                                                // ((b * ksplit) + ks) * nphase + ph
     const int ph = a.nphase == 4 ? (z & 3) : 0;
     z = a.nphase == 4 ? z >> 2 : z;
-    int ks = a.ks_shift >= 0 ? (z & (a.ksplit - 1)) : z % a.ksplit;
-    int b = a.ks_shift >= 0 ? (z >> a.ks_shift) : z / a.ksplit;
-    if (KFIN) {   // the division runs on the VALU; in this instantiation the compiler otherwise keeps b - and the DMA soffsets derived from
-        ks = __builtin_amdgcn_readfirstlane(ks);      // it, which the inline asm needs in SGPRs - in VGPRs
-        b = __builtin_amdgcn_readfirstlane(b);
-    }
+    const int ks = a.ks_shift >= 0 ? (z & (a.ksplit - 1)) : z % a.ksplit;
+    const int b = a.ks_shift >= 0 ? (z >> a.ks_shift) : z / a.ksplit;
     const int oy0 = ty * a.TH, ox0 = tx * a.TWB * 16;
     const int iy_base = oy0 * a.SH - a.PT[ph], ix_base = ox0 * a.SW - a.PL[ph];
     const int HsWs = a.Hs * a.Ws;
@@ -655,7 +650,7 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     }
     if (MR_DBG(8)) { if (acc[0][0][0] != 123.456f) return; }
     const int lq4 = (lane >> 4) * 4;
-    if (!KFIN && a.ksplit > 1) {                       // raw partial sums; splitk_epilogue_kernel finishes them
+    if (a.ksplit > 1) {                                // raw partial sums; splitk_epilogue_kernel finishes them
         const long long plane = (long long)a.Ho * a.Wo;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -671,56 +666,6 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
             }
         }
         return;
-    }
-    if (KFIN) {
-        // split_k finished INSIDE the launch (its own instantiation, so that the other launches keep their register allocation): the
-        // LAST of the ksplit workgroups of a tile to arrive sums all slices - in slice order, deterministic - and runs the epilogue.
-        // No fence anywhere: the partial sums travel as agent-scope atomic stores / loads (sc1: written through to / read from the
-        // point all XCDs agree on), so neither side needs the L2 write-back / invalidate of a release / acquire fence - those cost
-        // ~20 us per layer when every workgroup issues them (measured, round 1).  The arrival counter is an agent-scope atomic add
-        // issued after this workgroup's stores have completed (vmcnt(0) + barrier); the last arrival leaves it at zero again.
-        const long long plane = (long long)a.Ho * a.Wo;
-        const long long slice = (long long)a.nphase * a.batch * CB16 * plane;        // floats per K slice
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int cout0 = (cb0 + m) * 16 + lq4;
-            if (cout0 >= CB16) continue;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
-                if (oy >= a.Ho || ox >= a.Wo) continue;
-                float* w = a.ws + ks * slice + (((long long)ph * a.batch + b) * CB16 + cout0) * plane + (long long)oy * a.Wo + ox;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) __hip_atomic_store(w + r * plane, acc[m][i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            int* cnt = a.kcnt + (((b * a.nphase + ph) * (int)gridDim.y + grp) * (int)gridDim.x + tile);
-            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == a.ksplit - 1 ? 1 : 0;
-            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ((volatile int*)lds)[0] = last;
-        }
-        __syncthreads();
-        if (!((volatile int*)lds)[0]) return;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int cout0 = (cb0 + m) * 16 + lq4;
-            if (cout0 >= CB16) continue;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
-                if (oy >= a.Ho || ox >= a.Wo) continue;
-                const float* w = a.ws + (((long long)ph * a.batch + b) * CB16 + cout0) * plane + (long long)oy * a.Wo + ox;
-                f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int k2 = 0; k2 < a.ksplit; ++k2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sum[r] += __hip_atomic_load(w + k2 * slice + r * plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc[m][i] = sum;
-            }
-        }
     }
     {
         // bias / residual operands are fetched in batches ahead of the stores that need them: a load issued
@@ -915,7 +860,6 @@ int derive(const mr_conv_desc* d, Derived* out) {
         plane = k.IH * k.IW; if (k.SW == 1) { while ((plane & 31) != 16) ++plane; } else { plane |= 1; }
         k.PLANE = plane; k.ppt = mr_ceil_div(k.IH * k.IW, 256); if (k.ppt > MR_MAX_PPT) return MR_ERR_UNSUPPORTED; }
     k.ksplit = d->split_k; k.nchunks = nchunks; k.batch = d->batch; k.ws = d->workspace;
-    k.kcnt = nullptr;          // set below once the staging path is known
     const int taps = k.KH * k.KW;
     for (int p = 0; p < nphase; ++p) k.wgroup_stride[p] = (long long)k.KHp[p] * k.KWp[p] * cpad_total * mb * (bf16 == 1 ? 8 : 16);
     int ck_max = 0;                                              // largest chunk of any source
@@ -934,8 +878,6 @@ int derive(const mr_conv_desc* d, Derived* out) {
     if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
     { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     out->mb = mb; out->nb = nb; out->wv = wv;
-    // in-launch finish: fp32 launches on the LDS-DMA staging path (the instantiations that exist); anything else keeps the finishing launch
-    if (d->split_k > 1 && d->split_k_counters && !bf16 && !kws && k.dma_in) k.kcnt = d->split_k_counters;
     if (wv == 8 && !k.dma_x4) return MR_ERR_UNSUPPORTED;
     if (kws && !k.dma_in) return MR_ERR_UNSUPPORTED;
     if (bf16 && !k.dma_in) return MR_ERR_UNSUPPORTED;                 // bf16 mode: LDS-DMA staged inputs only
@@ -948,7 +890,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     return 0;
 }
 
-template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false, bool KFIN = false>
+template <int MB, int NB, bool DMA_IN, int WV, int BF16, bool KWS = false>
 int launch(const Derived& dv, hipStream_t stream) {
     // raise the dynamic-LDS ceiling once per instantiation AND device (the attribute lives in the device's code object:
     // a process that drives several GPUs - nn.DataParallel replicas - must set it on each)
@@ -957,12 +899,12 @@ int launch(const Derived& dv, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS, KFIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS, KFIN>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<MB, NB, DMA_IN, WV, BF16, KWS>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
@@ -979,10 +921,6 @@ int launch_variant(const Derived& dv, hipStream_t stream) {
     if (dv.k.kws) {                                    // K split across the waves: LDS-DMA staged fp32 launches only (derive() checked)
         if (dv.wv == 8) return launch<MB, NB, true, 8, 0, true>(dv, stream);
         return launch<MB, NB, true, 4, 0, true>(dv, stream);
-    }
-    if (dv.k.kcnt) {                                   // split_k finished inside the launch (derive(): fp32, LDS-DMA staging)
-        if (dv.wv == 8) return launch<MB, NB, true, 8, 0, false, true>(dv, stream);
-        return launch<MB, NB, true, 4, 0, false, true>(dv, stream);
     }
     if (dv.wv == 8) return launch<MB, NB, true, 8, 0>(dv, stream);         // dwordx4 DMA path only (derive() checked)
     if (dv.k.dma_in) return launch<MB, NB, true, 4, 0>(dv, stream);
@@ -1149,14 +1087,6 @@ extern "C" int64_t mr_conv2d_lds_bytes(const mr_conv_desc* desc) {
     return (int64_t)dv.lds_bytes;
 }
 
-extern "C" int64_t mr_conv2d_splitk_counters(const mr_conv_desc* desc) {
-    Derived dv;
-    const int rc = derive(desc, &dv);
-    if (rc != 0) return rc;
-    if (dv.k.ksplit <= 1) return 0;
-    return (int64_t)dv.grid.x * dv.grid.y * (dv.grid.z / dv.k.ksplit);
-}
-
 extern "C" int mr_conv2d_f32(const mr_conv_desc* desc, void* stream_) {
     Derived dv;
     int rc = derive(desc, &dv);
@@ -1171,7 +1101,7 @@ extern "C" int mr_conv2d_f32(const mr_conv_desc* desc, void* stream_) {
         default: rc = launch_nb<6>(dv, stream); break;
     }
     if (rc != 0) return rc;
-    if (dv.k.ksplit > 1 && !dv.k.kcnt) {
+    if (dv.k.ksplit > 1) {
         const long long total = (long long)dv.k.nphase * dv.k.batch * dv.k.Cout * dv.k.Ho * dv.k.Wo;
         const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, dv.k);

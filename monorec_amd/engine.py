@@ -273,11 +273,6 @@ class Plan:
             import os
             one_channel_kernels = os.environ.get("MR_ONE_CHANNEL_KERNELS", "1") != "0"
         self.one_channel_kernels = bool(one_channel_kernels)
-        import os as _os
-        # split-K layers finish inside their launch (arrival counters, no finishing launch); MR_SPLITK_INLINE=0: A/B aid
-        self.splitk_inline = _os.environ.get("MR_SPLITK_INLINE", "1") != "0"
-        self._cnt_ints = {}       # stage -> int32 arrival counters the largest split-K launch of the stage needs
-        self._pending_cnt = []
         self.input_ptr = {}       # "keyframe" -> device pointer the launches read the keyframe from (resident copy or the caller's tensor)
         self._input_srcs = []     # (ConvDesc, source index, "keyframe"): descriptor slots that follow input_ptr
         self._frame_ptrs = None   # ctypes array of the F source-frame pointers handed to the cost-volume launch
@@ -298,14 +293,8 @@ class Plan:
             self.buf[f"splitk_workspace.{stage}"] = torch.empty(max(floats, 4), dtype=torch.float32, device=self.device)
         for stage, desc in self._pending_ws:
             desc.workspace = self.buf[f"splitk_workspace.{stage}"].data_ptr()
-        for stage, ints in self._cnt_ints.items():      # zero once; every launch leaves its counters at zero again
-            self.buf[f"splitk_counters.{stage}"] = torch.zeros(max(ints, 1), dtype=torch.int32, device=self.device)
-        for stage, desc in self._pending_cnt:
-            desc.split_k_counters = self.buf[f"splitk_counters.{stage}"].data_ptr()
         self._pending_ws = []
-        self._pending_cnt = []
         self._ws_floats = {}
-        self._cnt_ints = {}
 
     # ------------------------------------------------------------------ buffers / parameters
     def alloc(self, name, *shape):
@@ -387,12 +376,6 @@ class Plan:
                                          split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
             self._pending_ws.append((stage, d))
             d.workspace = 1  # placeholder (non-null) until the shared workspace exists
-            if self.splitk_inline:
-                ncnt = int(self.lib.mr_conv2d_splitk_counters(ctypes.byref(d)))
-                if ncnt < 0:
-                    _lib.check(ncnt, f"plan {name} sched={sched}")
-                self._cnt_ints[stage] = max(self._cnt_ints.get(stage, 0), ncnt)
-                self._pending_cnt.append((stage, d))
         lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} sched={sched}")

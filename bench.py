@@ -131,7 +131,7 @@ def committed_kernel_stats(cfg):
         forwards = 0
         for r in list(csv.reader(open(path)))[1:]:
             name, calls, total = r[0], int(r[1]), float(r[2])
-            if "conv_mfma_kernel" in name:
+            if "conv_mfma_kernel" in name or "conv3x3_wino_kernel" in name:
                 conv_us += total
                 conv_n += calls
             elif "splitk_epilogue_kernel" in name:
@@ -468,15 +468,18 @@ def main():
                              "valu_frac_note": "SQ_INSTS_VALU x 64 lanes / sad-kernel time / 78.6e12 lane-instr/s", "counters_source": pmc_src})
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
+        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd"))
         roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
-                ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4_f32)"),
+                ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
+                 f"conv_mfma_kernel (direct) + conv3x3_wino_kernel (Winograd F(2x2,3x3), {n_wino} of the launches); both fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": pmc.get("conv_hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
                 "traffic_source": pmc_src, "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
                 "avg_launch_us_note": "HIP events around each layer: kernel + dispatch gap (+ split-K finishing kernel)",
                 "algorithmic_gflop_per_step": conv_flops / 1e9, "executed_gflop_per_step": conv_flops_executed / 1e9,
                 "algorithmic_note": "the reference's Conv2d / ConvTranspose2d MACs x 2 (SURVEY 8d); executed is lower where Upconv runs "
-                                    "phase-decomposed on the low-resolution input (9 of 16 taps)",
+                                    "phase-decomposed on the low-resolution input (9 of 16 taps) and where a 3x3 convolution runs as Winograd "
+                                    "F(2x2,3x3) (16 of 36 multiplies)",
                 "conv_ms_per_step": conv_s * 1e3}
         if kst:
             roof.update({"rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,

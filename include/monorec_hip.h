@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 5
+#define MR_ABI_VERSION 6
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -175,6 +175,35 @@ int64_t mr_conv2d_lds_bytes(const mr_conv_desc* desc);
 
 /* launch (replaces the reference lines listed above mr_conv_desc) */
 int mr_conv2d_f32(const mr_conv_desc* desc, void* stream);
+
+/*
+ * 3x3, stride 1, zero padding 1 convolution (PadSameConv2d(3) + nn.Conv2d(3): every ConvReLU of the MaskModule,
+ * model/monorec/monorec_model.py:296-343, model/layers.py:317-335; the 3x3 stride-1 convolutions of the ResNet trunk) as Winograd
+ * F(2x2, 3x3) on the fp32 matrix cores: 16 multiplies per (input channel, output channel) and 2x2 output tile instead of 36.
+ * Same conventions as mr_conv2d_f32: up to MR_MAX_SOURCES sources concatenated on channels and read in place, dense NCHW fp32,
+ * bias / residual / activation (MR_ACT_NONE, MR_ACT_RELU, MR_ACT_LEAKY_RELU) in the epilogue, dst = (batch, out_channels, height,
+ * width).  width % 4 == 0.  Results differ from the direct convolution by the rounding of the transforms (~1e-6 relative).
+ */
+typedef struct mr_wino_desc {
+    const float* src[MR_MAX_SOURCES];
+    int32_t src_channels[MR_MAX_SOURCES];
+    int32_t num_src;
+    int32_t batch, height, width;
+    float* dst;
+    int32_t out_channels;
+    const float* packed_weights;     /* from mr_wino_pack_weights_f32 with the same cout_blocks_per_wave (device copy) */
+    const float* bias;               /* out_channels floats or NULL */
+    const float* residual;           /* same shape as dst or NULL */
+    int32_t activation;
+    float act_p0;
+    int32_t cout_blocks_per_wave;    /* 1 or 2: a workgroup (8 waves, 8 x 32 output pixels) produces 32 or 64 output channels */
+} mr_wino_desc;
+size_t mr_wino_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
+/* weight: (out_channels, sum(src_channels), 3, 3) fp32 host memory; the transformed filters G g G^T are formed in double */
+int mr_wino_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                             int32_t cout_blocks_per_wave, float* dst);
+int64_t mr_conv3x3_winograd_lds_bytes(const mr_wino_desc* desc);   /* dynamic LDS of the launch, or a negative MR_ERR_* code */
+int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
 
 /*
  * Fused plane-sweep cost volume.  Replaces CostVolumeModule.forward per-pixel work,

@@ -57,6 +57,15 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class WinoDesc(ctypes.Structure):
+    """mirror of `mr_wino_desc` (include/monorec_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p * MR_MAX_SOURCES), ("src_channels", ctypes.c_int32 * MR_MAX_SOURCES), ("num_src", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("dst", ctypes.c_void_p), ("out_channels", ctypes.c_int32),
+                ("packed_weights", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+                ("activation", ctypes.c_int32), ("act_p0", ctypes.c_float), ("cout_blocks_per_wave", ctypes.c_int32)]
+
+
 class HeadDesc(ctypes.Structure):
     """mirror of `mr_head_desc` (include/monorec_hip.h)."""
     _fields_ = [("src", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("dst", ctypes.c_void_p),
@@ -84,6 +93,11 @@ ABI = {
                                                  ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv2d_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(ConvDesc)]),
     "mr_conv2d_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "mr_wino_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32]),
+    "mr_wino_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv3x3_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_conv3x3_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_cost_volume_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -169,7 +183,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 5:
+    if lib.mr_abi_version() != 6:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

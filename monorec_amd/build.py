@@ -24,6 +24,7 @@ SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("eltwise.hip", []),
     ("heads.hip", []),
+    ("conv_wino.hip", []),
 ]
 
 

@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_ABS_TANH_AFFINE, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, IN_DIRECT, IN_MAXPOOL2,
-                   IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM, ConvDesc, HeadDesc)
+                   IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM, ConvDesc, HeadDesc, WinoDesc)
 
 LEAKY_SLOPE = 0.1   # model/layers.py:290,318,381
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, used by torchvision's ResNet
@@ -148,6 +148,41 @@ def _load_tuned():
 
 _load_tuned()
 
+WINOGRAD = {}       # signature (without the phase / mode suffixes) -> 0 (direct kernel), 1 or 2 (cout blocks per wave); measured
+
+
+def _load_winograd():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_winograd.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            WINOGRAD.update({k: int(v) for k, v in json.load(f).items()})
+
+
+_load_winograd()
+
+
+def winograd_signature(cout, src_channels, h, w, batch):
+    return f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_o{h}x{w}_b{batch}"
+
+
+def choose_winograd(cout, src_channels, h, w, batch):
+    """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
+    for a 3x3 stride-1 convolution.  The measured table (tools/bench_wino.py --write-table, MI355X) wins; shapes it does not know
+    go to the Winograd kernel when it has enough workgroups (8 x 32 output pixels each) to fill the chip - below that the direct
+    kernel's smaller tiles and split-K win (measured: every ResNet layer of a batch-1 keyframe)."""
+    if w % 4:
+        return 0
+    sig = winograd_signature(cout, src_channels, h, w, batch)
+    if sig in WINOGRAD:
+        return WINOGRAD[sig]
+    tiles = math.ceil(h / 8) * math.ceil(w / 32) * batch
+    if tiles * math.ceil(cout / 32) < 256:
+        return 0
+    return 2 if (cout > 32 and tiles * math.ceil(cout / 64) >= 256) else 1
+
+
 
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
     """`mixed_phases`: the phases sweep different tap counts (phase-decomposed Upconv: 1, 2, 2 and 4 taps of a 2x2 tile)."""
@@ -243,7 +278,7 @@ class Plan:
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
                  pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3,
-                 one_channel_kernels=None):
+                 one_channel_kernels=None, winograd=None):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -273,6 +308,9 @@ class Plan:
             import os
             one_channel_kernels = os.environ.get("MR_ONE_CHANNEL_KERNELS", "1") != "0"
         self.one_channel_kernels = bool(one_channel_kernels)
+        import os as _os
+        # 3x3 stride-1 convolutions on the Winograd F(2x2,3x3) kernel where it is faster (choose_winograd); MR_WINOGRAD=0: A/B aid
+        self.winograd = _os.environ.get("MR_WINOGRAD", "1") != "0" if winograd is None else bool(winograd)
         self.input_ptr = {}       # "keyframe" -> device pointer the launches read the keyframe from (resident copy or the caller's tensor)
         self._input_srcs = []     # (ConvDesc, source index, "keyframe"): descriptor slots that follow input_ptr
         self._frame_ptrs = None   # ctypes array of the F source-frame pointers handed to the cost-volume launch
@@ -326,6 +364,13 @@ class Plan:
             assert s.shape[0] == n and s.shape[2] == hs and s.shape[3] == ws and s.is_contiguous()
         w0 = weight if phases is None else phases[0][0]
         cout, cin, kh, kw = w0.shape
+        if (self.winograd and phases is None and (kh, kw) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and
+                in_mode == IN_DIRECT and tf == TF_NONE and tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0) and out_ch_offset == 0 and
+                out.shape[1] == cout and tuple(grid) == (hs, ws) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY_RELU) and self.bf16 == 0 and
+                name not in self.schedule_override):
+            mbw = choose_winograd(cout, src_channels, hs, ws, n)
+            if mbw:
+                return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw)
         if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
             kh, kw = max(p[0].shape[2] for p in phases), max(p[0].shape[3] for p in phases)
         mixed = phases is not None and any(tuple(p[0].shape[2:]) != (kh, kw) for p in phases)
@@ -394,6 +439,49 @@ class Plan:
                                                                                 for wp, pt, pl, oh, ow in phases])))
         self.keep += [d, out, residual] + list(srcs)      # the descriptor only holds raw pointers
         self.stages[stage].append((name, self._launch_conv(d, name)))
+        return out
+
+    def _conv_winograd(self, stage, name, srcs, weight, bias, out, act, p0, residual, mbw):
+        """One mr_conv3x3_winograd_f32 launch (csrc/conv_wino.hip) in place of a 3x3 stride-1 mr_conv2d_f32 launch."""
+        lib = self.lib
+        n, _, hs, ws = srcs[0].shape
+        src_channels = [int(s.shape[1]) for s in srcs]
+        cout, cin = int(weight.shape[0]), int(weight.shape[1])
+        sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
+        w = weight.detach().to(torch.float32).contiguous().cpu()
+        nfl = lib.mr_wino_packed_weight_floats(cout, sc, len(src_channels), mbw)
+        packed = torch.empty(nfl, dtype=torch.float32)
+        _lib.check(lib.mr_wino_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino_pack_weights_f32")
+        d = WinoDesc()
+        for i, s_ in enumerate(srcs):
+            d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
+            if "keyframe" in self.buf and s_ is self.buf["keyframe"]:
+                self._input_srcs.append((d, i, "keyframe"))
+        d.num_src, d.batch, d.height, d.width = len(srcs), n, hs, ws
+        d.dst, d.out_channels = out.data_ptr(), cout
+        assert out.is_contiguous() and tuple(out.shape) == (n, cout, hs, ws)
+        d.packed_weights = self._dev(packed).data_ptr()
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        if residual is not None:
+            assert residual.shape == out.shape
+            d.residual = residual.data_ptr()
+        d.activation, d.act_p0, d.cout_blocks_per_wave = act, p0, mbw
+        lds = lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d))
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name} winograd")
+        ref = n * hs * ws * cout * cin * 9
+        wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (32 * mbw))
+        self.conv_log.append(dict(name=name, macs=ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+                                  cout=cout, cin=cin, k=(3, 3), out=(hs, ws), batch=n, phases=1, winograd=mbw, bf16=0,
+                                  sig=winograd_signature(cout, src_channels, hs, ws, n),
+                                  spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 3, 3), stride=(1, 1), pad=(1, 1),
+                                            grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=act, p0=p0, p1=0.0, residual=residual is not None,
+                                            out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
+        self.keep += [d, out, residual] + list(srcs)
+
+        def run(stream):
+            _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), name)
+        self.stages[stage].append((name, run))
         return out
 
     def same_conv(self, stage, name, srcs, wkey, bkey, out, *, stride=(1, 1), act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert getattr(hip_lib, name) is not None
-    assert hip_lib.mr_abi_version() == 5
+    assert hip_lib.mr_abi_version() == 6
     assert b"LDS" in hip_lib.mr_error_string(-3)
 
 
@@ -244,14 +244,22 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     aux = sum(a["ref_macs"] for a in plan.aux_log)
     assert [a["name"] for a in plan.aux_log] == ["mask.classifier", "depth.heads"] and abs(aux / 1e9 - 0.068) < 0.001
     assert abs((plan.conv_ref_macs() + aux) / 1e9 - 61.07) < 0.01
-    # executed: the four mask-decoder Upconv layers (3.934 GMAC in the reference) run phase-decomposed at 9/16 of their taps
-    assert abs((plan.conv_macs() + aux) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
+    # executed: the four mask-decoder Upconv layers (3.934 GMAC in the reference) run phase-decomposed at 9/16 of their taps, and the
+    # 3x3 layers the measured table sends to the Winograd kernel (csrc/conv_wino.hip) at 16/36 of their multiplies
+    wino = [c for c in plan.conv_log if c.get("winograd")]
+    assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
+                                         "mask.dec3.2", "depth.dec4.2"}
+    assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
+    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino)
+    assert abs((plan.conv_macs() + aux + wino_saved) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
+    direct = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)               # A/B aid: every 3x3 layer on the direct kernel
+    assert not any(c.get("winograd") for c in direct.conv_log) and abs((direct.conv_macs() + aux) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
     assert [n for n, _ in plan.stages["main"]][-1] == "depth.heads" and "apply_mask" not in [n for n, _ in plan.stages["main"]]
     legacy = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", one_channel_kernels=False)       # A/B aid: everything on mr_conv2d_f32
     assert abs(legacy.conv_ref_macs() / 1e9 - 61.07) < 0.01 and not legacy.aux_log and "apply_mask" in [n for n, _ in legacy.stages["main"]]
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
-               for c in plan.conv_log)
+               for c in plan.conv_log if not c.get("winograd"))
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 

@@ -597,3 +597,66 @@ def test_mask_classifier_kernel_matches_torch(shape, with_cv):
     else:
         assert torch.equal(cvd.cpu(), cv)
     assert lib.mr_mask_classifier_f32(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), b, c, 7, mask.data_ptr(), None, d, _stream()) == -1   # odd plane
+
+
+# ---- Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) -------------------------------------------------------------------------
+WINO_CASES = [
+    # (srcs_c, cout, (H, W), batch, act, residual, mbw)
+    ((32,), 32, (64, 96), 2, ACT_LEAKY_RELU, False, 1),
+    ((32,), 48, (40, 64), 1, ACT_LEAKY_RELU, False, 2),
+    ((48, 64, 96), 64, (24, 32), 1, ACT_LEAKY_RELU, False, 1),        # three concatenated sources (mask.dec2.1)
+    ((32, 64), 48, (32, 64), 2, ACT_LEAKY_RELU, False, 2),
+    ((64,), 64, (16, 24), 1, ACT_RELU, True, 1),                      # ResNet BasicBlock conv2: residual, ReLU; W % 32 != 0
+    ((5, 11), 40, (13, 20), 3, ACT_NONE, False, 2),                   # ragged everything: C % 8 != 0, H % 8 != 0, W % 32 != 0, cout % 32 != 0
+    ((3,), 7, (9, 4), 1, ACT_NONE, False, 1),                         # tiny
+    ((96,), 96, (32, 64), 2, ACT_LEAKY_RELU, False, 2),               # two cout groups of 64 (second half empty)
+]
+
+
+@pytest.mark.parametrize("case", range(len(WINO_CASES)))
+def test_winograd_conv_matches_torch_fp32(hip_lib, case):
+    """mr_conv3x3_winograd_f32 against F.conv2d(padding=1) on the CPU: the transforms round differently from the direct sum, so the
+    bar is a few 1e-6 of the output scale - far inside the 1e-4 of the path."""
+    srcs_c, cout, (h, w), batch, act, residual, mbw = WINO_CASES[case]
+    lib = hip_lib
+    g = torch.Generator().manual_seed(100 + case)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * math.sqrt(cin)))
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(batch, cout, h, w, generator=g) if residual else None
+    ref = F.conv2d(torch.cat(srcs, 1), wt, bias, padding=1)
+    if residual:
+        ref = ref + res
+    ref = _act_ref(ref, act, 0.1, 0.0)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_wino_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+    packed = torch.empty(n)
+    _lib.check(lib.mr_wino_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s.to(DEV) for s in srcs]
+    for i, s in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, h, w), float("nan"), device=DEV)
+    pk, bs, rs = packed.to(DEV), bias.to(DEV), (res.to(DEV) if residual else None)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), (rs.data_ptr() if residual else None)
+    d.activation, d.act_p0, d.cout_blocks_per_wave = act, 0.1, mbw
+    assert lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d)) <= 160 * 1024
+    _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()), "mr_conv3x3_winograd_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_winograd_bad_arguments(hip_lib):
+    d = _lib.WinoDesc()
+    assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1
+    x = torch.zeros(1, 8, 8, 6, device=DEV)
+    d.src[0], d.src_channels[0], d.num_src, d.batch, d.height, d.width = x.data_ptr(), 8, 1, 1, 8, 6
+    d.dst, d.out_channels, d.packed_weights, d.cout_blocks_per_wave = x.data_ptr(), 8, x.data_ptr(), 1
+    assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -2          # width % 4 != 0
+    d.width, d.cout_blocks_per_wave = 8, 3
+    assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1

@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from monorec_amd.model import MonoRecModel
     from tools.tune_conv import build_candidate, time_op
     m = MonoRecModel(cv_depth_steps=32); sd = synth.seeded_state_dict(m.state_dict())
-    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)
     g = torch.Generator().manual_seed(0)
     names = sys.argv[2].split(",")
     res = {}

@@ -28,7 +28,7 @@ def main():
     names = (sys.argv[1] if len(sys.argv) > 1 else DEFAULT).split(",")
     m = MonoRecModel(cv_depth_steps=32)
     sd = synth.seeded_state_dict(m.state_dict())
-    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)
     g = torch.Generator().manual_seed(0)
     rows = {}
     for c in plan.conv_log:

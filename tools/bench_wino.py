@@ -64,11 +64,12 @@ def main():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--emit", default=None, help="write {signature: 0 | 1 | 2} (fastest kernel per layer; Winograd must win by 3 %%) to this JSON file")
     a = ap.parse_args()
     lib = _lib.load()
     m = MonoRecModel(cv_depth_steps=a.depths)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
-    ref_plan = engine.Plan(sd, a.batch, a.height, a.width, a.frames, a.depths, (0.33, 0.0025), "cpu")
+    ref_plan = engine.Plan(sd, a.batch, a.height, a.width, a.frames, a.depths, (0.33, 0.0025), "cpu", winograd=False)
     g = torch.Generator().manual_seed(0)
     rows = []
     for c in ref_plan.conv_log:
@@ -83,6 +84,7 @@ def main():
         bias = torch.randn(cout, generator=g) * 0.1
         res = torch.randn(*sp["out_shape"], generator=g).to(DEV) if sp["residual"] else None
         plan = engine.Plan.bare(DEV)
+        plan.winograd = False                                             # the direct kernel, whatever the measured table says
         out_d = torch.empty(*sp["out_shape"], device=DEV)
         plan.conv("main", c["name"], srcs, w, bias, out_d, stride=(1, 1), pad=(1, 1), grid=sp["grid"], act=sp["act"], p0=sp["p0"], residual=res)
         plan.finalize()
@@ -99,8 +101,18 @@ def main():
             torch.cuda.synchronize()
             row[f"wino{mbw}_maxdiff"] = float((out_w - out_d).abs().max())
             row[f"wino{mbw}_us"] = round(timed(fn), 1)
+        best, tb = 0, row["direct_us"]
+        for mbw in (1, 2):
+            if f"wino{mbw}_us" in row and row[f"wino{mbw}_us"] < 0.97 * tb:
+                best, tb = mbw, row[f"wino{mbw}_us"]
+        row["sig"] = engine.winograd_signature(cout, [s_[1] for s_ in sp["src_shapes"]], sp["grid"][0], sp["grid"][1], sp["out_shape"][0])
+        row["best"] = best
         rows.append(row)
         print(json.dumps(row), flush=True)
+    if a.emit:
+        os.makedirs(os.path.dirname(os.path.abspath(a.emit)), exist_ok=True)
+        with open(a.emit, "w") as f:
+            json.dump({r["sig"]: r["best"] for r in rows}, f, indent=0, sort_keys=True)
     tot_d = sum(r["direct_us"] for r in rows)
     tot_w = sum(min(r["direct_us"], r.get("wino1_us", 1e9), r.get("wino2_us", 1e9)) for r in rows)
     print(json.dumps({"layers": len(rows), "direct_total_us": round(tot_d, 1), "best_of_both_total_us": round(tot_w, 1)}))

@@ -569,3 +569,55 @@ def test_forward_returns_owned_outputs_with_the_reference_aliasing():
     assert out["result"].data_ptr() != kf.data_ptr() and out["cost_volume"].data_ptr() != kf.data_ptr()
     kf.add_(100.0)                                              # the "resident buffer" changes: owned outputs do not
     assert float(out["result"][0, 0, 0, 1]) == 2.0 and float(out["cv_mask"][0, 0, 0, 0]) == float(8 * 16 + 1)
+
+
+def test_winograd_weight_packing_and_algebra(hip_lib):
+    """mr_wino_pack_weights_f32: U = G g G^T (formed in double, rounded once) in the stream order the kernel reads -
+    [cout group][chunk of 8 channels, source-major][position 4a + b][channel quad][cout block][64 lanes], lane = (cout l & 15, channel
+    l >> 4) - padded channels / couts zero; and the F(2x2,3x3) identity Y = A^T [(G g G^T) o (B^T d B)] A == correlation, in numpy."""
+    import numpy as np
+    g = torch.Generator().manual_seed(0)
+    cout, srcs = 40, [5, 11]
+    w = torch.randn(cout, sum(srcs), 3, 3, generator=g)
+    arr = (ctypes.c_int32 * 2)(*srcs)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    U = np.einsum("ai,ocij,bj->ocab", G, w.double().numpy(), G)              # (cout, cin, 4, 4)
+    for mbw in (1, 2):
+        n = hip_lib.mr_wino_packed_weight_floats(cout, arr, 2, mbw)
+        groups, nchunks = -(-cout // (32 * mbw)), 1 + 2                       # 5 -> one chunk of 8, 11 -> two
+        assert n == groups * nchunks * 16 * 2 * (2 * mbw) * 64
+        packed = torch.full((n,), float("nan"))
+        assert hip_lib.mr_wino_pack_weights_f32(w.data_ptr(), cout, arr, 2, mbw, packed.data_ptr()) == 0
+        P = packed.view(groups, nchunks, 16, 2, 2 * mbw, 64).numpy()
+        assert np.isfinite(P).all()
+        want = np.zeros_like(P)
+        for co in range(cout):
+            for ci in range(sum(srcs)):
+                chunk, cl = (0, ci) if ci < 5 else (1 + (ci - 5) // 8, (ci - 5) % 8)
+                gi, mb, l15 = co // (32 * mbw), (co % (32 * mbw)) // 16, co % 16
+                want[gi, chunk, :, cl // 4, mb, (cl % 4) * 16 + l15] = U[co, ci].reshape(16)
+        assert np.abs(P - want).max() <= 1e-7                                 # one rounding to fp32; every padded slot exactly zero
+        assert (P[want == 0] == 0).all()
+    assert hip_lib.mr_wino_packed_weight_floats(cout, arr, 2, 3) == 0 and hip_lib.mr_wino_pack_weights_f32(w.data_ptr(), cout, arr, 2, 4, packed.data_ptr()) == -1
+    rng = np.random.default_rng(0)
+    d, gk = rng.standard_normal((4, 4)), rng.standard_normal((3, 3))
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]])
+    Y = At @ ((G @ gk @ G.T) * (Bt @ d @ Bt.T)) @ At.T
+    ref = np.array([[(d[i:i + 3, j:j + 3] * gk).sum() for j in range(2)] for i in range(2)])
+    assert np.abs(Y - ref).max() < 1e-12
+
+
+def test_winograd_choice_table_and_rule():
+    """engine.choose_winograd: the measured table wins (c2: the two full-resolution mask stages and the big decoder layers go to the
+    Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
+    rule; widths that are not a multiple of 4 never qualify."""
+    assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2}
+    assert engine.choose_winograd(32, [32], 256, 512, 2) == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) == 2    # mask.enc0.*, mask.dec3.1 @ c2
+    assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
+    assert engine.choose_winograd(64, [64], 256, 512, 32) == 2                                                               # mask.enc0.* @ c3
+    assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct
+    assert engine.choose_winograd(32, [32], 256, 768, 3) == 1          # unknown, 2304 workgroups, 32 couts
+    assert engine.choose_winograd(96, [96], 256, 768, 3) == 2
+    assert engine.choose_winograd(32, [32], 256, 510, 4) == 0          # width % 4

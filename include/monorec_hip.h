@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 6
+#define MR_ABI_VERSION 7
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -204,6 +204,21 @@ int mr_wino_pack_weights_f32(const float* weight, int32_t out_channels, const in
                              int32_t cout_blocks_per_wave, float* dst);
 int64_t mr_conv3x3_winograd_lds_bytes(const mr_wino_desc* desc);   /* dynamic LDS of the launch, or a negative MR_ERR_* code */
 int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
+
+/*
+ * nn.ConvTranspose2d(kernel 4, stride 2) + the centre crop of layers.Refine (model/layers.py:380-400: the decoder stages of the
+ * DepthModule, model/monorec/monorec_model.py:503-513) as Winograd F(2x2, 2x2): each of the four output parities is a 2x2 stride-1
+ * convolution on the low-resolution input (9 multiplies per 2x2 parity tile instead of 16; transform coefficients 0 / +-1 only).
+ * Same descriptor as mr_conv3x3_winograd_f32: sources (batch, C_s, height, width) read in place, dst = (batch, out_channels,
+ * 2 * height, 2 * width), bias / activation in the epilogue, no residual; cout_blocks_per_wave 1, 2 or 4 (32 / 64 / 128 output channels
+ * per workgroup); packed_weights from mr_wino_t_pack_weights_f32 with the same value.  width % 4 == 0.
+ */
+size_t mr_wino_t_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
+/* weight: the nn.ConvTranspose2d tensor (sum(src_channels), out_channels, 4, 4), fp32 host memory */
+int mr_wino_t_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                               int32_t cout_blocks_per_wave, float* dst);
+int64_t mr_convt4x4s2_winograd_lds_bytes(const mr_wino_desc* desc);
+int mr_convt4x4s2_winograd_f32(const mr_wino_desc* desc, void* stream);
 
 /*
  * Fused plane-sweep cost volume.  Replaces CostVolumeModule.forward per-pixel work,

@@ -98,6 +98,11 @@ ABI = {
                                                 ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv3x3_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
     "mr_conv3x3_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
+    "mr_wino_t_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32]),
+    "mr_wino_t_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                                                  ctypes.c_int32, ctypes.c_void_p]),
+    "mr_convt4x4s2_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_convt4x4s2_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_cost_volume_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -183,7 +188,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 6:
+    if lib.mr_abi_version() != 7:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -25,6 +25,7 @@ SOURCES = [
     ("eltwise.hip", []),
     ("heads.hip", []),
     ("conv_wino.hip", []),
+    ("convt_wino.hip", []),
 ]
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert getattr(hip_lib, name) is not None
-    assert hip_lib.mr_abi_version() == 6
+    assert hip_lib.mr_abi_version() == 7
     assert b"LDS" in hip_lib.mr_error_string(-3)
 
 

@@ -660,3 +660,49 @@ def test_winograd_bad_arguments(hip_lib):
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -2          # width % 4 != 0
     d.width, d.cout_blocks_per_wave = 8, 3
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1
+
+
+# ---- ConvTranspose2d(4, 2) + crop as Winograd F(2x2,2x2) (csrc/convt_wino.hip) ------------------------------------------------------
+WINO_T_CASES = [
+    # (srcs_c, cout, (h, w) of the input, batch, act, mbw)
+    ((32,), 32, (16, 32), 1, ACT_LEAKY_RELU, 1),
+    ((64, 64, 64), 48, (24, 32), 1, ACT_LEAKY_RELU, 2),               # depth.dec3: three concatenated sources, 48 couts
+    ((96,), 128, (8, 32), 2, ACT_LEAKY_RELU, 4),
+    ((5, 11), 40, (13, 20), 3, ACT_NONE, 2),                          # ragged: C % 8, h % 8, w % 32, cout % 64
+    ((3,), 7, (5, 4), 1, ACT_LEAKY_RELU, 1),
+    ((40,), 256, (4, 8), 1, ACT_LEAKY_RELU, 4),                       # two cout groups of 128
+]
+
+
+@pytest.mark.parametrize("case", range(len(WINO_T_CASES)))
+def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case):
+    """mr_convt4x4s2_winograd_f32 against F.conv_transpose2d(stride=2) cropped by one pixel on every side (layers.Refine,
+    model/layers.py:389-397) + bias + LeakyReLU on the CPU."""
+    srcs_c, cout, (h, w), batch, act, mbw = WINO_T_CASES[case]
+    lib = hip_lib
+    g = torch.Generator().manual_seed(200 + case)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) * (1.0 / (2.0 * math.sqrt(cin)))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = _act_ref(F.conv_transpose2d(torch.cat(srcs, 1), wt, bias, stride=2)[:, :, 1:-1, 1:-1], act, 0.1, 0.0)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_wino_t_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+    packed = torch.empty(n)
+    _lib.check(lib.mr_wino_t_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s.to(DEV) for s in srcs]
+    for i, s in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, 2 * h, 2 * w), float("nan"), device=DEV)
+    pk, bs = packed.to(DEV), bias.to(DEV)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), None
+    d.activation, d.act_p0, d.cout_blocks_per_wave = act, 0.1, mbw
+    assert 0 < lib.mr_convt4x4s2_winograd_lds_bytes(ctypes.byref(d)) <= 160 * 1024
+    _lib.check(lib.mr_convt4x4s2_winograd_f32(ctypes.byref(d), _stream()), "mr_convt4x4s2_winograd_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err

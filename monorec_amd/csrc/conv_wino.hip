@@ -21,6 +21,7 @@
 // per position like every fp32 MFMA.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 
@@ -231,6 +232,146 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoKArgs a) {
         }
 }
 
+
+// ---- variant with the input transform in registers (MR_WINO_REGB=1; measured next to the kernel above before it replaces it) --------
+// The B operand of the MFMA for (position p, channel quad c4) is V[p][4 c4 + (lane >> 4)][tile lane & 15] - so the lane that needs it
+// can compute it itself: it reads the 4x4 patches of ITS two channels of the chunk at ITS tile from the raw region (32 LDS reads),
+// transforms them (64 adds) and holds the 32 values as MFMA operands.  No V buffer (40 KB of LDS), no V round trip (16 writes + 32
+// reads per lane and chunk), ONE barrier per chunk instead of two; the price is that the two waves of a tile row (the cout halves)
+// both transform its patches.  Same products in the same order per accumulator as the kernel above: bit-identical outputs.
+template <int MBW>
+__global__ __launch_bounds__(512) void conv3x3_wino_rb_kernel(const WinoKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int U_FLOATS = 16 * 2 * (2 * MBW) * 64;
+    constexpr int BUF = WCK * RAW_PLANE + U_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    const int oy0 = ty_wg * 8, ox0 = tx_wg * 32;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / 10, g4 = r - row * 10;
+        const int gy = oy0 - 1 + row, gx = ox0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < RAW_ROWS * 10 ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)grp * a.wgroup_stride;
+
+    f32x4 acc[16][MBW];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF * 4;
+        const unsigned u_addr = buf_addr + WCK * RAW_PLANE * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS;
+        for (int kb = wave; kb < U_FLOATS / 256; kb += 8) dma_global_x4(u_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int tb = wave & 3, chalf = wave >> 2;
+    const int patch0 = (lane >> 4) * RAW_PLANE + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 3;   // channel lane >> 4, tile (tb, lane & 15)
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF;
+        const float* ub = raw + WCK * RAW_PLANE + (chalf * MBW) * 64 + lane;
+        dma_wait_all();
+        __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][16];                                       // B operands of this lane: V[p] of channels 4 c4 + (lane >> 4)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE;
+            float d[4][4], t[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[r][c] = rp[r * RAW_PITCH + c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[c4][r * 4 + 0] = t[r][0] - t[r][2];
+                v[c4][r * 4 + 1] = t[r][1] + t[r][2];
+                v[c4][r * 4 + 2] = t[r][2] - t[r][1];
+                v[c4][r * 4 + 3] = t[r][1] - t[r][3];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    const float av = ub[((p * 2 + c4) * (2 * MBW) + m) * 64];
+                    acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c4][p], acc[p][m], 0, 0, 0);
+                }
+    }
+    // ---- output transform Y = A^T M A per (cout, tile) in registers, epilogue (as above) ------------------------------------------
+    const int ox = ox0 + 2 * (lane & 15);
+    const int oyb = oy0 + 2 * tb;
+    if (ox >= W) return;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cout = grp * (32 * MBW) + (chalf * MBW + m) * 16 + (lane >> 4) * 4 + r;
+            if (cout >= a.Cout) continue;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s0[c] = (acc[0 + c][m][r] + acc[4 + c][m][r]) + acc[8 + c][m][r];
+                s1[c] = (acc[4 + c][m][r] - acc[8 + c][m][r]) - acc[12 + c][m][r];
+            }
+            float y[2][2];
+            y[0][0] = (s0[0] + s0[1]) + s0[2];
+            y[0][1] = (s0[1] - s0[2]) - s0[3];
+            y[1][0] = (s1[0] + s1[1]) + s1[2];
+            y[1][1] = (s1[1] - s1[2]) - s1[3];
+            const float bs = a.bias ? a.bias[cout] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oy = oyb + i;
+                if (oy >= H) continue;
+                const long long idx = ((long long)(b * a.Cout + cout) * H + oy) * W + ox;
+                float2 o;
+                o.x = y[i][0] + bs;
+                o.y = y[i][1] + bs;
+                if (a.res) {
+                    const float2 rv = *(const float2*)(a.res + idx);
+                    o.x += rv.x;
+                    o.y += rv.y;
+                }
+                o.x = wino_activate(o.x, a.act, a.p0);
+                o.y = wino_activate(o.y, a.act, a.p0);
+                *(float2*)(a.dst + idx) = o;
+            }
+        }
+}
+
 bool valid_mbw(int m) { return m == 1 || m == 2; }
 int pad8(int c) { return (c + 7) & ~7; }
 
@@ -239,6 +380,7 @@ struct WinoDerived {
     dim3 grid;
     size_t lds_bytes;
     int mbw;
+    bool regb;
 };
 
 int wino_derive(const mr_wino_desc* d, WinoDerived* out) {
@@ -276,24 +418,27 @@ int wino_derive(const mr_wino_desc* d, WinoDerived* out) {
     const int groups = (d->out_channels + 32 * mbw - 1) / (32 * mbw);
     if (d->batch >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
     out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)d->batch);
-    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ufl) + V_FLOATS) * 4;
+    static const bool regb = getenv("MR_WINO_REGB") != nullptr;                 // the in-register-transform variant (see there)
+    out->regb = regb;
+    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ufl) + (regb ? 0 : V_FLOATS)) * 4;
     out->mbw = mbw;
     return 0;
 }
 
-template <int MBW>
+template <int MBW, bool REGB>
 int wino_launch(const WinoDerived& dv, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_set{0};      // dynamic-LDS ceiling once per instantiation AND device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
+    const void* fn = REGB ? reinterpret_cast<const void*>(&conv3x3_wino_rb_kernel<MBW>) : reinterpret_cast<const void*>(&conv3x3_wino_kernel<MBW>);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<MBW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(conv3x3_wino_kernel<MBW>, dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
+    if (REGB) hipLaunchKernelGGL(conv3x3_wino_rb_kernel<MBW>, dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
+    else hipLaunchKernelGGL(conv3x3_wino_kernel<MBW>, dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
@@ -355,5 +500,6 @@ extern "C" int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream) {
     WinoDerived dv;
     const int rc = wino_derive(desc, &dv);
     if (rc != 0) return rc;
-    return dv.mbw == 2 ? wino_launch<2>(dv, (hipStream_t)stream) : wino_launch<1>(dv, (hipStream_t)stream);
+    if (dv.regb) return dv.mbw == 2 ? wino_launch<2, true>(dv, (hipStream_t)stream) : wino_launch<1, true>(dv, (hipStream_t)stream);
+    return dv.mbw == 2 ? wino_launch<2, false>(dv, (hipStream_t)stream) : wino_launch<1, false>(dv, (hipStream_t)stream);
 }

@@ -473,6 +473,9 @@ def main():
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
                  f"conv_mfma_kernel (direct) + conv3x3_wino_kernel (Winograd F(2x2,3x3), {n_wino} of the launches); both fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "frac_executed": conv_flops_executed / conv_s / 1e12 / peak,
+                "frac_note": "frac counts the reference's multiply-adds (SURVEY 8d) over the measured conv time; frac_executed counts what the "
+                             "matrix cores execute (less where Upconv is phase-decomposed and where the Winograd kernel runs)",
                 "traffic": pmc.get("conv_hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
                 "traffic_source": pmc_src, "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
                 "avg_launch_us_note": "HIP events around each layer: kernel + dispatch gap (+ split-K finishing kernel)",

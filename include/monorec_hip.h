@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 7
+#define MR_ABI_VERSION 8
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -197,6 +197,9 @@ typedef struct mr_wino_desc {
     int32_t activation;
     float act_p0;
     int32_t cout_blocks_per_wave;    /* 1 or 2: a workgroup (8 waves, 8 x 32 output pixels) produces 32 or 64 output channels */
+    int32_t variant;                 /* mr_conv3x3_winograd_f32 only: 0 input transform through an LDS buffer (thread = channel x tile),
+                                        1 input transform in the registers of the lane that feeds it to the matrix core (no V buffer,
+                                        one barrier per chunk; bit-identical results).  Which is faster is measured per layer shape. */
 } mr_wino_desc;
 size_t mr_wino_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
 /* weight: (out_channels, sum(src_channels), 3, 3) fp32 host memory; the transformed filters G g G^T are formed in double */
@@ -280,6 +283,18 @@ int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in
  * (mr_conv2d_f32 can also pool while staging - MR_IN_MAXPOOL2 - but the separate pass + DMA-staged conv is
  * faster on MI355X.) */
 int mr_maxpool2x2_f32(const float* src, float* dst, int64_t planes, int32_t in_h, int32_t in_w, void* stream);
+
+/* MonoRecModel.forward returns tensors the caller owns (the reference's outputs are fresh tensors: monorec_model.py:256-279,
+ * 690, 713-727; create_pointcloud.py:79-98 keeps `result` of five keyframes and multiplies one in place).  The path computes into
+ * resident buffers, so forward() ends with ONE launch that copies every output into the caller's memory: `num_segments`
+ * (<= MR_MAX_COPY_SEGMENTS) independent device-to-device copies; src / dst 16-byte aligned, bytes a positive multiple of 16. */
+#define MR_MAX_COPY_SEGMENTS 24
+typedef struct mr_copy_segment {
+    const void* src;
+    void* dst;
+    int64_t bytes;
+} mr_copy_segment;
+int mr_copy_segments(const mr_copy_segment* segments, int32_t num_segments, void* stream);
 
 /* ResnetEncoder input normalisation ((x + 0.5) - 0.45) / 0.225, elementwise (monorec_model.py:691 + :120);
  * count % 4 == 0.  (MR_TF_RESNET_NORM does the same while staging inside mr_conv2d_f32.) */

@@ -63,7 +63,17 @@ class WinoDesc(ctypes.Structure):
                 ("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
                 ("dst", ctypes.c_void_p), ("out_channels", ctypes.c_int32),
                 ("packed_weights", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p),
-                ("activation", ctypes.c_int32), ("act_p0", ctypes.c_float), ("cout_blocks_per_wave", ctypes.c_int32)]
+                ("activation", ctypes.c_int32), ("act_p0", ctypes.c_float), ("cout_blocks_per_wave", ctypes.c_int32),
+                ("variant", ctypes.c_int32)]
+
+
+MR_MAX_COPY_SEGMENTS = 24
+MR_ABI_VERSION = 8             # include/monorec_hip.h
+
+
+class CopySegment(ctypes.Structure):
+    """mirror of `mr_copy_segment` (include/monorec_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_int64)]
 
 
 class HeadDesc(ctypes.Structure):
@@ -128,6 +138,7 @@ ABI = {
     "mr_maxpool2x2_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_void_p]),
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_copy_segments": (ctypes.c_int, [ctypes.POINTER(CopySegment), ctypes.c_int32, ctypes.c_void_p]),
     "mr_max_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                               ctypes.c_void_p]),
     "mr_nonzero_mean_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
@@ -188,7 +199,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mr_abi_version() != 7:
+    if lib.mr_abi_version() != MR_ABI_VERSION:
         raise RuntimeError("libmonorec_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -876,7 +876,9 @@ int derive(const mr_conv_desc* d, Derived* out) {
     k.gpr_magic = 65536u / (unsigned)(k.IWa >> 2 > 0 ? k.IWa >> 2 : 1) + 1u;
     k.tiles_x_magic = k.tiles_x == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)k.tiles_x) + 1u;   // (1 would overflow)
     if ((long long)k.tiles_x * tiles_y >= 65536) return MR_ERR_UNSUPPORTED;
-    { const char* e = getenv("MR_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
+#ifdef MR_CONV_TIMELINE      // ablation / timestamp switches: diagnostic library only - the launch path of the product reads no environment
+    { static const int dbg = [] { const char* e = getenv("MR_CONV_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
+#endif
     out->mb = mb; out->nb = nb; out->wv = wv;
     if (wv == 8 && !k.dma_x4) return MR_ERR_UNSUPPORTED;
     if (kws && !k.dma_in) return MR_ERR_UNSUPPORTED;

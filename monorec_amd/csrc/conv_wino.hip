@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoKArgs a) {
 }
 
 
-// ---- variant with the input transform in registers (MR_WINO_REGB=1; measured next to the kernel above before it replaces it) --------
+// ---- variant with the input transform in registers (mr_wino_desc.variant = 1; the plan picks per layer shape by measurement) --------
 // The B operand of the MFMA for (position p, channel quad c4) is V[p][4 c4 + (lane >> 4)][tile lane & 15] - so the lane that needs it
 // can compute it itself: it reads the 4x4 patches of ITS two channels of the chunk at ITS tile from the raw region (32 LDS reads),
 // transforms them (64 adds) and holds the 32 values as MFMA operands.  No V buffer (40 KB of LDS), no V round trip (16 writes + 32
@@ -418,7 +418,8 @@ int wino_derive(const mr_wino_desc* d, WinoDerived* out) {
     const int groups = (d->out_channels + 32 * mbw - 1) / (32 * mbw);
     if (d->batch >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
     out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)d->batch);
-    static const bool regb = getenv("MR_WINO_REGB") != nullptr;                 // the in-register-transform variant (see there)
+    if (d->variant != 0 && d->variant != 1) return MR_ERR_BAD_ARGUMENT;
+    const bool regb = d->variant == 1;                                          // the in-register-transform variant (see there)
     out->regb = regb;
     out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ufl) + (regb ? 0 : V_FLOATS)) * 4;
     out->mbw = mbw;

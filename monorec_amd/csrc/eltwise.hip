@@ -192,6 +192,23 @@ inline unsigned grid_for(long long work_items) {
     return (unsigned)blocks;
 }
 
+// forward() hands the caller tensors it owns (monorec_model.py:713-727: the reference's outputs are fresh tensors): all outputs of
+// one forward leave the slot's resident buffers in ONE launch - blockIdx.y = segment, grid-stride over its 16-byte units.
+typedef float copy_f32x4 __attribute__((ext_vector_type(4)));
+struct CopyArgs {
+    const copy_f32x4* src[MR_MAX_COPY_SEGMENTS];
+    copy_f32x4* dst[MR_MAX_COPY_SEGMENTS];
+    long long units[MR_MAX_COPY_SEGMENTS];
+};
+
+__global__ __launch_bounds__(256) void copy_segments_kernel(const CopyArgs a) {
+    const int s = blockIdx.y;
+    const copy_f32x4* __restrict__ src = a.src[s];
+    copy_f32x4* __restrict__ dst = a.dst[s];
+    const long long n = a.units[s];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 }  // namespace
 
 extern "C" int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in_h, int32_t in_w, void* stream) {
@@ -257,6 +274,25 @@ extern "C" int mr_apply_mask_f32(const float* cv, const float* mask, float* dst,
     hipLaunchKernelGGL(apply_mask_kernel, dim3(grid_for((long long)batch * num_depths * plane / 4)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)cv, (const float4*)mask, (float4*)dst, batch, num_depths,
                        (long long)(plane / 4));
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_copy_segments(const mr_copy_segment* segments, int32_t num_segments, void* stream) {
+    if (!segments || num_segments < 1 || num_segments > MR_MAX_COPY_SEGMENTS) return MR_ERR_BAD_ARGUMENT;
+    CopyArgs a;
+    long long most = 0;
+    for (int s = 0; s < num_segments; ++s) {
+        const mr_copy_segment& g = segments[s];
+        if (!g.src || !g.dst || g.bytes < 16 || (g.bytes & 15) || ((unsigned long long)g.src & 15) || ((unsigned long long)g.dst & 15))
+            return MR_ERR_BAD_ARGUMENT;
+        a.src[s] = (const copy_f32x4*)g.src;
+        a.dst[s] = (copy_f32x4*)g.dst;
+        a.units[s] = g.bytes / 16;
+        if (a.units[s] > most) most = a.units[s];
+    }
+    const long long blocks = (most + 255) / 256;
+    hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)num_segments), dim3(256), 0,
+                       (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -15,10 +15,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+def init_from_env(backend=None, single_rank_group=False):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  A one-process job creates no
+    group unless `single_rank_group` asks for one (tests: a 1-rank "nccl" group runs the RCCL branch on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 or dist.is_initialized():
+    if (world == 1 and not single_rank_group) or dist.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
@@ -28,13 +29,19 @@ def init_from_env(backend=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         kwargs["device_id"] = torch.device("cuda", local)
-    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world, **kwargs)
+    dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kwargs)
 
 
 def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def group_active():
+    """True when a process group exists - also a one-rank group: the collectives below then really run (RCCL with the "nccl"
+    backend), so that the branch a multi-GPU job takes is the branch a one-GPU box can test."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_batches(num_batches, rank=None, world=None, contiguous=False):
@@ -52,7 +59,7 @@ def gather_sums(local_sums, device=None):
     """all_gather of a small float64 vector; returns a (world, n) tensor on every rank."""
     rank, world = world_info()
     t = torch.as_tensor(local_sums, dtype=torch.float64)
-    if world == 1:
+    if not group_active():
         return t.reshape(1, -1)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -72,7 +79,7 @@ def gather_batch_records(per_batch_metrics, batch_sizes, batch_indices, n_metric
     for r, (m, bs, gi) in enumerate(zip(per_batch_metrics, batch_sizes, batch_indices)):
         local[r, 0], local[r, 1] = float(gi), float(bs)
         local[r, 2:] = torch.as_tensor([float(v) for v in m], dtype=torch.float64)
-    if world == 1:
+    if not group_active():
         rows = local
     else:
         counts = gather_sums([float(local.shape[0])]).reshape(-1).to(torch.int64)
@@ -96,7 +103,7 @@ def reduce_batch_metrics(per_batch_metrics):
     which also reproduces 'metrics_correct'.)"""
     n_metrics = len(per_batch_metrics[0]) if per_batch_metrics else 0
     _, world = world_info()
-    if world > 1:   # ranks with an empty shard still need the vector length
+    if group_active():   # ranks with an empty shard still need the vector length
         lens = gather_sums([float(n_metrics)])
         n_metrics = int(lens.max().item())
     local = torch.zeros(n_metrics + 1, dtype=torch.float64)

@@ -148,7 +148,8 @@ def _load_tuned():
 
 _load_tuned()
 
-WINOGRAD = {}       # signature (without the phase / mode suffixes) -> 0 (direct kernel), 1 or 2 (cout blocks per wave); measured
+WINOGRAD = {}       # signature (without the phase / mode suffixes) -> 0 (direct kernel), 1 or 2 (cout blocks per wave; + 10: the variant
+                    # with the input transform in registers); measured
 
 
 def _load_winograd():
@@ -169,9 +170,11 @@ def winograd_signature(cout, src_channels, h, w, batch):
 
 def choose_winograd(cout, src_channels, h, w, batch):
     """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
-    for a 3x3 stride-1 convolution.  The measured table (tools/bench_wino.py --write-table, MI355X) wins; shapes it does not know
-    go to the Winograd kernel when it has enough workgroups (8 x 32 output pixels each) to fill the chip - below that the direct
-    kernel's smaller tiles and split-K win (measured: every ResNet layer of a batch-1 keyframe)."""
+    11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), for a 3x3 stride-1 convolution.  The
+    measured table (tools/bench_wino.py --emit, MI355X) wins; shapes it does not know go to the Winograd kernel when it has enough
+    workgroups (8 x 32 output pixels each) to fill the chip - below that the direct kernel's smaller tiles and split-K win
+    (measured: every ResNet layer of a batch-1 keyframe) - with the variant that measured faster at that width on every shape of
+    the table (32 channels per workgroup: transform in registers, two workgroups per CU; 64: the LDS buffer)."""
     if w % 4:
         return 0
     sig = winograd_signature(cout, src_channels, h, w, batch)
@@ -180,7 +183,7 @@ def choose_winograd(cout, src_channels, h, w, batch):
     tiles = math.ceil(h / 8) * math.ceil(w / 32) * batch
     if tiles * math.ceil(cout / 32) < 256:
         return 0
-    return 2 if (cout > 32 and tiles * math.ceil(cout / 64) >= 256) else 1
+    return 2 if (cout > 32 and tiles * math.ceil(cout / 64) >= 256) else 11
 
 
 
@@ -370,7 +373,7 @@ class Plan:
                 name not in self.schedule_override):
             mbw = choose_winograd(cout, src_channels, hs, ws, n)
             if mbw:
-                return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw)
+                return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw % 10, mbw // 10)
         if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
             kh, kw = max(p[0].shape[2] for p in phases), max(p[0].shape[3] for p in phases)
         mixed = phases is not None and any(tuple(p[0].shape[2:]) != (kh, kw) for p in phases)
@@ -441,7 +444,7 @@ class Plan:
         self.stages[stage].append((name, self._launch_conv(d, name)))
         return out
 
-    def _conv_winograd(self, stage, name, srcs, weight, bias, out, act, p0, residual, mbw):
+    def _conv_winograd(self, stage, name, srcs, weight, bias, out, act, p0, residual, mbw, variant=0):
         """One mr_conv3x3_winograd_f32 launch (csrc/conv_wino.hip) in place of a 3x3 stride-1 mr_conv2d_f32 launch."""
         lib = self.lib
         n, _, hs, ws = srcs[0].shape
@@ -465,14 +468,14 @@ class Plan:
         if residual is not None:
             assert residual.shape == out.shape
             d.residual = residual.data_ptr()
-        d.activation, d.act_p0, d.cout_blocks_per_wave = act, p0, mbw
+        d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
         lds = lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} winograd")
         ref = n * hs * ws * cout * cin * 9
         wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (32 * mbw))
         self.conv_log.append(dict(name=name, macs=ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
-                                  cout=cout, cin=cin, k=(3, 3), out=(hs, ws), batch=n, phases=1, winograd=mbw, bf16=0,
+                                  cout=cout, cin=cin, k=(3, 3), out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=variant, bf16=0,
                                   sig=winograd_signature(cout, src_channels, hs, ws, n),
                                   spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 3, 3), stride=(1, 1), pad=(1, 1),
                                             grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=act, p0=p0, p1=0.0, residual=residual is not None,

@@ -109,7 +109,7 @@ class Evaluater:
             for s in host:
                 vals = _metrics.metrics_from_sums(s)
                 per_batch.append([float(vals[c]) for c in self._cols])
-        if world > 1:
+        if distributed and _dist.group_active():      # also a one-rank group: the collective is the code path under test there
             per_batch, sizes, indices = _dist.gather_batch_records(per_batch, sizes, indices, len(self._cols))
         if not per_batch:
             return evaluation_log([], [])

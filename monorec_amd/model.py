@@ -8,6 +8,7 @@ dict-in / dict-out `forward` (reference model/monorec/monorec_model.py:560-729),
 launch plan in `engine.py`.  There is no PyTorch/CPU fallback: calling `forward` without a HIP device
 or without the built library raises.
 """
+import collections
 import threading
 import time
 import warnings
@@ -215,7 +216,7 @@ class MonoRecModel(nn.Module):
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1):
+                 hip_batch_keyframes=1, hip_queue_depth=2):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -252,6 +253,12 @@ class MonoRecModel(nn.Module):
         # stream: at batch 1 two thirds of the launches are latency chains); 1 = every request is launched on its own
         self._batch_keyframes = max(1, int(hip_batch_keyframes))
         self._open_group = None
+        # how far the host may run ahead of the GPU: submit() blocks until all but the last `hip_queue_depth - 1` earlier forwards of
+        # the slot it is about to reuse have finished, i.e. at most hip_in_flight * hip_queue_depth forwards are ever enqueued.
+        # (Enqueueing a forward takes the host ~0.3-0.6 ms; kept >= one forward ahead, the slot streams never run dry between
+        # keyframes - measured +10 % keyframes/s against enqueueing each forward only once its slot is free.)
+        self._queue_depth = max(1, int(hip_queue_depth))
+        self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
         # hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
@@ -319,6 +326,20 @@ class MonoRecModel(nn.Module):
         self._consts = {}
         self._packed_state = None
 
+    def _weights_snapshot(self):
+        """CPU fp32 copy of the weights, shared by the plans of every slot / device (and by nn.DataParallel replicas)."""
+        if self._packed_state is None:
+            self._packed_state = ("cpu", {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
+        return self._packed_state[1]
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel replicates the module on every forward; a replica's `_parameters` are empty (torch sets the weight copies
+        # as plain attributes), so its state_dict() holds buffers only.  The snapshot is therefore taken here, on the original,
+        # and travels to the replicas through the shallow copy of __dict__ - also when the very first forward is a wrapped one
+        # (evaluater.py:27-30 wraps right after construction / checkpoint load).
+        self._weights_snapshot()
+        return super()._replicate_for_data_parallel()
+
     def _apply(self, fn, *a, **k):   # .to() / .cuda(): parameters moved or cast -> repack
         self._invalidate()
         return super()._apply(fn, *a, **k)
@@ -347,9 +368,7 @@ class MonoRecModel(nn.Module):
         key = (slot, batch, h, w, nf, self.cv_depth_steps, str(device))
         plan = self._plans.get(key)
         if plan is None:
-            if self._packed_state is None:          # CPU fp32 copy of the weights, shared by the plans of every slot / device
-                self._packed_state = (str(device), {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()})
-            plan = Plan(self._packed_state[1], batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
+            plan = Plan(self._weights_snapshot(), batch, h, w, nf, self.cv_depth_steps, self.inv_depth_min_max, device,
                         alpha=self.cv_module.alpha, channel_weights=self.cv_module.channel_weights, bf16=self._bf16,
                         use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
                         no_cv=self.no_cv, mask_use_cv=self.mask_use_cv or self.simple_mask,
@@ -359,7 +378,10 @@ class MonoRecModel(nn.Module):
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
             plan.geom_uploaded = None       # event behind the last H2D copy out of host_geom
-            plan.host_time = torch.zeros(1, dtype=torch.float32).pin_memory()
+            plan.host_time = torch.zeros(8, dtype=torch.float32).pin_memory()   # ring: one scalar per submit, reused 8 submits of this slot later
+            plan.host_time_at = 0
+            plan.enqueued = collections.deque()   # completion events of this slot's forwards the host has not waited for yet
+            plan.consumers = []                   # streams that were handed results of this slot since its last enqueue
             self._plans[key] = plan
         return key, plan
 
@@ -379,18 +401,69 @@ class MonoRecModel(nn.Module):
         with self._lock:
             out = self.submit(data_dict).result()
             with torch.cuda.device(out["keyframe"].device):
-                for k in self._OUTPUT_KEYS:
-                    v = out.get(k)
-                    if torch.is_tensor(v):
-                        out[k] = v.clone()
-                    elif isinstance(v, list):
-                        out[k] = [t.clone() for t in v]
+                self._own_outputs(out)
         if self.pretrain_mode == 2:                           # :723-727, same aliasing as the reference
             out["result"] = out["cv_mask"]
         else:
             out["result"] = out["predicted_inverse_depths"][0]
             out["mask"] = out["cv_mask"]
         return out
+
+    def _own_outputs(self, out):
+        """Replace the output views of `out` (resident slot buffers) by tensors the caller owns: one allocation, ONE copy launch
+        (mr_copy_segments) on the caller's stream instead of one ATen clone per tensor (~16 launches at c2)."""
+        device = out["keyframe"].device
+        todo = []                                             # (key, list index or None, tensor)
+        for k in self._OUTPUT_KEYS:
+            v = out.get(k)
+            if torch.is_tensor(v):
+                todo.append((k, None, v))
+            elif isinstance(v, list):
+                out[k] = list(v)
+                todo += [(k, i, t) for i, t in enumerate(v)]
+        fast, offset = [], 0
+        ckeys = ("inv_depth_min", "inv_depth_max", "cv_depth_steps")
+        cvals = [out.get(k) for k in ckeys]
+        consts = None
+        if all(torch.is_tensor(c) and c.is_cuda for c in cvals) and cvals[1].data_ptr() == cvals[0].data_ptr() + 4 and \
+                cvals[2].data_ptr() == cvals[0].data_ptr() + 8 and cvals[0].data_ptr() % 16 == 0:
+            consts, offset = cvals[0].data_ptr(), 256         # the three constants of :675-677 travel as one 16-byte segment
+            todo = [e for e in todo if e[0] not in ckeys]
+        for k, i, t in todo:
+            nbytes = t.numel() * t.element_size()
+            if t.is_cuda and t.is_contiguous() and nbytes >= 16 and nbytes % 16 == 0 and t.data_ptr() % 16 == 0 and t.device == device:
+                fast.append((k, i, t, offset, nbytes))
+                offset += (nbytes + 255) // 256 * 256
+            else:                                             # the three one-element constants, anything unusual
+                c = t.clone()
+                if i is None:
+                    out[k] = c
+                else:
+                    out[k][i] = c
+        if not fast and consts is None:
+            return
+        arena = torch.empty(offset, dtype=torch.uint8, device=device)
+        base = arena.data_ptr()
+        if consts is not None:
+            fast.insert(0, (None, None, None, 0, 16))
+            out["inv_depth_min"], out["inv_depth_max"] = arena[0:4].view(torch.float32), arena[4:8].view(torch.float32)
+            out["cv_depth_steps"] = arena[8:12].view(torch.int32)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        lib = _lib.load()
+        for lo in range(0, len(fast), _lib.MR_MAX_COPY_SEGMENTS):
+            part = fast[lo:lo + _lib.MR_MAX_COPY_SEGMENTS]
+            segs = (_lib.CopySegment * len(part))()
+            for j, (_, _, t, off, nbytes) in enumerate(part):
+                segs[j].src, segs[j].dst, segs[j].bytes = (consts if t is None else t.data_ptr()), base + off, nbytes
+            _lib.check(lib.mr_copy_segments(segs, len(part), stream), "mr_copy_segments")
+        for k, i, t, off, nbytes in fast:
+            if t is None:
+                continue
+            c = arena[off:off + nbytes].view(t.dtype).view(t.shape)
+            if i is None:
+                out[k] = c
+            else:
+                out[k][i] = c
 
     def _submit_one(self, data_dict):
         """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
@@ -454,7 +527,12 @@ class MonoRecModel(nn.Module):
             return self._submit_one(data_dict)
         with self._lock:
             data_dict.pop(_METRIC_CACHE_KEY, None)            # cached metric sums of an earlier forward on this dict are stale now
-            kf = data_dict["keyframe"]
+            # a request is checked when it is submitted, not when some later call happens to launch its group
+            if self.training:
+                raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
+            kf = data_dict["keyframe"]                        # missing keys -> KeyError, like the reference
+            for k in self._required_inputs():
+                data_dict[k]
             sig = (tuple(kf.shape), str(kf.device), len(data_dict.get("frames", ())))
             g = self._open_group
             if g is not None and g.sig != sig:
@@ -468,47 +546,66 @@ class MonoRecModel(nn.Module):
                 self._flush_open_group()
             return handle
 
+    def _required_inputs(self):
+        """Input keys `_submit_one` reads for the current options (monorec_model.py:160-167,672-686)."""
+        keys = ["keyframe", "keyframe_intrinsics", "keyframe_pose"]
+        if self.no_cv or self.use_mono:
+            keys += ["frames", "intrinsics", "poses"]
+        if self.use_stereo and not self.no_cv:
+            keys += ["stereoframe", "stereoframe_intrinsics", "stereoframe_pose"]
+        return keys
+
     def _flush_open_group(self):
-        """Launch the requests collected so far as one batch and hand every member its slice of the outputs."""
+        """Launch the requests collected so far as one batch and hand every member its slice of the outputs.  A launch that fails
+        leaves its exception on the group: every member's handle re-raises it instead of tripping over a missing launch."""
         with self._lock:
             g, self._open_group = self._open_group, None
-            if g is None or g.pending is not None:
+            if g is None or g.pending is not None or g.error is not None:
                 return
-            ms = g.members
-            if len(ms) == 1:
-                g.pending = self._submit_one(ms[0])
-                return
-            combined = {}
-            for k in self._BATCHED_INPUTS:
-                if k not in ms[0]:
+            try:
+                self._launch_group(g)
+            except BaseException as e:
+                g.error = e
+                raise
+
+    def _launch_group(self, g):
+        ms = g.members
+        if len(ms) == 1:
+            g.pending = self._submit_one(ms[0])
+            return
+        combined = {}
+        for k in self._BATCHED_INPUTS:
+            if k not in ms[0]:
+                continue
+            v = ms[0][k]
+            combined[k] = ([torch.cat([m[k][i] for m in ms]) for i in range(len(v))] if isinstance(v, (list, tuple))
+                           else torch.cat([m[k] for m in ms]))
+        g.pending = self._submit_one(combined)
+        b = ms[0]["keyframe"].shape[0]
+        for j, m in enumerate(ms):
+            lo, hi = j * b, (j + 1) * b
+            for k, v in combined.items():
+                if k in self._BATCHED_INPUTS:
                     continue
-                v = ms[0][k]
-                combined[k] = ([torch.cat([m[k][i] for m in ms]) for i in range(len(v))] if isinstance(v, (list, tuple))
-                               else torch.cat([m[k] for m in ms]))
-            g.pending = self._submit_one(combined)
-            b = ms[0]["keyframe"].shape[0]
-            for j, m in enumerate(ms):
-                lo, hi = j * b, (j + 1) * b
-                for k, v in combined.items():
-                    if k in self._BATCHED_INPUTS:
-                        continue
-                    if torch.is_tensor(v):
-                        m[k] = v[lo:hi] if (v.dim() == 4 and v.shape[0] == b * len(ms)) else v
-                    elif isinstance(v, list):
-                        m[k] = [t[lo:hi] for t in v]
-                if self.pretrain_mode == 2:
-                    m["result"] = m["cv_mask"]
-                else:
-                    m["result"] = m["predicted_inverse_depths"][0]
-                    m["mask"] = m["cv_mask"]
+                if torch.is_tensor(v):
+                    m[k] = v[lo:hi] if (v.dim() == 4 and v.shape[0] == b * len(ms)) else v
+                elif isinstance(v, list):
+                    m[k] = [t[lo:hi] for t in v]
+            if self.pretrain_mode == 2:
+                m["result"] = m["cv_mask"]
+            else:
+                m["result"] = m["predicted_inverse_depths"][0]
+                m["mask"] = m["cv_mask"]
 
     def _submit_locked(self, data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device):
         # the three constants of :675-677: built once per device (a `new_tensor` from a Python list is a blocking pageable H2D copy on
         # the caller's stream, three of them per keyframe); forward() hands out copies like every other output
         consts = self._consts.get(str(device))
-        if consts is None:
-            consts = (keyframe.new_tensor([self.inv_depth_min_max[0]]), keyframe.new_tensor([self.inv_depth_min_max[1]]),
-                      keyframe.new_tensor([self.cv_depth_steps], dtype=torch.int32))
+        if consts is None:                                    # one 16-byte slab: forward() hands out a copy of it with the other outputs
+            slab = torch.zeros(4, dtype=torch.float32, device=device)
+            slab[0], slab[1] = self.inv_depth_min_max[0], self.inv_depth_min_max[1]
+            slab.view(torch.int32)[2] = int(self.cv_depth_steps)
+            consts = (slab[0:1], slab[1:2], slab.view(torch.int32)[2:3])
             self._consts[str(device)] = consts
         data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = consts
 
@@ -518,10 +615,22 @@ class MonoRecModel(nn.Module):
         streams = self._slot_streams(slot, device)
         main, enc, geom = streams["main"], streams["enc"], streams["geom"]
         caller = torch.cuda.current_stream(device)
+        # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time
+        while len(plan.enqueued) >= self._queue_depth:
+            plan.enqueued.popleft().synchronize()
         start_time = time.time()
 
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(caller)
+        # streams other than the caller's that took results of this slot (`.result()` under another current stream): the launches
+        # below overwrite what those streams read, so they are ordered behind everything enqueued there so far (the caller's own
+        # stream is covered by `inputs_ready`)
+        for cs in plan.consumers:
+            if cs != caller:
+                ev = torch.cuda.Event()
+                ev.record(cs)
+                main.wait_event(ev)
+        plan.consumers.clear()
         # 1. pose / intrinsics matrices -> pinned host memory.  Their own stream, ordered only behind the caller's inputs: the
         #    copy must not queue behind the slot's previous keyframe (the host waits for it below).  Matrices that already live
         #    on the host (a loader that keeps the 4x4s on the CPU) are used in place, without any device round trip.
@@ -592,8 +701,14 @@ class MonoRecModel(nn.Module):
             main.wait_event(tail_done)
             done = torch.cuda.Event()
             done.record(main)
-        plan.host_time[0] = time.time() - start_time         # (:279: host seconds spent in the cost-volume module; here: enqueueing)
-        data_dict["cv_module_time"] = plan.host_time.to(device, non_blocking=True)
+            plan.enqueued.append(done)
+        self.host_enqueue_stats[0] += 1
+        self.host_enqueue_stats[1] += time.time() - start_time
+        # (:279: host seconds spent in the cost-volume module; here: enqueueing.)  The async H2D copy below reads pinned memory some
+        # time later: every submit of the slot gets its own scalar of a ring, rewritten only 8 submits of this slot later
+        i = plan.host_time_at = (plan.host_time_at + 1) % plan.host_time.numel()
+        plan.host_time[i] = time.time() - start_time
+        data_dict["cv_module_time"] = plan.host_time[i:i + 1].to(device, non_blocking=True)
 
         data_dict["cost_volume"] = plan.buf["cost_volume"]
         data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
@@ -605,7 +720,7 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = list(plan.preds)
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-        return _Pending(data_dict, done, device)
+        return _Pending(data_dict, done, device, plan.consumers)
 
     def _run_stage(self, key, plan, stage, stream):
         """Run one stage of the plan on `stream`: eagerly, or (hip_graph) as a captured hipGraph replay."""
@@ -636,7 +751,7 @@ class _Group:
     """Requests collected by MonoRecModel.submit for one coalesced launch (hip_batch_keyframes > 1)."""
 
     def __init__(self, sig):
-        self.sig, self.members, self.pending = sig, [], None
+        self.sig, self.members, self.pending, self.error = sig, [], None, None
 
 
 class _GroupHandle:
@@ -646,9 +761,12 @@ class _GroupHandle:
         self._model, self._group, self._index = model, group, index
 
     def _launched(self):
-        if self._group.pending is None:
+        g = self._group
+        if g.pending is None and g.error is None:
             self._model._flush_open_group()       # asked for before the group filled up: launch what has been collected
-        return self._group.pending
+        if g.error is not None:                   # the combined launch failed (here or in the call that triggered it)
+            raise RuntimeError(f"the coalesced launch of this request's group failed: {g.error!r}") from g.error
+        return g.pending
 
     def result(self):
         self._launched().result()
@@ -662,12 +780,16 @@ class _GroupHandle:
 class _Pending:
     """Handle of an enqueued forward (MonoRecModel.submit)."""
 
-    def __init__(self, data_dict, done, device):
-        self._data, self._done, self._device = data_dict, done, device
+    def __init__(self, data_dict, done, device, consumers=None):
+        self._data, self._done, self._device, self._consumers = data_dict, done, device, consumers
 
     def result(self):
-        """Order the caller's current stream after the forward and return the output dict."""
-        torch.cuda.current_stream(self._device).wait_event(self._done)
+        """Order the caller's current stream after the forward and return the output dict.  The stream is remembered: the submit
+        that reuses the slot orders its launches behind whatever that stream has been given to do with the outputs by then."""
+        cs = torch.cuda.current_stream(self._device)
+        cs.wait_event(self._done)
+        if self._consumers is not None and cs not in self._consumers:
+            self._consumers.append(cs)
         return self._data
 
     def synchronize(self):

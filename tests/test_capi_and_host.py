@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert getattr(hip_lib, name) is not None
-    assert hip_lib.mr_abi_version() == 7
+    assert hip_lib.mr_abi_version() == _lib.MR_ABI_VERSION == int(re.search(r"#define MR_ABI_VERSION (\d+)", text).group(1))
     assert b"LDS" in hip_lib.mr_error_string(-3)
 
 
@@ -528,7 +528,7 @@ def _stub_submit_one(model, calls):
 def test_dynamic_batching_groups_requests_and_slices_outputs():
     """Host logic of MonoRecModel(hip_batch_keyframes=K).submit: K equal-shaped requests -> one launch over the concatenated batch,
     every request gets its slice; a result asked for early launches the partial group; a shape change closes the group."""
-    m = MonoRecModel(cv_depth_steps=8, hip_batch_keyframes=3)
+    m = MonoRecModel(cv_depth_steps=8, hip_batch_keyframes=3).eval()
     calls = []
     _stub_submit_one(m, calls)
     reqs = [dict(keyframe=torch.full((1, 3, 8, 16), float(i)), keyframe_intrinsics=torch.eye(4).unsqueeze(0),
@@ -548,6 +548,34 @@ def test_dynamic_batching_groups_requests_and_slices_outputs():
     h5 = m.submit(other)                                        # another shape: the open group is launched first
     assert calls == [3, 1, 1]
     assert float(h4.result()["result"][0, 0, 0, 0]) == 8.0 and h5.result()["result"].shape == (1, 1, 16, 16) and calls == [3, 1, 1, 1]
+
+
+def test_dynamic_batching_failed_launch_reaches_every_member_and_bad_requests_fail_at_submit():
+    """A coalesced launch that fails must not leave handles without a launch behind: every member's handle re-raises the
+    launch's error; a request with a missing key, or a model in training mode, is refused by the submit() that receives it."""
+    m = MonoRecModel(cv_depth_steps=8, hip_batch_keyframes=2).eval()
+
+    def boom(data):
+        raise ValueError("launch failed")
+    m._submit_one = boom
+    req = lambda i: dict(keyframe=torch.full((1, 3, 8, 16), float(i)), keyframe_intrinsics=torch.eye(4).unsqueeze(0),
+                         keyframe_pose=torch.eye(4).unsqueeze(0), frames=[torch.zeros(1, 3, 8, 16)] * 2,
+                         intrinsics=[torch.eye(4).unsqueeze(0)] * 2, poses=[torch.eye(4).unsqueeze(0)] * 2)
+    h0 = m.submit(req(0))
+    with pytest.raises(ValueError, match="launch failed"):
+        m.submit(req(1))                                        # fills the group: the launch fails here ...
+    for h in (h0,):
+        with pytest.raises(RuntimeError, match="coalesced launch") as e:
+            h.result()                                          # ... and every member sees that error, not an AttributeError
+        assert isinstance(e.value.__cause__, ValueError)
+    assert m._open_group is None
+    bad = req(2)
+    del bad["poses"]
+    with pytest.raises(KeyError):
+        m.submit(bad)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.submit(req(3))
 
 
 def test_forward_returns_owned_outputs_with_the_reference_aliasing():
@@ -613,11 +641,11 @@ def test_winograd_choice_table_and_rule():
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2}
-    assert engine.choose_winograd(32, [32], 256, 512, 2) == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) == 2    # mask.enc0.*, mask.dec3.1 @ c2
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 11, 12}            # + 10: input transform in registers (mr_wino_desc.variant)
+    assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) % 10 == 2    # mask.enc0.*, mask.dec3.1 @ c2
     assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
-    assert engine.choose_winograd(64, [64], 256, 512, 32) == 2                                                               # mask.enc0.* @ c3
+    assert engine.choose_winograd(64, [64], 256, 512, 32) % 10 == 2                                                          # mask.enc0.* @ c3
     assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct
-    assert engine.choose_winograd(32, [32], 256, 768, 3) == 1          # unknown, 2304 workgroups, 32 couts
+    assert engine.choose_winograd(32, [32], 256, 768, 3) == 11         # unknown, 2304 workgroups, 32 couts: transform in registers
     assert engine.choose_winograd(96, [96], 256, 768, 3) == 2
     assert engine.choose_winograd(32, [32], 256, 510, 4) == 0          # width % 4

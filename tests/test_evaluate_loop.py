@@ -132,3 +132,51 @@ def test_two_rank_evaluation_equals_one_rank(hip_lib):
         for key in ("metrics", "metrics_correct"):
             for a, b in zip(log[key], single[key]):
                 assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (rank, key, a, b)
+
+
+def _rccl_single_rank_worker(port, q):
+    import os
+    import torch.distributed as dist
+    from monorec_amd import distributed as mrd
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mrd.init_from_env("nccl", single_rank_group=True)          # "nccl" is RCCL on ROCm
+    assert dist.get_backend() == "nccl" and mrd.group_active() and mrd.world_info() == (0, 1)
+    # the collective itself, on device tensors through RCCL: records incl. a NaN batch come back unchanged and index-sorted
+    per_batch = [[0.25, float("nan"), 3.0], [1.0, 2.0, 3.0], [0.5, 0.125, 8.0]]
+    rows, sizes, idx = mrd.gather_batch_records(per_batch, [2, 1, 2], [4, 0, 2], 3)
+    assert idx == [0, 2, 4] and sizes == [1, 2, 2]
+    assert rows[0] == [1.0, 2.0, 3.0] and rows[1] == [0.5, 0.125, 8.0] and rows[2][0] == 0.25 and rows[2][1] != rows[2][1]
+    g = mrd.gather_sums([1.5, -2.0])
+    assert tuple(g.shape) == (1, 2) and g.tolist() == [[1.5, -2.0]]
+    means, valid = mrd.reduce_batch_metrics(per_batch)
+    assert valid == 2 and means == [0.75, 1.0625, 5.5]
+    log = _eval_log(distributed=True)                          # model -> fused metrics -> RCCL all-gather -> bookkeeping
+    q.put(log)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_group_runs_the_collective_branch(hip_lib):
+    """The "nccl" (= RCCL) branch of monorec_amd.distributed / Evaluater.eval(distributed=True) on the one GPU a test box has:
+    a 1-rank process group on cuda:0.  The all-gathers run on device tensors through RCCL (base/base_trainer.py:26-29 is what the
+    multi-GPU path replaces); the log must equal the plain single-process log."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    single = _eval_log(distributed=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(port, q))
+    p.start()
+    log = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert log["valid_batches"] == single["valid_batches"] == 4
+    for key in ("metrics", "metrics_correct"):
+        for a, b in zip(log[key], single[key]):
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (key, a, b)

@@ -613,10 +613,12 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", range(len(WINO_CASES)))
-def test_winograd_conv_matches_torch_fp32(hip_lib, case):
+def test_winograd_conv_matches_torch_fp32(hip_lib, case, variant):
     """mr_conv3x3_winograd_f32 against F.conv2d(padding=1) on the CPU: the transforms round differently from the direct sum, so the
-    bar is a few 1e-6 of the output scale - far inside the 1e-4 of the path."""
+    bar is a few 1e-6 of the output scale - far inside the 1e-4 of the path.  Both variants (input transform through LDS / in
+    registers) - they must also agree with each other bit for bit."""
     srcs_c, cout, (h, w), batch, act, residual, mbw = WINO_CASES[case]
     lib = hip_lib
     g = torch.Generator().manual_seed(100 + case)
@@ -641,7 +643,7 @@ def test_winograd_conv_matches_torch_fp32(hip_lib, case):
     pk, bs, rs = packed.to(DEV), bias.to(DEV), (res.to(DEV) if residual else None)
     d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
     d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), (rs.data_ptr() if residual else None)
-    d.activation, d.act_p0, d.cout_blocks_per_wave = act, 0.1, mbw
+    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, mbw, variant
     assert lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d)) <= 160 * 1024
     _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()), "mr_conv3x3_winograd_f32")
     torch.cuda.synchronize()
@@ -649,6 +651,12 @@ def test_winograd_conv_matches_torch_fp32(hip_lib, case):
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
+    if variant == 1:                                  # same products in the same order per accumulator: identical words
+        d.variant = 0
+        out.fill_(float("nan"))
+        _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()), "mr_conv3x3_winograd_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), got)
 
 
 def test_winograd_bad_arguments(hip_lib):
@@ -660,6 +668,8 @@ def test_winograd_bad_arguments(hip_lib):
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -2          # width % 4 != 0
     d.width, d.cout_blocks_per_wave = 8, 3
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1
+    d.cout_blocks_per_wave, d.variant = 1, 2
+    assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1          # unknown variant
 
 
 # ---- ConvTranspose2d(4, 2) + crop as Winograd F(2x2,2x2) (csrc/convt_wino.hip) ------------------------------------------------------
@@ -706,3 +716,45 @@ def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case):
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_copy_segments(hip_lib):
+    """mr_copy_segments: all outputs of a forward leave the resident buffers in one launch - independent 16-byte-granular copies."""
+    g = torch.Generator().manual_seed(5)
+    sizes = [4, 8 * 12, 64 * 96 * 8, 3 * 1000 * 1000 + 4, 1024, 52]
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    dsts = [torch.full((n + 8,), float("nan"), device=DEV) for n in sizes]
+    segs = (_lib.CopySegment * len(sizes))()
+    for i, (a, b, n) in enumerate(zip(srcs, dsts, sizes)):
+        segs[i].src, segs[i].dst, segs[i].bytes = a.data_ptr(), b.data_ptr() + 16, n * 4
+    _lib.check(hip_lib.mr_copy_segments(segs, len(sizes), _stream()), "mr_copy_segments")
+    torch.cuda.synchronize()
+    for a, b, n in zip(srcs, dsts, sizes):
+        assert torch.equal(b[4:4 + n], a)
+        assert torch.isnan(b[:4]).all() and torch.isnan(b[4 + n:]).all()          # nothing outside the segment is written
+    segs[0].bytes = 12
+    assert hip_lib.mr_copy_segments(segs, 1, _stream()) == -1                     # not a multiple of 16
+    segs[0].bytes, segs[0].dst = 16, dsts[0].data_ptr() + 4
+    assert hip_lib.mr_copy_segments(segs, 1, _stream()) == -1                     # misaligned
+    assert hip_lib.mr_copy_segments(segs, 0, _stream()) == -1 and hip_lib.mr_copy_segments(segs, 25, _stream()) == -1
+
+
+def test_plan_routes_unknown_3x3_shapes_by_the_workgroup_rule(hip_lib):
+    """engine.choose_winograd for shapes outside tuned_winograd.json: enough 8 x 32 tiles -> the Winograd kernel (H % 8 != 0, a
+    batch of 4), too few -> the direct kernel; both must match F.conv2d (the fallback rule had no parity test)."""
+    g = torch.Generator().manual_seed(9)
+    for (n, cin, cout, h, w), want_wino in (((4, 32, 32, 100, 256), True), ((1, 32, 32, 20, 64), False)):
+        assert engine.winograd_signature(cout, [cin], h, w, n) not in engine.WINOGRAD
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * math.sqrt(cin)))
+        bias = torch.randn(cout, generator=g) * 0.1
+        plan = engine.Plan.bare(DEV)
+        plan.winograd = True
+        out = torch.full((n, cout, h, w), float("nan"), device=DEV)
+        plan.conv("main", "t", [x.to(DEV)], wt, bias, out, stride=(1, 1), pad=(1, 1), grid=(h, w), act=ACT_LEAKY_RELU, p0=0.1)
+        plan.finalize()
+        assert bool(plan.conv_log[0].get("winograd")) == want_wino
+        plan.run_stage("main", _stream())
+        torch.cuda.synchronize()
+        ref = F.leaky_relu(F.conv2d(x, wt, bias, padding=1), 0.1)
+        assert float((out.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))

@@ -37,7 +37,7 @@ def timed(fn, iters=50):
     return best
 
 
-def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None):
+def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, variant=0):
     sc = [int(s.shape[1]) for s in srcs]
     arr = (ctypes.c_int32 * len(sc))(*sc)
     n = lib.mr_wino_packed_weight_floats(weight.shape[0], arr, len(sc), mbw)
@@ -51,7 +51,7 @@ def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None):
     pk, bs = packed.to(DEV), (bias.to(DEV) if bias is not None else None)
     d.packed_weights, d.bias = pk.data_ptr(), (bs.data_ptr() if bs is not None else None)
     d.residual = residual.data_ptr() if residual is not None else None
-    d.activation, d.act_p0, d.cout_blocks_per_wave = act, p0, mbw
+    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
     keep = (pk, bs, d)
     return (lambda stream: _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), "wino")), keep
 
@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--only", default=None)
-    ap.add_argument("--emit", default=None, help="write {signature: 0 | 1 | 2} (fastest kernel per layer; Winograd must win by 3 %%) to this JSON file")
+    ap.add_argument("--emit", default=None, help="write {signature: 0 | 1 | 2 | 11 | 12} (fastest kernel per layer; Winograd must win by 3 %%; + 10 = input "
+                                                 "transform in registers) to this JSON file; entries already in the file for other shapes are kept")
     a = ap.parse_args()
     lib = _lib.load()
     m = MonoRecModel(cv_depth_steps=a.depths)
@@ -91,30 +92,33 @@ def main():
         direct = plan.stages["main"][0][1]
         row = {"name": c["name"], "cin": cin, "cout": cout, "hw": list(sp["grid"]), "n": sp["out_shape"][0], "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"]],
                "direct_us": round(timed(direct), 1)}
-        for mbw in (1, 2):
+        for code in (1, 2, 11, 12):                       # cout blocks per wave, + 10: input transform in registers
+            mbw, variant = code % 10, code // 10
             if mbw == 2 and cout <= 32:
                 continue
             out_w = torch.full(sp["out_shape"], float("nan"), device=DEV)
-            fn, keep = wino_launch(lib, srcs, w, bias, out_w, sp["act"], sp["p0"], mbw, res)
+            fn, keep = wino_launch(lib, srcs, w, bias, out_w, sp["act"], sp["p0"], mbw, res, variant)
             fn(torch.cuda.current_stream().cuda_stream)
             direct(torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            row[f"wino{mbw}_maxdiff"] = float((out_w - out_d).abs().max())
-            row[f"wino{mbw}_us"] = round(timed(fn), 1)
-        best, tb = 0, row["direct_us"]
-        for mbw in (1, 2):
-            if f"wino{mbw}_us" in row and row[f"wino{mbw}_us"] < 0.97 * tb:
-                best, tb = mbw, row[f"wino{mbw}_us"]
+            row[f"wino{code}_maxdiff"] = float((out_w - out_d).abs().max())
+            row[f"wino{code}_us"] = round(timed(fn), 1)
+        best, tb = 0, 0.97 * row["direct_us"]                # Winograd must win by 3 %
+        for code in (1, 2, 11, 12):
+            if f"wino{code}_us" in row and row[f"wino{code}_us"] < tb:
+                best, tb = code, row[f"wino{code}_us"]
         row["sig"] = engine.winograd_signature(cout, [s_[1] for s_ in sp["src_shapes"]], sp["grid"][0], sp["grid"][1], sp["out_shape"][0])
         row["best"] = best
         rows.append(row)
         print(json.dumps(row), flush=True)
     if a.emit:
         os.makedirs(os.path.dirname(os.path.abspath(a.emit)), exist_ok=True)
+        table = json.load(open(a.emit)) if os.path.exists(a.emit) else {}
+        table.update({r["sig"]: r["best"] for r in rows})
         with open(a.emit, "w") as f:
-            json.dump({r["sig"]: r["best"] for r in rows}, f, indent=0, sort_keys=True)
+            json.dump(table, f, indent=0, sort_keys=True)
     tot_d = sum(r["direct_us"] for r in rows)
-    tot_w = sum(min(r["direct_us"], r.get("wino1_us", 1e9), r.get("wino2_us", 1e9)) for r in rows)
+    tot_w = sum(min([r["direct_us"]] + [r.get(f"wino{c}_us", 1e9) for c in (1, 2, 11, 12)]) for r in rows)
     print(json.dumps({"layers": len(rows), "direct_total_us": round(tot_d, 1), "best_of_both_total_us": round(tot_w, 1)}))
 
 

@@ -97,7 +97,7 @@ def main():
     model = MonoRecModel(cv_depth_steps=args.depths)
     sd = synth.seeded_state_dict(model.state_dict())
     engine.TUNED.clear()
-    plan = engine.Plan(sd, args.batch, args.height, args.width, args.frames, args.depths, (0.33, 0.0025), "cpu", bf16=2 if args.bf16x3 else int(args.bf16, winograd=False))
+    plan = engine.Plan(sd, args.batch, args.height, args.width, args.frames, args.depths, (0.33, 0.0025), "cpu", bf16=2 if args.bf16x3 else int(args.bf16), winograd=False)
     table = {}
     if args.merge and os.path.exists(args.out):
         table = json.load(open(args.out))

@@ -78,12 +78,15 @@ def parse():
     ap.add_argument("--primer", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="GPU_MAX_HW_QUEUES for this process (0: leave the runtime default of 4); an exported GPU_MAX_HW_QUEUES wins")
-    ap.add_argument("--queue-depth", type=int, default=2,
+    ap.add_argument("--queue-depth", type=int, default=1,
                     help="MonoRecModel(hip_queue_depth=): forwards per in-flight slot the host may have enqueued (run-ahead bound)")
-    ap.add_argument("--caller-stream", action="store_true",
-                    help="submit and collect on the process's current stream (the pre-round-3 loop) instead of a submit stream and a "
-                         "result stream: every submit() is then ordered behind the previous result()'s wait, and - with the 4x4s on the "
-                         "device - the host waits for it")
+    ap.add_argument("--no-forward-api", action="store_true", help="skip the forward_api measurement")
+    ap.add_argument("--stream-collect", action="store_true",
+                    help="collect results with handle.result() (the caller's stream waits for the forward) right after the next submit, "
+                         "as before round 3, instead of handle.synchronize() (the host waits) right before the submit that reuses the slot")
+    ap.add_argument("--side-streams", action="store_true",
+                    help="submit under one side stream and take results under another instead of the process's current stream "
+                         "(measured in round 3: 5-15 %% SLOWER in every combination - kept as a switch for that measurement)")
     ap.add_argument("--host-mats", action="store_true",
                     help="keep the 4x4 pose / intrinsics matrices of the resident batch on the host (what kitti.DeviceLoader hands out): "
                          "submit() then never waits for a device-to-host copy of them")
@@ -210,8 +213,11 @@ def with_data_loading(model, dev, frames, depths, steps=60, in_flight=2):
         return a
     threads = max(1, min(8, (os.cpu_count() or 2) - 1))
     cache = input_pipeline.FrameCache(load, pre, capacity=8, workers=threads)
-    k = input_pipeline.format_intrinsics(intr, (256, 512)).unsqueeze(0).to(dev)
-    base = synth.clone_batch(synth.make_batch(1, 256, 512, frames, seed=1), dev)
+    k = input_pipeline.format_intrinsics(intr, (256, 512)).unsqueeze(0)             # 4x4s stay on the host (kitti.KittiOdometryDataset)
+    base_cpu = synth.make_batch(1, 256, 512, frames, seed=1)
+    base = synth.clone_batch(base_cpu, dev)
+    for key in ("keyframe_pose", "poses"):
+        base[key] = base_cpu[key]
     pending = collections.deque()
 
     def run(n, first):
@@ -427,30 +433,35 @@ def main():
     pending = collections.deque()
     last = [None]
 
-    # The inputs are resident and final before the loop starts, and nothing on the process's main stream produces them: requests
-    # are submitted under one stream and results taken under another, so that "inputs ready" of request i+1 is not ordered behind
-    # the wait for result i-1 (on ONE stream it is - and with the 4x4 matrices on the device the host then waits for that result
-    # before it can form the projection matrices, i.e. enqueues every keyframe only when its slot has drained).
+    # Requests are submitted and results taken on the process's current stream, like any PyTorch loop.  (--side-streams: one stream
+    # for submit(), one for result(), so that "inputs ready" of request i+1 is not ordered behind the wait for result i-1.)
     torch.cuda.synchronize()
-    s_submit = torch.cuda.current_stream() if args.caller_stream else torch.cuda.Stream()
-    s_result = torch.cuda.current_stream() if args.caller_stream else torch.cuda.Stream()
+    s_submit = torch.cuda.current_stream() if (not args.side_streams) else torch.cuda.Stream()
+    s_result = torch.cuda.current_stream() if (not args.side_streams) else torch.cuda.Stream()
 
     def step():
-        """One forward over one resident batch.  With --in-flight N the result of step i is collected when step
-        i+N-1 has been enqueued (keyframes are independent); every step's outputs are produced inside the
-        timed region (the queue is drained before the closing synchronize)."""
+        """One forward over one resident batch.  With --in-flight N keyframes in flight the result of step i - N is collected right
+        before step i is submitted (its slot is the one step i reuses; keyframes are independent); every step's outputs are produced
+        inside the timed region (the queue is drained before the closing synchronize).  Results are collected by waiting on the HOST
+        (`handle.synchronize()`): a stream-side wait (`handle.result()`, --stream-collect) parks a blocked barrier packet in the
+        caller's hardware queue for a whole keyframe, and blocked packets slow the other queues down."""
         with torch.no_grad():
-            with torch.cuda.stream(s_submit):
+            if args.stream_collect:
+                with torch.cuda.stream(s_submit):
+                    pending.append(model.submit(dict(batch_dev)))
+                if len(pending) >= args.in_flight:
+                    with torch.cuda.stream(s_result):
+                        last[0] = pending.popleft().result()
+            else:
+                if len(pending) >= args.in_flight:
+                    last[0] = pending.popleft().synchronize()
                 pending.append(model.submit(dict(batch_dev)))
-            if len(pending) >= args.in_flight:
-                with torch.cuda.stream(s_result):
-                    last[0] = pending.popleft().result()
         return last[0]
 
     def drain():
         with torch.cuda.stream(s_result):
             while pending:
-                last[0] = pending.popleft().result()
+                last[0] = pending.popleft().result() if args.stream_collect else pending.popleft().synchronize()
         torch.cuda.current_stream().wait_stream(s_result)
         return last[0]
 
@@ -589,7 +600,8 @@ def main():
                                       "bf16 MFMA convolutions (fp32 storage and cost volume), " if args.bf16 else "fp32, ") + "random-init weights",
                        "batch_per_gpu": args.batch, "hip_graph": args.graph, "keyframes_in_flight": args.in_flight,
                        "host_queue_depth_per_slot": args.queue_depth, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "submit_and_result_streams": "caller's" if args.caller_stream else "one stream for submit(), one for result()",
+                       "results_collected_by": "stream wait (handle.result())" if args.stream_collect else "host wait (handle.synchronize())",
+                       "submit_and_result_streams": "caller's" if (not args.side_streams) else "one stream for submit(), one for result()",
                        "pose_matrices": "host" if args.host_mats else "device",
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
             "roofline": roof,
@@ -606,7 +618,7 @@ def main():
                                            "at batch 1 both launches are latency chains (launch floor ~6 us each), not bandwidth"},
             "device_ms_per_step_sum_of_kernels": sum(r["seconds"] for r in rows) * 1e3,
         }
-        if world == 1:
+        if world == 1 and not args.no_forward_api:
             result["forward_api"] = forward_api(model, batch_dev, args.batch)
         if args.dump_layers:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_layers)), exist_ok=True)

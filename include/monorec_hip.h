@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 8
+#define MR_ABI_VERSION 9
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -295,6 +295,17 @@ typedef struct mr_copy_segment {
     int64_t bytes;
 } mr_copy_segment;
 int mr_copy_segments(const mr_copy_segment* segments, int32_t num_segments, void* stream);
+
+/* Host helper of the cost-volume launch: 1 when the 3-instruction reciprocal sequence the kernels use for `u / (W - 1)`, `v / (H - 1)`
+ * (model/layers.py:67-68) reproduces the correctly rounded fp32 quotient for every dividend (exhaustive over a binade, cached per
+ * divisor), 0 when the launch must use IEEE division for this divisor.  Exposed so that tests can pin the verdicts. */
+int mr_exact_const_division(float divisor);
+
+/* `num` (<= MR_MAX_GATHER) small fp32 tensors of `floats_each` elements each, anywhere in device memory, -> dst[num][floats_each],
+ * one launch.  MonoRecModel uses it to bring the 4x4 pose / intrinsics matrices of a forward (monorec_model.py:160-171: they feed
+ * torch.inverse / matmul, which this implementation runs with the reference's CPU operators) into device-writable pinned host memory. */
+#define MR_MAX_GATHER (2 + 2 * MR_MAX_FRAMES)
+int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_each, float* dst, void* stream);
 
 /* ResnetEncoder input normalisation ((x + 0.5) - 0.45) / 0.225, elementwise (monorec_model.py:691 + :120);
  * count % 4 == 0.  (MR_TF_RESNET_NORM does the same while staging inside mr_conv2d_f32.) */

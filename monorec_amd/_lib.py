@@ -68,7 +68,7 @@ class WinoDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 8             # include/monorec_hip.h
+MR_ABI_VERSION = 9             # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -138,6 +138,8 @@ ABI = {
     "mr_maxpool2x2_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_void_p]),
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_exact_const_division": (ctypes.c_int, [ctypes.c_float]),
+    "mr_gather_small_f32": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_copy_segments": (ctypes.c_int, [ctypes.POINTER(CopySegment), ctypes.c_int32, ctypes.c_void_p]),
     "mr_max_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                               ctypes.c_void_p]),

@@ -25,8 +25,11 @@
 // chain; ATen grid_sampler unnormalise + bilinear FMA chain; see oracle/make_golden.py for the
 // bitwise pinning), so warped samples, SSIM values and the validity mask reproduce the CPU bits.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/monorec_hip.h"
 
@@ -47,6 +50,10 @@ struct CvArgs {
     float cw[3];          // channel_weight / 9 (fp32 division, monorec_model.py:141)
     float inv_dm1;        // fp32(1/(D-1)) (python double division, then cast; :258)
     int border;           // border_radius = patch_size / 2 + 1 (monorec_model.py:139); 2 for the default 3x3 patch
+    float wm1, hm1;       // fp32(W - 1), fp32(H - 1): the divisors of layers.py:67-68
+    float rwm1, rhm1;     // fp32(1 / wm1), fp32(1 / hm1)
+    int fast_w, fast_h;   // 1: the 3-instruction sequence div_const() equals the correctly rounded quotient for EVERY fp32 dividend
+                          // (checked exhaustively on the host, mr_exact_const_division); 0: IEEE division
 };
 
 // a / 9.0f in 3 instructions instead of the ~10 of the IEEE division sequence: q0 = a*y, r = fma(-9, q0, a),
@@ -60,6 +67,24 @@ __device__ __forceinline__ float div9(float a) {
     return fmaf(r, y, q0);
 }
 
+// a / d for the constant divisors W - 1 / H - 1 of layers.py:67-68 by the same 3-instruction sequence (y = fp32(1/d)) - used only
+// where the host has checked the sequence against the correctly rounded quotient for all 2^24 mantissas of the dividend (it is
+// scale invariant, cannot overflow because |y| < 1, and a dividend small enough to underflow vanishes in `u - 0.5` anyway);
+// `fast` is a kernel argument, i.e. wave-uniform.  The pixel coordinate decides validity: this division stays bit-exact.
+__device__ __forceinline__ float div_const(float a, float d, float y, int fast) {
+    if (fast) {
+        const float q0 = a * y;
+        const float r = fmaf(-d, q0, a);
+        return fmaf(r, y, q0);
+    }
+    return a / d;
+}
+
+// The SSIM ratio of layers.py:137.  The reference divides; here v_rcp_f32 (1 ulp) and one multiply: the quotient lies in [-1, 1],
+// so the result moves by <= 2e-7 and the sad by <= 1e-7 - it feeds nothing index-like (round 3: -8 VALU instructions per channel).
+// sd >= C1 * C2 = 9e-8: a normal number, never 0.
+__device__ __forceinline__ float ssim_ratio(float sn, float sd) { return sn * __builtin_amdgcn_rcpf(sd); }
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {  // nn.ReflectionPad2d(1), layers.py:112
     return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
 }
@@ -70,7 +95,7 @@ struct Sample {
     float nw, ne, sw, se;
 };
 
-__device__ __forceinline__ Sample project(float r0, float r1, float r2, float depth, const float* P, int H, int W) {
+__device__ __forceinline__ Sample project(float r0, float r1, float r2, float depth, const float* P, int H, int W, const CvArgs& a) {
     // cam point = depth * ray (monorec_model.py:200); pc = P[:, :3] X + P[:, 3] as MKL's k-ascending FMA chain
     const float X0 = depth * r0, X1 = depth * r1, X2 = depth * r2;
     const float pcx = fmaf(P[3], 1.0f, fmaf(P[2], X2, fmaf(P[1], X1, P[0] * X0)));
@@ -78,8 +103,8 @@ __device__ __forceinline__ Sample project(float r0, float r1, float r2, float de
     const float pcz = fmaf(P[11], 1.0f, fmaf(P[10], X2, fmaf(P[9], X1, P[8] * X0)));
     const float z = pcz + 1e-7f;                       // layers.py:66
     float u = pcx / z, v = pcy / z;
-    u = u / (float)(W - 1);                            // layers.py:67
-    v = v / (float)(H - 1);                            // layers.py:68
+    u = div_const(u, a.wm1, a.rwm1, a.fast_w);         // layers.py:67
+    v = div_const(v, a.hm1, a.rhm1, a.fast_h);         // layers.py:68
     u = fminf(fmaxf((u - 0.5f) * 2.0f, -2.0f), 2.0f);  // layers.py:69 + clamp(-2,2) monorec_model.py:208
     v = fminf(fmaxf((v - 0.5f) * 2.0f, -2.0f), 2.0f);
     // grid_sample(align_corners=False): unnormalise as fma(g + 1, size/2, -0.5) (ATen GridSamplerKernel)
@@ -244,7 +269,7 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
             const float* pd = PIXD ? a.pix_depths + ((long long)b * D + d + u) * HWp : nullptr;
             float* wru = wr + u * 3 * HY * HX;
             if (own_in) {
-                const Sample sp = project(ro[0], ro[1], ro[2], PIXD ? pd[opy * W + opx] : depth, P, H, W);
+                const Sample sp = project(ro[0], ro[1], ro[2], PIXD ? pd[opy * W + opx] : depth, P, H, W, a);
                 hit_all = hit_all && mask_hit(sp, H, W);                   // monorec_model.py:218-219
                 const Taps tp = tap_offsets(sp, H, W);
                 bool any_nz = false, all_eq = true;
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                 pflag[u] = any_nz || all_eq;                                     // :253
             }
             if (has_halo) {
-                const Sample sp = project(rh[0], rh[1], rh[2], PIXD ? pd[hpy * W + hpx] : depth, P, H, W);
+                const Sample sp = project(rh[0], rh[1], rh[2], PIXD ? pd[hpy * W + hpx] : depth, P, H, W, a);
                 const Taps tp = tap_offsets(sp, H, W);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                                 const float sig_xy = div9(sxy) - mu_xy;
                                 const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);          // layers.py:133
                                 const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[r][c] + C2); // layers.py:134
-                                sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);               // layers.py:137
+                                sv = fminf(fmaxf((1.0f - ssim_ratio(sn, sd)) / 2.0f, 0.0f), 1.0f);               // layers.py:137
                             }
                             if (MODE == 0 || MODE == 2) {                                             // |warped - keyframe|, :228,239
                                 const int li = (c * HY + sly[r] + 1) * HX + slx[r] + 1;
@@ -427,8 +452,17 @@ __device__ __forceinline__ void div9_batch(float (&a)[N]) {
 }
 
 // project() for N depth hypotheses of one pixel ray, stage by stage (same operations, same order per hypothesis)
-template <int N>
-__device__ __forceinline__ void project_batch(Sample (&o)[N], float r0, float r1, float r2, const float (&depth)[N], const float* P, int H, int W) {
+// hit[i]: the bilinear sample of the border mask (ones inside a 2-pixel frame, monorec_model.py:282-284) at the sample position is
+// != 0 (:218-219), evaluated as logic instead of the reference's 4-term FMA chain: all terms are >= 0, so the chain is 0 iff every
+// term is, and a term is mask(tap) * wy * wx with wy in {s, n}, wx in {e, w} - the weights of a tap inside the frame (coordinate
+// >= 2, hence sx, sy >= 1) are 0 or >= 2^-24, their product never underflows.  Hence hit = ((top in frame & s != 0) | (bottom in
+// frame & n != 0)) & ((left in frame & e != 0) | (right in frame & w != 0)) - exactly the reference's result, ~12 instead of ~25
+// VALU instructions.
+// FD (compile time - a branch inside the marching step, even a uniform one, splits the basic block and the DPP shifts stop folding
+// into their adds): both constant divisions by the exact 3-instruction sequence (the host checked both divisors), else IEEE.
+template <int N, bool FD>
+__device__ __forceinline__ void project_batch(Sample (&o)[N], bool (&hit)[N], float r0, float r1, float r2, const float (&depth)[N], const float* P,
+                                              int H, int W, const CvArgs& a) {
     float X0[N], X1[N], X2[N], px[N], py[N], pz[N], u[N], v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { X0[i] = depth[i] * r0; X1[i] = depth[i] * r1; X2[i] = depth[i] * r2; }
@@ -445,7 +479,7 @@ __device__ __forceinline__ void project_batch(Sample (&o)[N], float r0, float r1
 #pragma unroll
     for (int i = 0; i < N; ++i) { u[i] = px[i] / pz[i]; v[i] = py[i] / pz[i]; }
 #pragma unroll
-    for (int i = 0; i < N; ++i) { u[i] = u[i] / (float)(W - 1); v[i] = v[i] / (float)(H - 1); }              // layers.py:67-68
+    for (int i = 0; i < N; ++i) { u[i] = div_const(u[i], a.wm1, a.rwm1, FD ? 1 : 0); v[i] = div_const(v[i], a.hm1, a.rhm1, FD ? 1 : 0); }   // layers.py:67-68
 #pragma unroll
     for (int i = 0; i < N; ++i) {                                       // layers.py:69 + clamp(-2,2) monorec_model.py:208
         u[i] = fminf(fmaxf((u[i] - 0.5f) * 2.0f, -2.0f), 2.0f);
@@ -460,6 +494,10 @@ __device__ __forceinline__ void project_batch(Sample (&o)[N], float r0, float r1
         o[i].x0 = (int)fx;
         o[i].y0 = (int)fy;
         o[i].nw = s_ * e; o[i].ne = s_ * w; o[i].sw = n * e; o[i].se = n * w;
+        const unsigned fw = (unsigned)(W - 4), fh = (unsigned)(H - 4);          // columns / rows inside the 2-pixel frame
+        const bool lft = (unsigned)(o[i].x0 - 2) < fw && e != 0.f, rgt = (unsigned)(o[i].x0 - 1) < fw && w != 0.f;
+        const bool top = (unsigned)(o[i].y0 - 2) < fh && s_ != 0.f, bot = (unsigned)(o[i].y0 - 1) < fh && n != 0.f;
+        hit[i] = (lft || rgt) && (top || bot);
     }
 }
 
@@ -511,7 +549,7 @@ struct MarchCtx {
     float depth[DP];
     const float* pixd;      // per-pixel depths of plane d0 of this sample, or null
     const float* kstats;    // prepass output of this sample: 3 planes of the keyframe's 3x3 mean, 3 of its variance (KFS), or null
-    float* out;             // raw sad plane d0 of frame f, sample b
+    __amdgpu_buffer_rsrc_t outr;   // raw sad planes d0 .. d0 + DP - 1 of frame f, sample b
     int cx, vx, y0, y1;
     bool col_in, out_lane;
 };
@@ -519,7 +557,7 @@ struct MarchCtx {
 // One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
 // sad of output row r - 2 (box over the e rows), then turn `mid` into the next top sums.  The caller alternates two MarchRow
 // objects as mid / cur, so the raw rows never move between registers.
-template <int DP, bool PIXD, bool KFS>
+template <int DP, bool PIXD, bool KFS, bool FD>
 __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid, MarchRow<DP, KFS>& cur,
                                            unsigned (&hits)[DP]) {
     constexpr int NQ = DP * 9 + (KFS ? 0 : 6), KQ = DP * 9;
@@ -542,10 +580,11 @@ __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRo
     float dep[DP];
 #pragma unroll
     for (int u = 0; u < DP; ++u) dep[u] = PIXD ? c.pixd[(long long)u * HWp + pix] : c.depth[u];
-    project_batch<DP>(sp, ray[0], ray[1], ray[2], dep, c.P, H, W);
+    bool hit[DP];
+    project_batch<DP, FD>(sp, hit, ray[0], ray[1], ray[2], dep, c.P, H, W, a);
 #pragma unroll
     for (int u = 0; u < DP; ++u) {
-        hits[u] = (hits[u] << 1) | (mask_hit(sp[u], H, W) ? 1u : 0u);     // monorec_model.py:218-219
+        hits[u] = (hits[u] << 1) | (hit[u] ? 1u : 0u);                    // monorec_model.py:218-219
         tp[u] = tap_offsets(sp[u], H, W);
     }
     float xw[DP * 3];
@@ -601,7 +640,7 @@ __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRo
 #pragma unroll
     for (int i = 0; i < NS; ++i) sd[i] = (mu_x_sq[i] + kmu2[i % 3] + C1) * (sig_x[i] + ksg[i % 3] + C2);         // layers.py:134
 #pragma unroll
-    for (int i = 0; i < NS; ++i) sv[i] = fminf(fmaxf((1.0f - sn[i] / sd[i]) / 2.0f, 0.0f), 1.0f);                // layers.py:137
+    for (int i = 0; i < NS; ++i) sv[i] = fminf(fmaxf((1.0f - ssim_ratio(sn[i], sd[i])) / 2.0f, 0.0f), 1.0f);                // layers.py:137
 #pragma unroll
     for (int u = 0; u < DP; ++u) {
         const float ev = fmaf(sv[u * 3 + 2], a.cw[2], fmaf(sv[u * 3 + 1], a.cw[1], sv[u * 3] * a.cw[0]));
@@ -609,13 +648,16 @@ __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRo
     }
     // ---- 3x3 box over e rows r-3, r-2, r-1 -> sad of output row y = r - 2 ---------------------------------------------
     const int y = r - 2;
-    if (y >= c.y0 && y < c.y1) {                                            // wave-uniform
+    {   // no branch: a row outside the segment / a halo lane stores through an out-of-range offset (dropped by the descriptor) - one
+        // basic block per step keeps every DPP shift next to the add it folds into
         float sad[DP];
         win9_batch<DP>(sad, top.e, mid.e, cur.e);
+        const bool st = (y >= c.y0) & (y < c.y1) & c.out_lane;
+        const int voff = st ? (y * W + c.vx) * 4 : -1;
 #pragma unroll
         for (int u = 0; u < DP; ++u) {
             if (!(hits[u] & 4u)) sad[u] = -sad[u];                          // sad >= 0: the sign bit is free (-0.0 keeps it)
-            if (c.out_lane) c.out[(long long)u * HWp + y * W + c.vx] = sad[u];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sad[u]), c.outr, voff, u * HWp * 4, 0);
         }
     }
     // ---- the middle row becomes the top row of the next step (as horizontal sums) -----------------------------------------
@@ -654,7 +696,7 @@ __global__ __launch_bounds__(256) void cv_kf_stats_kernel(const CvArgs a) {
     }
 }
 
-template <int DP, bool PIXD, bool KFS>
+template <int DP, bool PIXD, bool KFS, bool FD>
 __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const MarchGeom g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -679,7 +721,7 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
                       __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000),
                       {0.f, 0.f, 0.f}, {}, PIXD ? a.pix_depths + ((long long)b * D + d0) * HWp : nullptr,
                       KFS ? a.cv + (long long)b * D * HWp : nullptr,
-                      a.sfcv[f] + ((long long)b * D + d0) * HWp,
+                      __builtin_amdgcn_make_buffer_rsrc((void*)(a.sfcv[f] + ((long long)b * D + d0) * HWp), 0, DP * HWp * 4, 0x00020000),
                       cx, vx, y0, min(y0 + g.TY, H),
                       vx >= 0 && vx < W,                      // SSIM positions outside the image contribute 0 to the box (:247)
                       lane >= 2 && lane < 2 + g.pitch && vx < W};
@@ -694,8 +736,8 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
     for (int u = 0; u < DP; ++u) hits[u] = 0u;
     const int r_last = c.y1 + 1;
     for (int r = y0 - 2; r <= r_last; r += 2) {
-        march_step<DP, PIXD, KFS>(c, r, top, rowA, rowB, hits);
-        if (r + 1 <= r_last) march_step<DP, PIXD, KFS>(c, r + 1, top, rowB, rowA, hits);
+        march_step<DP, PIXD, KFS, FD>(c, r, top, rowA, rowB, hits);
+        if (r + 1 <= r_last) march_step<DP, PIXD, KFS, FD>(c, r + 1, top, rowB, rowA, hits);
     }
 }
 
@@ -847,7 +889,7 @@ __global__ __launch_bounds__(256) void cv_sad_patch_kernel(const CvArgs a, const
             float ray[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) ray[k] = fmaf(Ki[3 * k + 2], 1.0f, fmaf(Ki[3 * k + 1], (float)gy, Ki[3 * k] * (float)gx));
-            const Sample sp = project(ray[0], ray[1], ray[2], PIXD ? pd[gy * W + gx] : plane_depth, P, H, W);
+            const Sample sp = project(ray[0], ray[1], ray[2], PIXD ? pd[gy * W + gx] : plane_depth, P, H, W, a);
             const Taps tp = tap_offsets(sp, H, W);
 #pragma unroll
             for (int c = 0; c < 3; ++c) wr[(c * HY + ly) * HX + lx] = bilinear(img, c * HWp * 4, tp, sp) + 0.5f;
@@ -856,7 +898,7 @@ __global__ __launch_bounds__(256) void cv_sad_patch_kernel(const CvArgs a, const
             float ray[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) ray[k] = fmaf(Ki[3 * k + 2], 1.0f, fmaf(Ki[3 * k + 1], (float)opy, Ki[3 * k] * (float)opx));
-            const Sample sp = project(ray[0], ray[1], ray[2], PIXD ? pd[opy * W + opx] : plane_depth, P, H, W);
+            const Sample sp = project(ray[0], ray[1], ray[2], PIXD ? pd[opy * W + opx] : plane_depth, P, H, W, a);
             hit_all = hit_all && mask_hit_r(sp, H, W, a.border);          // monorec_model.py:218-219
             const Taps tp = tap_offsets(sp, H, W);
             bool any_nz = false, all_eq = true;
@@ -902,7 +944,7 @@ __global__ __launch_bounds__(256) void cv_sad_patch_kernel(const CvArgs a, const
                         const float sig_xy = div9(sxy) - mu_xy;
                         const float sn = (2.0f * mu_xy + C1) * (2.0f * sig_xy + C2);                      // layers.py:133
                         const float sd = (mu_x_sq + mu_y_sq + C1) * (sig_x + ksg[c * SY * SX + i] + C2);  // layers.py:134
-                        sv = fminf(fmaxf((1.0f - sn / sd) / 2.0f, 0.0f), 1.0f);                           // layers.py:137
+                        sv = fminf(fmaxf((1.0f - ssim_ratio(sn, sd)) / 2.0f, 0.0f), 1.0f);                           // layers.py:137
                     }
                     if (MODE == 0 || MODE == 2) {
                         const int li = (c * HY + sy + 1) * HX + sx + 1;
@@ -1087,15 +1129,21 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         const MarchGeom g = march_geometry(a, dp1 ? 1 : 2);
         const dim3 grid((unsigned)(g.strips * g.ysegs), (unsigned)(a.F * ((g.npairs + 3) / 4)), (unsigned)a.B);
         static const bool no_prepass = getenv("MR_CV_NO_KF_PREPASS") != nullptr;           // A/B aid
-        if (dp1) {                           // twice the waves, each with one plane: for shapes that leave the SIMDs short of waves
+        const bool fd = a.fast_w && a.fast_h;  // both constant divisions by the exact 3-instruction sequence (checked on the host)
+        const bool kfs = dp1 || (a.D >= 6 && !no_prepass);
+        if (kfs)                             // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
             hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
-            hipLaunchKernelGGL((cv_sad_march_kernel<1, false, true>), grid, dim3(256), 0, stream, k, g);
-        } else if (a.D >= 6 && !no_prepass) {       // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
-            hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
-            if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true, true>), grid, dim3(256), 0, stream, k, g);
-            else hipLaunchKernelGGL((cv_sad_march_kernel<2, false, true>), grid, dim3(256), 0, stream, k, g);
-        } else if (a.pix_depths) hipLaunchKernelGGL((cv_sad_march_kernel<2, true, false>), grid, dim3(256), 0, stream, k, g);
-        else hipLaunchKernelGGL((cv_sad_march_kernel<2, false, false>), grid, dim3(256), 0, stream, k, g);
+#define MR_MARCH(DP_, PIXD_, KFS_)                                                                                              \
+    do {                                                                                                                        \
+        if (fd) hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, true>), grid, dim3(256), 0, stream, k, g);               \
+        else hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, false>), grid, dim3(256), 0, stream, k, g);                 \
+    } while (0)
+        if (dp1) MR_MARCH(1, false, true);   // twice the waves, each with one plane: for shapes that leave the SIMDs short of waves
+        else if (kfs && a.pix_depths) MR_MARCH(2, true, true);
+        else if (kfs) MR_MARCH(2, false, true);
+        else if (a.pix_depths) MR_MARCH(2, true, false);
+        else MR_MARCH(2, false, false);
+#undef MR_MARCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         launch_fuse(k, false, false, stream);
@@ -1192,12 +1240,43 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
     for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / (float)(patch_size * patch_size);      // :141
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
     a.border = patch_size / 2 + 1;                                                                   // :139
+    a.wm1 = (float)(width - 1); a.hm1 = (float)(height - 1);
+    a.rwm1 = 1.0f / a.wm1; a.rhm1 = 1.0f / a.hm1;
+    a.fast_w = mr_exact_const_division(a.wm1); a.fast_h = mr_exact_const_division(a.hm1);
     if (height < 2 * a.border + 1 || width < 2 * a.border + 1) return MR_ERR_BAD_ARGUMENT;
     if (patch_size == 3) return launch_cv<32, 16>(a, use_ssim, !sfcv_mult_mask, tiled, (hipStream_t)stream);
     return launch_cv_patch(a, use_ssim, !sfcv_mult_mask, patch_size / 2, (hipStream_t)stream);
 }
 
 }  // namespace
+
+// 1 when q = fma(r, y, q0), q0 = a * y, r = fma(-d, q0, a), y = fp32(1 / d) equals the correctly rounded fp32 quotient a / d for EVERY
+// dividend: all 2^23 mantissas of one binade are tried (the sequence is scale invariant; |y| < 1 excludes overflow), once per divisor
+// and process (~40 ms), the verdict is cached.  The cost-volume kernels then divide by W - 1 / H - 1 (layers.py:67-68) in 3
+// instructions instead of the ~10 of the IEEE sequence without giving up a bit (Markstein's correction step; every divisor tried so far
+// passes - 511, 255 (c2), 1023 (configs[4]), 95, 63 - the check is what makes that a fact per divisor rather than a belief).
+extern "C" int mr_exact_const_division(float d) {
+    if (!(d > 1.0f) || !(d < 1e30f)) return 0;
+    static std::mutex mu;
+    static std::map<uint32_t, int> verdict;
+    uint32_t key;
+    memcpy(&key, &d, 4);
+    std::lock_guard<std::mutex> lock(mu);
+    const auto it = verdict.find(key);
+    if (it != verdict.end()) return it->second;
+    const float y = 1.0f / d;
+    int ok = 1;
+    for (uint32_t m = 0x4b000000u; m < 0x4b800000u && ok; ++m) {       // [2^23, 2^24)
+        float a;
+        memcpy(&a, &m, 4);
+        const float q0 = a * y;
+        const float r = fmaf(-d, q0, a);
+        const float q = fmaf(r, y, q0);
+        if (q != a / d) ok = 0;
+    }
+    verdict[key] = ok;
+    return ok;
+}
 
 extern "C" int mr_cost_volume_patch_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
                                        const float* kinv, const float* proj, const float* depths,

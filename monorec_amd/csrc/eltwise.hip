@@ -209,6 +209,22 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const CopyArgs a) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// The 4x4 pose / intrinsics matrices of one forward (2 + 2 F tensors of 16 B floats each, anywhere in device memory) -> one pinned host
+// buffer the device can write (hipHostMalloc): the host-side pose algebra of MonoRecModel needs them back (model.host_geometry).  One
+// launch instead of an ATen stack + a copy-engine transfer - and its completion is a compute-queue marker, which the host can wait
+// for with far less wake-up latency than for the end of a small SDMA copy (measured: ~1 ms after a long wait).
+struct GatherArgs {
+    const float* src[MR_MAX_GATHER];
+    float* dst;
+    int count;
+};
+
+__global__ __launch_bounds__(64) void gather_small_kernel(const GatherArgs a) {
+    const float* __restrict__ s = a.src[blockIdx.x];
+    float* d = a.dst + (long long)blockIdx.x * a.count;
+    for (int i = threadIdx.x; i < a.count; i += 64) d[i] = s[i];
+}
+
 }  // namespace
 
 extern "C" int mr_maxpool3x3s2_f32(const float* src, float* dst, int32_t planes, int32_t in_h, int32_t in_w, void* stream) {
@@ -293,6 +309,19 @@ extern "C" int mr_copy_segments(const mr_copy_segment* segments, int32_t num_seg
     const long long blocks = (most + 255) / 256;
     hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)num_segments), dim3(256), 0,
                        (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_each, float* dst, void* stream) {
+    if (!srcs || !dst || num < 1 || num > MR_MAX_GATHER || floats_each < 1) return MR_ERR_BAD_ARGUMENT;
+    GatherArgs a;
+    for (int s = 0; s < MR_MAX_GATHER; ++s) {
+        a.src[s] = s < num ? srcs[s] : nullptr;
+        if (s < num && !a.src[s]) return MR_ERR_BAD_ARGUMENT;
+    }
+    a.dst = dst;
+    a.count = floats_each;
+    hipLaunchKernelGGL(gather_small_kernel, dim3((unsigned)num), dim3(64), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

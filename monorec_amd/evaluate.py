@@ -65,6 +65,11 @@ class Evaluater:
         self.in_flight = max(1, min(int(in_flight), int(getattr(model, "_in_flight", in_flight))))
         self._sums_fn = sums_fn or _metrics.sparse_metric_sums_device   # (B, 8) per-sample sums; injectable for host-logic tests
 
+    # the 4x4 matrices feed the model's HOST-side pose algebra (model.host_geometry): moved to the device they would have to come back,
+    # and submit() would wait for that copy - a loader's CPU matrices are left where they are (the reference moves everything,
+    # evaluater.py:82; the values are the same either way)
+    _HOST_KEYS = ("keyframe_pose", "keyframe_intrinsics", "poses", "intrinsics", "stereoframe_pose", "stereoframe_intrinsics")
+
     @staticmethod
     def _to(obj, device):
         if torch.is_tensor(obj):
@@ -72,7 +77,7 @@ class Evaluater:
         if isinstance(obj, (list, tuple)):
             return [Evaluater._to(o, device) for o in obj]
         if isinstance(obj, dict):
-            return {k: Evaluater._to(v, device) for k, v in obj.items()}
+            return {k: (v if k in Evaluater._HOST_KEYS else Evaluater._to(v, device)) for k, v in obj.items()}
         return obj
 
     def eval(self, data_loader, distributed=False):
@@ -86,7 +91,7 @@ class Evaluater:
 
         def collect():
             data, handle, gidx = pending.popleft()
-            out = handle.result()                                   # ordered behind the forward on the caller's stream
+            out = handle.synchronize()                              # the host waits: no blocked wait packet on the caller's stream
             sums.append(self._sums_fn({"result": out["result"], "target": data["target"]}, self.roi, self.max_distance))
             sizes.append(int(data["target"].shape[0]))
             indices.append(gidx)
@@ -98,9 +103,9 @@ class Evaluater:
                     continue
                 data = self._to(data, device)
                 data["target"] = self._to(target, device)
-                pending.append((data, self.model.submit(data), rank + i * world if presharded else i))
-                if len(pending) >= self.in_flight:
+                if len(pending) >= self.in_flight:                  # the slot the next submit reuses: reduce its result first
                     collect()
+                pending.append((data, self.model.submit(data), rank + i * world if presharded else i))
             while pending:
                 collect()
         per_batch = []

@@ -144,7 +144,6 @@ class KittiOdometryDataset:
         self._decode_workers = int(decode_workers)
         self._cache_frames = int(cache_frames) if cache_frames is not None else 2 * (frame_count * dilation + 2)
         self._caches = {}                # (dataset index, camera) -> FrameCache
-        self._dev_intrinsics = None
 
     # ------------------------------------------------------------------ bookkeeping like the reference
     def __len__(self):
@@ -216,12 +215,14 @@ class KittiOdometryDataset:
             index = self._indices[dataset_index][index] - self._offset
         seq = self._datasets[dataset_index]
         key = index + self._offset
-        if self._dev_intrinsics is None:
-            self._dev_intrinsics = [k.to(self._device) for k in self._intrinsics]
-        k = self._dev_intrinsics[dataset_index]
+        # The 4x4 pose / intrinsics matrices stay on the HOST: MonoRecModel forms its projection matrices with the reference's CPU
+        # operators (model.host_geometry) - matrices handed over on the device would have to come back first, and submit() would wait
+        # for that copy behind everything queued on the caller's stream.  (A loop that moves them to the device anyway - the
+        # reference's `to(data, device)`, evaluater.py:82 - still works; monorec_amd.evaluate.Evaluater leaves them where they are.)
+        k = self._intrinsics[dataset_index]
         cache = self._cache(dataset_index, self._cam)
         sources = [key + i + self.offset_d for i in self._neighbour_offsets()]
-        pose = lambda j: torch.tensor(seq.poses[j], dtype=torch.float32).to(self._device, non_blocking=True)
+        pose = lambda j: torch.tensor(seq.poses[j], dtype=torch.float32)
         data = {
             "keyframe": cache.frame(key),
             "keyframe_pose": pose(key),
@@ -234,7 +235,7 @@ class KittiOdometryDataset:
         }
         if self.return_stereo:                              # :272-279
             data["stereoframe"] = self._cache(dataset_index, self._cam + 1).frame(key)
-            data["stereoframe_pose"] = (torch.tensor(seq.poses[key], dtype=torch.float32) @ self._stereo_transform[dataset_index]).to(self._device)
+            data["stereoframe_pose"] = torch.tensor(seq.poses[key], dtype=torch.float32) @ self._stereo_transform[dataset_index]
             data["stereoframe_intrinsics"] = k
         if self.return_mvobj_mask > 0:                      # :281-285
             path = os.path.join(self.dataset_dir, "sequences", self.sequences[dataset_index], "mvobj_mask", f"{key:06d}.npy")

@@ -9,6 +9,7 @@ launch plan in `engine.py`.  There is no PyTorch/CPU fallback: calling `forward`
 or without the built library raises.
 """
 import collections
+import ctypes
 import threading
 import time
 import warnings
@@ -200,6 +201,15 @@ def host_geometry(keyframe_intrinsics, keyframe_pose, intrinsics, poses):
     return kinv, proj
 
 
+def _host_wait(event):
+    """Block the host until `event` has happened - by polling.  hipEventSynchronize polls only for a while and then sleeps, and a
+    sleeping wait wakes up late (measured on MI355X / ROCm 7: sequential forwards of 2 ms each went to 3.2 ms once the wait inside
+    submit() crossed ~2 ms).  These waits are short or end with work for the host, so it keeps polling; the GIL is released between
+    polls (nn.DataParallel drives replicas from threads)."""
+    while not event.query():
+        time.sleep(0)
+
+
 def depth_hypotheses(inv_depth_min_max, steps):
     """monorec_model.py:675-677,184: the bounds pass through fp32 tensors and `.item()` before linspace."""
     lo = torch.tensor([inv_depth_min_max[1]], dtype=torch.float32)[0].item()
@@ -216,7 +226,7 @@ class MonoRecModel(nn.Module):
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1, hip_queue_depth=2):
+                 hip_batch_keyframes=1, hip_queue_depth=1):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -255,8 +265,8 @@ class MonoRecModel(nn.Module):
         self._open_group = None
         # how far the host may run ahead of the GPU: submit() blocks until all but the last `hip_queue_depth - 1` earlier forwards of
         # the slot it is about to reuse have finished, i.e. at most hip_in_flight * hip_queue_depth forwards are ever enqueued.
-        # (Enqueueing a forward takes the host ~0.3-0.6 ms; kept >= one forward ahead, the slot streams never run dry between
-        # keyframes - measured +10 % keyframes/s against enqueueing each forward only once its slot is free.)
+        # Measured (round 3, 48-run grid tools/sessions/r03_s3.sh): 1 is best - a forward enqueued while its slot is still busy
+        # (depth 2 and more) costs 5-7 % keyframes/s, whatever stream the requests come in on.
         self._queue_depth = max(1, int(hip_queue_depth))
         self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
@@ -615,87 +625,105 @@ class MonoRecModel(nn.Module):
         streams = self._slot_streams(slot, device)
         main, enc, geom = streams["main"], streams["enc"], streams["geom"]
         caller = torch.cuda.current_stream(device)
+        mat_list = [kf_intrinsics, kf_pose] + intrinsics + poses
+        mats_on_host = all(not m.is_cuda for m in mat_list)
+
+        def geometry(hm):
+            # host 4x4 algebra with the same ATen CPU operators as the reference: bit-identical matrices (~0.1 ms)
+            kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+            if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
+                kinv, proj = self._geometry_override
+            return kinv, proj
+
+        # Matrices that already live on the host (a loader that keeps the 4x4s on the CPU, kitti.DeviceLoader) need no device round
+        # trip - and their algebra does not need the slot: it is done BEFORE the host waits for the slot to come free, and the cost
+        # volume (head of the longest launch chain: cost volume -> mask encoder -> mask decoder -> depth) is launched first.
+        geo = geometry([m.detach().float() for m in mat_list]) if mats_on_host else None
         # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time
         while len(plan.enqueued) >= self._queue_depth:
-            plan.enqueued.popleft().synchronize()
+            _host_wait(plan.enqueued.popleft())
         start_time = time.time()
 
+        # The host - not the device - waits for the caller's stream to reach this point and for the streams that took results of this
+        # slot (`.result()` under another current stream; the launches below overwrite what they read).  A launch enqueued behind an
+        # unsatisfied stream dependency sits in its hardware queue as a blocked barrier packet, and blocked packets slow the OTHER
+        # queues down (measured, round 3: sequential forwards 2.1 -> 3.2 ms with the next forward's encoder pre-enqueued behind such a
+        # wait; a stream of requests enqueued one forward ahead 5-7 % slower).  Everything below is therefore enqueued ready to run.
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(caller)
-        # streams other than the caller's that took results of this slot (`.result()` under another current stream): the launches
-        # below overwrite what those streams read, so they are ordered behind everything enqueued there so far (the caller's own
-        # stream is covered by `inputs_ready`)
+        _host_wait(inputs_ready)
         for cs in plan.consumers:
             if cs != caller:
                 ev = torch.cuda.Event()
                 ev.record(cs)
-                main.wait_event(ev)
+                _host_wait(ev)
         plan.consumers.clear()
-        # 1. pose / intrinsics matrices -> pinned host memory.  Their own stream, ordered only behind the caller's inputs: the
-        #    copy must not queue behind the slot's previous keyframe (the host waits for it below).  Matrices that already live
-        #    on the host (a loader that keeps the 4x4s on the CPU) are used in place, without any device round trip.
-        mat_list = [kf_intrinsics, kf_pose] + intrinsics + poses
-        mats_on_host = all(not m.is_cuda for m in mat_list)
+        # Matrices on the device: one small copy into pinned host memory on their own stream, ordered only behind the caller's
+        # inputs (it must not queue behind the slot's previous keyframe: the host waits for it below); the pose-independent encoder
+        # launches are enqueued while it is under way.
         mats_done = None
         if not mats_on_host:
-            geom.wait_event(inputs_ready)
+            dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
+                  m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
             with torch.cuda.stream(geom):
-                mats = torch.stack([m.to(device=device, dtype=torch.float32) for m in mat_list])
-                plan.host_mats.copy_(mats, non_blocking=True)
+                ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
+                _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, plan.host_mats.data_ptr(), geom.cuda_stream),
+                           "mr_gather_small_f32")         # one launch into device-writable pinned memory
                 mats_done = torch.cuda.Event()
                 mats_done.record(geom)
-            mats.record_stream(geom)
-        main.wait_event(inputs_ready)
+            for m in dm:
+                m.record_stream(geom)
         with torch.cuda.stream(main):
-            # 2. images into the slot's resident buffers; ResNet encoder stage (pose independent) on its own stream
             # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
             # captured launches keep their pointers - goes through the slot's resident buffers
             plan.bind_inputs(keyframe, frames, in_place=not self._hip_graph)
             for t in [keyframe] + frames:
                 t.record_stream(main)
                 t.record_stream(enc)
-            enc.wait_stream(main)
-            self._run_stage(key, plan, "encoder", enc)
-            enc_done = torch.cuda.Event()
-            enc_done.record(enc)
-            # ResNet layer4 is output-only (image_features[4]): it keeps running on the encoder stream while the mask /
-            # depth stages proceed, and only the completion event of the keyframe waits for it
-            self._run_stage(key, plan, "encoder_tail", enc)
-            tail_done = torch.cuda.Event()
-            tail_done.record(enc)
+            enc.wait_stream(main)          # behind the inputs and behind the slot's previous main stage (it reads the image features)
 
-            # 3. host 4x4 algebra (same ATen CPU operators as the reference: bit-identical matrices) while the encoder runs,
-            #    then one H2D copy of 9 + 12 F floats per sample
+            def encoder_stage():
+                self._run_stage(key, plan, "encoder", enc)    # ResNet up to layer3, pose independent, its own stream
+                enc_done = torch.cuda.Event()
+                enc_done.record(enc)
+                # ResNet layer4 is output-only (image_features[4]): it keeps running on the encoder stream while the mask /
+                # depth stages proceed, and only the completion event of the keyframe waits for it
+                self._run_stage(key, plan, "encoder_tail", enc)
+                tail_done = torch.cuda.Event()
+                tail_done.record(enc)
+                return enc_done, tail_done
+
+            def cv_stage(kinv, proj):
+                # one H2D copy of 9 + 12 F floats per sample, then cost volume + mask encoder (concurrent with the ResNet stage)
+                if plan.geom_uploaded is not None:
+                    _host_wait(plan.geom_uploaded)            # the slot's previous upload has left the pinned buffer (long ago)
+                plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
+                plan.host_geom[b * 9:].copy_(proj.reshape(-1))
+                plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
+                plan.geom_uploaded = torch.cuda.Event()
+                plan.geom_uploaded.record(main)
+                plan.pix_depths_on = cv_depths is not None
+                if cv_depths is not None:
+                    if tuple(cv_depths.shape) != (b, self.cv_depth_steps, h, w):
+                        raise ValueError(f"cv_depths must be (B, cv_depth_steps, H, W), got {tuple(cv_depths.shape)}")
+                    if "pix_depths" not in plan.buf:
+                        plan.alloc("pix_depths", b, self.cv_depth_steps, h, w)
+                    plan.buf["pix_depths"].copy_(cv_depths)
+                if self.simple_mask and self.pretrain_mode in (0, 2):
+                    # SimpleMaskModule reads a previous prediction from the dict (:453) - KeyError without one, like the reference
+                    plan.buf["prev_depth"].copy_(data_dict["predicted_inverse_depths"][0])
+                if self.pretrain_mode == 3:                   # :711 cv_mask = data_dict["mvobj_mask"].clone()
+                    plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
+                self._run_stage(key, plan, "cv", main)
+
             if mats_on_host:
-                hm = [m.detach().float() for m in mat_list]
+                cv_stage(*geo)
+                enc_done, tail_done = encoder_stage()
             else:
-                mats_done.synchronize()                       # a ~100 byte copy enqueued before the encoder launches: done by now
-                hm = plan.host_mats
-            kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
-            if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
-                kinv, proj = self._geometry_override
-            if plan.geom_uploaded is not None:
-                plan.geom_uploaded.synchronize()              # the slot's previous upload has left the pinned buffer (long ago)
-            plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
-            plan.host_geom[b * 9:].copy_(proj.reshape(-1))
-            plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
-            plan.geom_uploaded = torch.cuda.Event()
-            plan.geom_uploaded.record(main)
-
-            plan.pix_depths_on = cv_depths is not None
-            if cv_depths is not None:
-                if tuple(cv_depths.shape) != (b, self.cv_depth_steps, h, w):
-                    raise ValueError(f"cv_depths must be (B, cv_depth_steps, H, W), got {tuple(cv_depths.shape)}")
-                if "pix_depths" not in plan.buf:
-                    plan.alloc("pix_depths", b, self.cv_depth_steps, h, w)
-                plan.buf["pix_depths"].copy_(cv_depths)
-            # 4. cost volume + mask encoder (concurrent with the ResNet stage), then join: mask decoder -> depth
-            if self.simple_mask and self.pretrain_mode in (0, 2):
-                # SimpleMaskModule reads a previous prediction from the dict (:453) - KeyError without one, like the reference
-                plan.buf["prev_depth"].copy_(data_dict["predicted_inverse_depths"][0])
-            if self.pretrain_mode == 3:                       # :711 cv_mask = data_dict["mvobj_mask"].clone()
-                plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
-            self._run_stage(key, plan, "cv", main)
+                enc_done, tail_done = encoder_stage()
+                _host_wait(mats_done)                         # on its way since before the encoder launches: there by now
+                cv_stage(*geometry(plan.host_mats))
+            # join: mask decoder -> depth
             main.wait_event(enc_done)
             self._run_stage(key, plan, "main", main)
             main.wait_event(tail_done)
@@ -793,7 +821,9 @@ class _Pending:
         return self._data
 
     def synchronize(self):
-        self._done.synchronize()
+        """Wait on the HOST for the forward and return the output dict: the caller's stream needs no wait packet then (a blocked
+        one slows the other hardware queues down) - the way to collect results in a pipelined loop."""
+        _host_wait(self._done)
         return self._data
 
 

@@ -83,6 +83,8 @@ class _StubHandle:
     def result(self):
         return self._out
 
+    synchronize = result
+
 
 class _StubModel:
     """Stands in for MonoRecModel on the CPU: `submit()` derives a deterministic 'prediction' from the keyframe."""

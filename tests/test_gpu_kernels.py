@@ -758,3 +758,21 @@ def test_plan_routes_unknown_3x3_shapes_by_the_workgroup_rule(hip_lib):
         torch.cuda.synchronize()
         ref = F.leaky_relu(F.conv2d(x, wt, bias, padding=1), 0.1)
         assert float((out.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_gather_small_into_pinned_host_memory(hip_lib):
+    """mr_gather_small_f32: the 4x4 matrices of a forward, scattered over device memory, land in ONE pinned host buffer through one
+    launch (the device writes the host allocation directly); the host reads them after waiting for the launch's event."""
+    g = torch.Generator().manual_seed(3)
+    mats = [torch.randn(2, 4, 4, generator=g) for _ in range(6)]
+    dev = [m.to(DEV) for m in mats]
+    host = torch.full((6, 2, 4, 4), float("nan")).pin_memory()
+    ptrs = (ctypes.c_void_p * 6)(*[m.data_ptr() for m in dev])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        _lib.check(hip_lib.mr_gather_small_f32(ptrs, 6, 32, host.data_ptr(), s.cuda_stream), "mr_gather_small_f32")
+        ev = torch.cuda.Event()
+        ev.record(s)
+    ev.synchronize()
+    assert torch.equal(host, torch.stack(mats))
+    assert hip_lib.mr_gather_small_f32(ptrs, 0, 32, host.data_ptr(), None) == -1 and hip_lib.mr_gather_small_f32(ptrs, 19, 32, host.data_ptr(), None) == -1

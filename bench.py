@@ -162,7 +162,7 @@ def committed_kernel_stats(cfg):
         forwards = 0
         for r in list(csv.reader(open(path)))[1:]:
             name, calls, total = r[0], int(r[1]), float(r[2])
-            if "conv_mfma_kernel" in name or "conv3x3_wino_kernel" in name:
+            if "conv_mfma_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name:
                 conv_us += total
                 conv_n += calls
             elif "splitk_epilogue_kernel" in name:
@@ -545,10 +545,12 @@ def main():
                              "valu_frac_note": "SQ_INSTS_VALU x 64 lanes / sad-kernel time / 78.6e12 lane-instr/s", "counters_source": pmc_src})
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
-        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd"))
+        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1)
+        n_wino_t = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 4)
         roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
-                 f"conv_mfma_kernel (direct) + conv3x3_wino_kernel (Winograd F(2x2,3x3), {n_wino} of the launches); both fp32 v_mfma_f32_16x16x4_f32"),
+                 f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches) + convt4x4_wino[_rb]_kernel "
+                 f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}); all fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "frac_executed": conv_flops_executed / conv_s / 1e12 / peak,
                 "frac_note": "frac counts the reference's multiply-adds (SURVEY 8d) over the measured conv time; frac_executed counts what the "
@@ -558,8 +560,8 @@ def main():
                 "avg_launch_us_note": "HIP events around each layer: kernel + dispatch gap (+ split-K finishing kernel)",
                 "algorithmic_gflop_per_step": conv_flops / 1e9, "executed_gflop_per_step": conv_flops_executed / 1e9,
                 "algorithmic_note": "the reference's Conv2d / ConvTranspose2d MACs x 2 (SURVEY 8d); executed is lower where Upconv runs "
-                                    "phase-decomposed on the low-resolution input (9 of 16 taps) and where a 3x3 convolution runs as Winograd "
-                                    "F(2x2,3x3) (16 of 36 multiplies)",
+                                    "phase-decomposed on the low-resolution input (9 of 16 taps), where a 3x3 convolution runs as Winograd "
+                                    "F(2x2,3x3) (16 of 36 multiplies) and where a ConvTranspose2d(4,2) runs as F(2x2,2x2) (9 of 16)",
                 "conv_ms_per_step": conv_s * 1e3}
         if kst:
             roof.update({"rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,

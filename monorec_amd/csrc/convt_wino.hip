@@ -224,6 +224,141 @@ __global__ __launch_bounds__(512) void convt4x4_wino_kernel(const WinoTKArgs a) 
         }
 }
 
+// ---- variant with the input transform in registers (mr_wino_desc.variant = 1; same idea as conv3x3_wino_rb_kernel) -----------------
+// The B operand of the MFMA for (position p, channel quad c4) is V[p][4 c4 + (lane >> 4)][tile lane & 15]: the lane that needs it
+// reads the 3x3 patch of its channel at its tile from the raw region (9 LDS reads per channel quad), transforms it (6 subtractions)
+// and holds the 9 values as MFMA operands.  No V buffer - the pipeline buffers of 64 output channels take 62 KB instead of 85, so TWO
+// workgroups share a CU and one's chunk fill hides behind the other's sweep - and one barrier per chunk instead of two.  Same
+// products in the same order per accumulator as the kernel above: bit-identical outputs.
+template <int MBW>
+__global__ __launch_bounds__(512) void convt4x4_wino_rb_kernel(const WinoTKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int U_FLOATS = NPOS * 2 * (2 * MBW) * 64;
+    constexpr int U_PAD = (U_FLOATS + 255) & ~255;
+    constexpr int BUF = WCK * RAW_PLANE + U_PAD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    const int grp = blockIdx.y;
+    const int ph = (int)blockIdx.z & 3, b = (int)blockIdx.z >> 2;
+    const int py = ph >> 1, px = ph & 1;
+    const int pt = 1 - py, pl = 1 - px;
+    const int y0 = ty_wg * 8, x0 = tx_wg * 32;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / 10, g4 = r - row * 10;
+        const int gy = y0 - pt + row, gx = x0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < RAW_ROWS * 10 ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)ph * a.wphase_stride + (long long)grp * a.wgroup_stride;
+
+    f32x4 acc[NPOS][MBW];
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF * 4;
+        const unsigned u_addr = buf_addr + WCK * RAW_PLANE * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS;
+        constexpr int N1K = U_FLOATS / 256;
+        for (int kb = wave; kb < N1K; kb += 8) dma_global_x4(u_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
+        for (int fr = N1K * 4 + wave; fr < U_FLOATS / 64; fr += 8) dma_global_x1(u_addr + fr * 256, wsrc + fr * 64 + lane);
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int tb = wave & 3, chalf = wave >> 2;
+    const int patch0 = (lane >> 4) * RAW_PLANE + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 4 - pl;   // channel lane >> 4, tile (tb, lane & 15)
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF;
+        const float* ub = raw + WCK * RAW_PLANE + (chalf * MBW) * 64 + lane;
+        dma_wait_all();
+        __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][NPOS];                                     // B operands of this lane: V[p] of channels 4 c4 + (lane >> 4)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE;
+            float d[3][3], t[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[r][c] = rp[r * RAW_PITCH + c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                t[0][c] = d[0][c] - d[1][c];
+                t[1][c] = d[1][c];
+                t[2][c] = d[2][c] - d[1][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                v[c4][r * 3 + 0] = t[r][0] - t[r][1];
+                v[c4][r * 3 + 1] = t[r][1];
+                v[c4][r * 3 + 2] = t[r][2] - t[r][1];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    const float av = ub[((p * 2 + c4) * (2 * MBW) + m) * 64];
+                    acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c4][p], acc[p][m], 0, 0, 0);
+                }
+    }
+    // ---- output transform Y = A^T M A, epilogue (as above) -------------------------------------------------------------------------
+    const int xo = x0 + 2 * (lane & 15);
+    const int yb = y0 + 2 * tb;
+    if (xo >= W) return;
+    const int OW = 2 * W;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cout = grp * (32 * MBW) + (chalf * MBW + m) * 16 + (lane >> 4) * 4 + r;
+            if (cout >= a.Cout) continue;
+            float s0[3], s1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s0[c] = acc[0 + c][m][r] + acc[3 + c][m][r];
+                s1[c] = acc[3 + c][m][r] + acc[6 + c][m][r];
+            }
+            float y[2][2];
+            y[0][0] = s0[0] + s0[1];
+            y[0][1] = s0[1] + s0[2];
+            y[1][0] = s1[0] + s1[1];
+            y[1][1] = s1[1] + s1[2];
+            const float bs = a.bias ? a.bias[cout] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yo = yb + i;
+                if (yo >= H) continue;
+                float* o = a.dst + ((long long)(b * a.Cout + cout) * (2 * H) + (2 * yo + py)) * OW + 2 * xo + px;
+                o[0] = act_t(y[i][0] + bs, a.act, a.p0);
+                if (xo + 1 < W) o[2] = act_t(y[i][1] + bs, a.act, a.p0);
+            }
+        }
+}
+
 bool valid_mbw_t(int m) { return m == 1 || m == 2 || m == 4; }
 int pad8(int c) { return (c + 7) & ~7; }
 
@@ -232,6 +367,7 @@ struct WinoTDerived {
     dim3 grid;
     size_t lds_bytes;
     int mbw;
+    bool regb;
 };
 
 int derive_t(const mr_wino_desc* d, WinoTDerived* out) {
@@ -270,24 +406,27 @@ int derive_t(const mr_wino_desc* d, WinoTDerived* out) {
     k.wphase_stride = (long long)groups * nchunks * ufl;
     if (d->batch * 4 >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
     out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)(d->batch * 4));
-    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ((ufl + 255) & ~255)) + V_FLOATS) * 4;
+    if (d->variant != 0 && d->variant != 1) return MR_ERR_BAD_ARGUMENT;
+    out->regb = d->variant == 1;
+    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ((ufl + 255) & ~255)) + (out->regb ? 0 : V_FLOATS)) * 4;
     out->mbw = mbw;
     return 0;
 }
 
-template <int MBW>
+template <int MBW, bool REGB>
 int launch_t(const WinoTDerived& dv, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_set{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
+    const void* fn = REGB ? reinterpret_cast<const void*>(&convt4x4_wino_rb_kernel<MBW>) : reinterpret_cast<const void*>(&convt4x4_wino_kernel<MBW>);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt4x4_wino_kernel<MBW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(convt4x4_wino_kernel<MBW>, dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
+    if (REGB) hipLaunchKernelGGL(convt4x4_wino_rb_kernel<MBW>, dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
+    else hipLaunchKernelGGL(convt4x4_wino_kernel<MBW>, dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
 }
 
@@ -352,9 +491,16 @@ extern "C" int mr_convt4x4s2_winograd_f32(const mr_wino_desc* desc, void* stream
     WinoTDerived dv;
     const int rc = derive_t(desc, &dv);
     if (rc != 0) return rc;
+    if (dv.regb) {
+        switch (dv.mbw) {
+            case 4: return launch_t<4, true>(dv, (hipStream_t)stream);
+            case 2: return launch_t<2, true>(dv, (hipStream_t)stream);
+            default: return launch_t<1, true>(dv, (hipStream_t)stream);
+        }
+    }
     switch (dv.mbw) {
-        case 4: return launch_t<4>(dv, (hipStream_t)stream);
-        case 2: return launch_t<2>(dv, (hipStream_t)stream);
-        default: return launch_t<1>(dv, (hipStream_t)stream);
+        case 4: return launch_t<4, false>(dv, (hipStream_t)stream);
+        case 2: return launch_t<2, false>(dv, (hipStream_t)stream);
+        default: return launch_t<1, false>(dv, (hipStream_t)stream);
     }
 }

@@ -187,6 +187,16 @@ def choose_winograd(cout, src_channels, h, w, batch):
 
 
 
+def choose_winograd_t(cout, src_channels, h, w, batch):
+    """layers.Refine (ConvTranspose2d(4, 2) + crop) on an input of h x w: 0 = the four parity phases on the direct MFMA kernel, 1 / 2 /
+    4 = the F(2x2,2x2) kernel (csrc/convt_wino.hip) with 32 / 64 / 128 output channels per workgroup, + 10 = its variant with the input
+    transform in registers.  Only what the measured table (tools/bench_wino_t.py --emit; keys prefixed `t_`) says: shapes it does not
+    know stay on the direct kernel."""
+    if w % 4:
+        return 0
+    return WINOGRAD.get("t_" + winograd_signature(cout, src_channels, h, w, batch), 0)
+
+
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
     """`mixed_phases`: the phases sweep different tap counts (phase-decomposed Upconv: 1, 2, 2 and 4 taps of a 2x2 tile)."""
     return (f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
@@ -518,9 +528,54 @@ class Plan:
         wt = self.sd[prefix + ".conv2d_t.weight"]
         bias = self.sd[prefix + ".conv2d_t.bias"]
         h, w = srcs[0].shape[2], srcs[0].shape[3]
+        if self.winograd and self.bf16 == 0 and name not in self.schedule_override and tuple(out.shape[2:]) == (2 * h, 2 * w):
+            code = choose_winograd_t(int(wt.shape[1]), [int(s_.shape[1]) for s_ in srcs], h, w, int(srcs[0].shape[0]))
+            if code:
+                return self._refine_winograd(stage, name, srcs, wt, bias, out, code % 10, code // 10)
         phases = [(wp, pt, pl, py, px) for (py, px), (wp, pt, pl) in transposed_phase_weights(wt).items()]
         return self.conv(stage, name, srcs, None, bias, out, stride=(1, 1), grid=(h, w), act=ACT_LEAKY_RELU,
                          p0=LEAKY_SLOPE, out_step=(2, 2), phases=phases)
+
+    def _refine_winograd(self, stage, name, srcs, wt, bias, out, mbw, variant):
+        """One mr_convt4x4s2_winograd_f32 launch (csrc/convt_wino.hip: F(2x2,2x2), 9 instead of 16 multiplies per 2x2 parity tile) in
+        place of the four-phase mr_conv2d_f32 launch of a Refine layer."""
+        lib = self.lib
+        n, _, hs, ws = srcs[0].shape
+        src_channels = [int(s_.shape[1]) for s_ in srcs]
+        cin, cout = int(wt.shape[0]), int(wt.shape[1])
+        assert cin == sum(src_channels) and tuple(wt.shape[2:]) == (4, 4), (name, wt.shape, src_channels)
+        sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
+        w = wt.detach().to(torch.float32).contiguous().cpu()
+        nfl = lib.mr_wino_t_packed_weight_floats(cout, sc, len(src_channels), mbw)
+        packed = torch.empty(nfl, dtype=torch.float32)
+        _lib.check(lib.mr_wino_t_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino_t_pack_weights_f32")
+        d = WinoDesc()
+        for i, s_ in enumerate(srcs):
+            assert s_.is_contiguous() and tuple(s_.shape[2:]) == (hs, ws) and s_.shape[0] == n
+            d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
+        d.num_src, d.batch, d.height, d.width = len(srcs), n, hs, ws
+        assert out.is_contiguous() and tuple(out.shape) == (n, cout, 2 * hs, 2 * ws)
+        d.dst, d.out_channels = out.data_ptr(), cout
+        d.packed_weights = self._dev(packed).data_ptr()
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = ACT_LEAKY_RELU, LEAKY_SLOPE, mbw, variant
+        lds = lib.mr_convt4x4s2_winograd_lds_bytes(ctypes.byref(d))
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name} winograd-t")
+        ref = n * hs * ws * cout * cin * 16
+        wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * 4 * math.ceil(cout / (32 * mbw))
+        self.conv_log.append(dict(name=name, macs=ref * 9 // 16, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+                                  cout=cout, cin=cin, k=(2, 2), out=(hs, ws), batch=n, phases=4, winograd=mbw, wino_variant=variant, bf16=0,
+                                  sig="t_" + winograd_signature(cout, src_channels, hs, ws, n),
+                                  spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 2, 2), stride=(1, 1), pad=(0, 0),
+                                            grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE, p1=0.0, residual=False,
+                                            out_shape=tuple(out.shape), out_step=(2, 2), out_off=(0, 0), phases=None)))
+        self.keep += [d, out] + list(srcs)
+
+        def run(stream):
+            _lib.check(lib.mr_convt4x4s2_winograd_f32(ctypes.byref(d), stream), name)
+        self.stages[stage].append((name, run))
+        return out
 
     def upconv(self, stage, name, srcs, wkey, bkey, out):
         """layers.Upconv (model/layers.py:349-356) phase-decomposed on the low-resolution input: the 4 output parities as the 4

@@ -658,21 +658,25 @@ class MonoRecModel(nn.Module):
                 ev.record(cs)
                 _host_wait(ev)
         plan.consumers.clear()
-        # Matrices on the device: one small copy into pinned host memory on their own stream, ordered only behind the caller's
-        # inputs (it must not queue behind the slot's previous keyframe: the host waits for it below); the pose-independent encoder
-        # launches are enqueued while it is under way.
-        mats_done = None
+        # Matrices on the device: one gather launch into device-writable pinned host memory on the slot's geometry stream, awaited at
+        # once (~15 us: everything it reads is ready) - then the same order as with host matrices.  (Round 2 hid the round trip behind
+        # the encoder launches; the cost volume then started ~0.2 ms later, and it heads the longest chain.)
         if not mats_on_host:
             dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
                   m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
-            with torch.cuda.stream(geom):
-                ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
-                _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, plan.host_mats.data_ptr(), geom.cuda_stream),
-                           "mr_gather_small_f32")         # one launch into device-writable pinned memory
-                mats_done = torch.cuda.Event()
-                mats_done.record(geom)
+            if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
+                ev = torch.cuda.Event()
+                ev.record(caller)
+                _host_wait(ev)
+            ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
+            _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, plan.host_mats.data_ptr(), geom.cuda_stream),
+                       "mr_gather_small_f32")
+            mats_done = torch.cuda.Event()
+            mats_done.record(geom)
             for m in dm:
                 m.record_stream(geom)
+            _host_wait(mats_done)
+            geo = geometry(plan.host_mats)
         with torch.cuda.stream(main):
             # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
             # captured launches keep their pointers - goes through the slot's resident buffers
@@ -716,13 +720,8 @@ class MonoRecModel(nn.Module):
                     plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
                 self._run_stage(key, plan, "cv", main)
 
-            if mats_on_host:
-                cv_stage(*geo)
-                enc_done, tail_done = encoder_stage()
-            else:
-                enc_done, tail_done = encoder_stage()
-                _host_wait(mats_done)                         # on its way since before the encoder launches: there by now
-                cv_stage(*geometry(plan.host_mats))
+            cv_stage(*geo)                 # head of the longest chain (cost volume -> mask encoder -> mask decoder -> depth): first
+            enc_done, tail_done = encoder_stage()
             # join: mask decoder -> depth
             main.wait_event(enc_done)
             self._run_stage(key, plan, "main", main)

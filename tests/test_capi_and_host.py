@@ -262,11 +262,15 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert abs((plan.conv_ref_macs() + aux) / 1e9 - 61.07) < 0.01
     # executed: the four mask-decoder Upconv layers (3.934 GMAC in the reference) run phase-decomposed at 9/16 of their taps, and the
     # 3x3 layers the measured table sends to the Winograd kernel (csrc/conv_wino.hip) at 16/36 of their multiplies
-    wino = [c for c in plan.conv_log if c.get("winograd")]
+    wino = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 1]
     assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
                                          "mask.dec3.2", "depth.dec4.2"}
     assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
-    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino)
+    # ... and the two large Refine layers (ConvTranspose2d(4, 2)) on the F(2x2,2x2) kernel (csrc/convt_wino.hip) at 9/16
+    wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4]
+    assert {c["name"] for c in wino_t} == {"depth.dec2.0", "depth.dec3"}
+    assert all(c["macs"] * 16 == c["ref_macs"] * 9 and c["lds"] <= 160 * 1024 and c["sig"].startswith("t_") for c in wino_t)
+    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t)
     assert abs((plan.conv_macs() + aux + wino_saved) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
     direct = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)               # A/B aid: every 3x3 layer on the direct kernel
     assert not any(c.get("winograd") for c in direct.conv_log) and abs((direct.conv_macs() + aux) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
@@ -658,10 +662,12 @@ def test_winograd_choice_table_and_rule():
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 11, 12}            # + 10: input transform in registers (mr_wino_desc.variant)
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 4, 11, 12, 14}     # + 10: input transform in registers (mr_wino_desc.variant)
+    assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
+    assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
     assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) % 10 == 2    # mask.enc0.*, mask.dec3.1 @ c2
     assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
-    assert engine.choose_winograd(64, [64], 256, 512, 32) % 10 == 2                                                          # mask.enc0.* @ c3
+    assert engine.choose_winograd(64, [64], 256, 512, 32) in (2, 11, 12)                                                     # mask.enc0.* @ c3
     assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct
     assert engine.choose_winograd(32, [32], 256, 768, 3) == 11         # unknown, 2304 workgroups, 32 couts: transform in registers
     assert engine.choose_winograd(96, [96], 256, 768, 3) == 2

@@ -684,10 +684,12 @@ WINO_T_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", range(len(WINO_T_CASES)))
-def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case):
+def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case, variant):
     """mr_convt4x4s2_winograd_f32 against F.conv_transpose2d(stride=2) cropped by one pixel on every side (layers.Refine,
-    model/layers.py:389-397) + bias + LeakyReLU on the CPU."""
+    model/layers.py:389-397) + bias + LeakyReLU on the CPU; both variants (input transform through LDS / in registers), which must
+    agree bit for bit."""
     srcs_c, cout, (h, w), batch, act, mbw = WINO_T_CASES[case]
     lib = hip_lib
     g = torch.Generator().manual_seed(200 + case)
@@ -708,7 +710,7 @@ def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case):
     pk, bs = packed.to(DEV), bias.to(DEV)
     d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
     d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), None
-    d.activation, d.act_p0, d.cout_blocks_per_wave = act, 0.1, mbw
+    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, mbw, variant
     assert 0 < lib.mr_convt4x4s2_winograd_lds_bytes(ctypes.byref(d)) <= 160 * 1024
     _lib.check(lib.mr_convt4x4s2_winograd_f32(ctypes.byref(d), _stream()), "mr_convt4x4s2_winograd_f32")
     torch.cuda.synchronize()
@@ -716,6 +718,36 @@ def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case):
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+    if variant == 1:
+        d.variant = 0
+        out.fill_(float("nan"))
+        _lib.check(lib.mr_convt4x4s2_winograd_f32(ctypes.byref(d), _stream()), "mr_convt4x4s2_winograd_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), got)
+
+
+def test_plan_refine_on_the_transposed_winograd_kernel(hip_lib, monkeypatch):
+    """Plan.refine routes a Refine layer to mr_convt4x4s2_winograd_f32 when the measured table names it (keys `t_...`): same result
+    as the four-phase direct launch to the rounding of the transforms, and as F.conv_transpose2d + crop + LeakyReLU."""
+    g = torch.Generator().manual_seed(77)
+    srcs = [torch.randn(1, c, 24, 32, generator=g) for c in (16, 24)]
+    wt = torch.randn(40, 48, 4, 4, generator=g) * (1.0 / (2.0 * math.sqrt(40)))
+    bias = torch.randn(48, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv_transpose2d(torch.cat(srcs, 1), wt, bias, stride=2)[:, :, 1:-1, 1:-1], 0.1)
+    outs = []
+    for code in (0, 12, 1):
+        monkeypatch.setitem(engine.WINOGRAD, "t_" + engine.winograd_signature(48, [16, 24], 24, 32, 1), code)
+        plan = engine.Plan.bare(DEV, state={"x.conv2d_t.weight": wt, "x.conv2d_t.bias": bias})
+        plan.winograd = True
+        out = torch.full((1, 48, 48, 64), float("nan"), device=DEV)
+        plan.refine("main", "t", [s.to(DEV) for s in srcs], "x", out)
+        plan.finalize()
+        assert bool(plan.conv_log[0].get("winograd")) == bool(code)
+        assert plan.conv_log[0]["ref_macs"] == 24 * 32 * 48 * 40 * 16
+        plan.run_stage("main", _stream())
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+        assert float((outs[-1] - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), code
 
 
 def test_copy_segments(hip_lib):

@@ -27,7 +27,9 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
+    ap.add_argument("--emit", default=None, help="merge {t_<signature>: 0 | mbw | 10 + mbw} (fastest; Winograd must win by 3 %%) into this JSON table")
     a = ap.parse_args()
+    table = {}
     lib = _lib.load()
     m = MonoRecModel(cv_depth_steps=a.depths)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
@@ -54,8 +56,9 @@ def main():
                "direct_us": round(timed(direct), 1)}
         sc = [int(s.shape[1]) for s in srcs]
         arr = (ctypes.c_int32 * len(sc))(*sc)
-        best = row["direct_us"]
-        for mbw in (1, 2, 4):
+        best, best_code = row["direct_us"], 0
+        for code in (1, 2, 4, 11, 12, 14):                   # output-channel blocks per wave; + 10: input transform in registers
+            mbw, variant = code % 10, code // 10
             if 32 * mbw >= 2 * cout and mbw > 1:
                 continue
             n = lib.mr_wino_t_packed_weight_floats(cout, arr, len(sc), mbw)
@@ -68,18 +71,26 @@ def main():
             pk, bs = packed.to(DEV), bias.to(DEV)
             d.num_src, d.batch, d.height, d.width = len(srcs), srcs[0].shape[0], srcs[0].shape[2], srcs[0].shape[3]
             d.dst, d.out_channels, d.packed_weights, d.bias = out_w.data_ptr(), cout, pk.data_ptr(), bs.data_ptr()
-            d.activation, d.act_p0, d.cout_blocks_per_wave = sp["act"], sp["p0"], mbw
+            d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = sp["act"], sp["p0"], mbw, variant
             fn = lambda stream, d=d: _lib.check(lib.mr_convt4x4s2_winograd_f32(ctypes.byref(d), stream), "wino_t")   # noqa: E731
             fn(torch.cuda.current_stream().cuda_stream)
             direct(torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            row[f"wino{mbw}_maxdiff"] = float((out_w - out_d).abs().max())
-            row[f"wino{mbw}_us"] = round(timed(fn), 1)
-            best = min(best, row[f"wino{mbw}_us"])
+            row[f"wino{code}_maxdiff"] = float((out_w - out_d).abs().max())
+            row[f"wino{code}_us"] = round(timed(fn), 1)
+            if row[f"wino{code}_us"] < best and row[f"wino{code}_us"] < 0.97 * row["direct_us"]:
+                best, best_code = row[f"wino{code}_us"], code
         tot_d += row["direct_us"]
         tot_b += best
+        row["best"] = best_code
+        table["t_" + engine.winograd_signature(cout, sc, srcs[0].shape[2], srcs[0].shape[3], srcs[0].shape[0])] = best_code
         print(json.dumps(row), flush=True)
     print(json.dumps({"direct_total_us": round(tot_d, 1), "best_of_both_total_us": round(tot_b, 1)}))
+    if a.emit:
+        old = json.load(open(a.emit)) if os.path.exists(a.emit) else {}
+        old.update(table)
+        with open(a.emit, "w") as f:
+            json.dump(old, f, indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -402,8 +402,10 @@ def main():
     dev_index = 0 if one_device else local_rank
     if args.primer:
         dev_index = int(os.environ.get("MR_BENCH_DEVICE", "0"))
+    # The primer is a single-GPU affair: in a multi-rank job every rank would fork its own throw-away process at the same time (N
+    # concurrent children building plans) - there the ranks just spin up in-process (the ~6 % first-process effect then stays in).
     primed = False
-    if not args.primer and not args.no_primer and not (one_device and rank > 0):
+    if not args.primer and not args.no_primer and world == 1:
         primed = prime_device(args, dev_index)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -477,7 +479,7 @@ def main():
             torch.cuda.synchronize()
     out = drain()
     torch.cuda.synchronize()
-    summary = torch.zeros(2, dtype=torch.float64, device=comm_dev)
+    summary = torch.zeros(3, dtype=torch.float64, device=comm_dev)     # keyframes, mean prediction, this rank's own elapsed seconds
     # the closing reduction of the timed region, once untimed: the first call of an ATen kernel in a process loads its code
     # object (~10 ms for .double() + .mean() here) - with 20 timed steps that load alone read as +0.7 ms per step
     summary[1] = out["result"].double().mean().to(comm_dev)
@@ -495,7 +497,8 @@ def main():
     out = drain()
     enq1 = list(model.host_enqueue_stats)
     summary[0] = args.steps * args.batch
-    summary[1] = out["result"].double().mean().to(comm_dev)
+    summary[1] = out["result"].double().mean().to(comm_dev)       # (synchronises this rank's device: every step's output exists now)
+    summary[2] = time.perf_counter() - t0
     if world > 1:   # the path's only collective: per-rank summaries, ~16 B per rank
         gathered = [torch.zeros_like(summary) for _ in range(world)]
         dist.all_gather(gathered, summary)
@@ -585,6 +588,8 @@ def main():
             "value": total_keyframes / elapsed,
             "unit": "keyframes/s",
             "n_gpus": world,
+            "ranks_seen": len(gathered),
+            "per_rank_keyframes_per_s": [float(g[0].item() / g[2].item()) for g in gathered],
             "steps": args.steps,
             "warmup": args.warmup,
             "untimed_spinup_steps": n_spin,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 9
+#define MR_ABI_VERSION 10
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -199,12 +199,18 @@ typedef struct mr_wino_desc {
     int32_t cout_blocks_per_wave;    /* 1 or 2: a workgroup (8 waves, 8 x 32 output pixels) produces 32 or 64 output channels */
     int32_t variant;                 /* mr_conv3x3_winograd_f32 only: 0 input transform through an LDS buffer (thread = channel x tile),
                                         1 input transform in the registers of the lane that feeds it to the matrix core (no V buffer,
-                                        one barrier per chunk; bit-identical results).  Which is faster is measured per layer shape. */
+                                        one barrier per chunk; bit-identical results).  Which is faster is measured per layer shape.
+                                        2 = 1 for out_channels = 32 a + r, 0 < r <= 16, cout_blocks_per_wave 1: the r tail channels are
+                                        produced by workgroups of 16 x 32 pixels x 16 channels instead of a half-empty 32-channel group
+                                        (the 48-channel layers); packed_weights then from mr_wino_pack_weights_tail_f32. */
 } mr_wino_desc;
 size_t mr_wino_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
 /* weight: (out_channels, sum(src_channels), 3, 3) fp32 host memory; the transformed filters G g G^T are formed in double */
 int mr_wino_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
                              int32_t cout_blocks_per_wave, float* dst);
+/* variant 2: the full 32-channel groups as above (cout_blocks_per_wave 1), then the tail group of 1..16 channels */
+size_t mr_wino_packed_weight_floats_tail(int32_t out_channels, const int32_t* src_channels, int32_t num_src);
+int mr_wino_pack_weights_tail_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
 int64_t mr_conv3x3_winograd_lds_bytes(const mr_wino_desc* desc);   /* dynamic LDS of the launch, or a negative MR_ERR_* code */
 int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
 
@@ -214,12 +220,16 @@ int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
  * convolution on the low-resolution input (9 multiplies per 2x2 parity tile instead of 16; transform coefficients 0 / +-1 only).
  * Same descriptor as mr_conv3x3_winograd_f32: sources (batch, C_s, height, width) read in place, dst = (batch, out_channels,
  * 2 * height, 2 * width), bias / activation in the epilogue, no residual; cout_blocks_per_wave 1, 2 or 4 (32 / 64 / 128 output channels
- * per workgroup); packed_weights from mr_wino_t_pack_weights_f32 with the same value.  width % 4 == 0.
+ * per workgroup); packed_weights from mr_wino_t_pack_weights_f32 with the same value.  width % 4 == 0.  `variant` as for
+ * mr_conv3x3_winograd_f32 (0 transform through LDS, 1 in registers, 2 = 1 with 16-channel tail workgroups).
  */
 size_t mr_wino_t_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
 /* weight: the nn.ConvTranspose2d tensor (sum(src_channels), out_channels, 4, 4), fp32 host memory */
 int mr_wino_t_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
                                int32_t cout_blocks_per_wave, float* dst);
+/* variant 2 (out_channels = 32 a + r, 0 < r <= 16, cout_blocks_per_wave 1): full 32-channel groups, then the tail group of r channels */
+size_t mr_wino_t_packed_weight_floats_tail(int32_t out_channels, const int32_t* src_channels, int32_t num_src);
+int mr_wino_t_pack_weights_tail_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
 int64_t mr_convt4x4s2_winograd_lds_bytes(const mr_wino_desc* desc);
 int mr_convt4x4s2_winograd_f32(const mr_wino_desc* desc, void* stream);
 

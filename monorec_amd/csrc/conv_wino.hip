@@ -52,6 +52,9 @@ struct WinoKArgs {
     int Cout, tiles_x, nchunks;
     const float* w;
     long long wgroup_stride;            // packed floats per cout group
+    int tail_grp;                       // variant 2 (in-register transform, 32 couts per workgroup): index of the 16-channel tail group
+                                        // (out_channels % 32 in 1..16), handled by 16-row workgroups (wino_rb_tail), or -1
+    int tiles_y16;                      // 16-row tile rows of the image (tail workgroups)
 };
 
 // ---- LDS-DMA through inline asm (see conv_mfma.hip: the builtins make hipcc drain vmcnt before every sweep) -------------------
@@ -233,6 +236,139 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoKArgs a) {
 }
 
 
+// ---- 16-channel tail of the in-register-transform kernel ------------------------------------------------------------------------------
+// out_channels = 32 a + r with 0 < r <= 16 (the 48-channel layers of the MaskModule: monorec_model.py:300-313) would leave half of
+// the last 32-channel workgroup multiplying zero weights.  The tail group is produced by workgroups of another shape instead: 16 x 32
+// output pixels (8 tile rows, one per wave) x ONE block of 16 channels - the same 8 (tile row, channel block) units of work per
+// workgroup, the same sweep (16 positions x 2 channel quads MFMAs per wave and chunk), one A read per MFMA.  Raw region 18 rows x 40
+// columns (plane pitch 720 floats = 16 mod 32 banks, like 400), U fragments of a chunk 8 KiB.
+constexpr int RAW_ROWS_T = 18, RAW_PLANE_T = RAW_PITCH * RAW_ROWS_T;
+constexpr int U_FLOATS_T = 16 * 2 * 64;
+constexpr int BUF_T = WCK * RAW_PLANE_T + U_FLOATS_T;
+
+__device__ __forceinline__ void wino_rb_tail(const WinoKArgs& a, float* lds) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    if (ty_wg >= a.tiles_y16) return;                         // the grid is sized for the 8-row workgroups of the full groups
+    const int b = blockIdx.z;
+    const int oy0 = ty_wg * 16, ox0 = tx_wg * 32;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[3];                                             // lane l owns the 16-byte groups r = l + 64 i (< 180): row r / 10, group r % 10
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / 10, g4 = r - row * 10;
+        const int gy = oy0 - 1 + row, gx = ox0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < RAW_ROWS_T * 10 ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)a.tail_grp * a.wgroup_stride;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF_T * 4;
+        const unsigned u_addr = buf_addr + WCK * RAW_PLANE_T * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS_T;
+        dma_global_x4(u_addr + wave * 1024, wsrc + wave * 256 + lane * 4);          // 8 pieces of 1 KiB, one per wave
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE_T * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int tb = wave;                                      // tile row 0..7
+    const int patch0 = (lane >> 4) * RAW_PLANE_T + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 3;
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF_T;
+        const float* ub = raw + WCK * RAW_PLANE_T + lane;
+        dma_wait_all();
+        __syncthreads();
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][16];
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE_T;
+            float d[4][4], t[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[r][c] = rp[r * RAW_PITCH + c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[c4][r * 4 + 0] = t[r][0] - t[r][2];
+                v[c4][r * 4 + 1] = t[r][1] + t[r][2];
+                v[c4][r * 4 + 2] = t[r][2] - t[r][1];
+                v[c4][r * 4 + 3] = t[r][1] - t[r][3];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4) {
+                const float av = ub[(p * 2 + c4) * 64];
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c4][p], acc[p], 0, 0, 0);
+            }
+    }
+    const int ox = ox0 + 2 * (lane & 15);
+    const int oyb = oy0 + 2 * tb;
+    if (ox >= W) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cout = a.tail_grp * 32 + (lane >> 4) * 4 + r;
+        if (cout >= a.Cout) continue;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s0[c] = (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r];
+            s1[c] = (acc[4 + c][r] - acc[8 + c][r]) - acc[12 + c][r];
+        }
+        float y[2][2];
+        y[0][0] = (s0[0] + s0[1]) + s0[2];
+        y[0][1] = (s0[1] - s0[2]) - s0[3];
+        y[1][0] = (s1[0] + s1[1]) + s1[2];
+        y[1][1] = (s1[1] - s1[2]) - s1[3];
+        const float bs = a.bias ? a.bias[cout] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oyb + i;
+            if (oy >= H) continue;
+            const long long idx = ((long long)(b * a.Cout + cout) * H + oy) * W + ox;
+            float2 o;
+            o.x = y[i][0] + bs;
+            o.y = y[i][1] + bs;
+            if (a.res) {
+                const float2 rv = *(const float2*)(a.res + idx);
+                o.x += rv.x;
+                o.y += rv.y;
+            }
+            o.x = wino_activate(o.x, a.act, a.p0);
+            o.y = wino_activate(o.y, a.act, a.p0);
+            *(float2*)(a.dst + idx) = o;
+        }
+    }
+}
+
 // ---- variant with the input transform in registers (mr_wino_desc.variant = 1; the plan picks per layer shape by measurement) --------
 // The B operand of the MFMA for (position p, channel quad c4) is V[p][4 c4 + (lane >> 4)][tile lane & 15] - so the lane that needs it
 // can compute it itself: it reads the 4x4 patches of ITS two channels of the chunk at ITS tile from the raw region (32 LDS reads),
@@ -242,6 +378,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoKArgs a) {
 template <int MBW>
 __global__ __launch_bounds__(512) void conv3x3_wino_rb_kernel(const WinoKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (MBW == 1 && (int)blockIdx.y == a.tail_grp) { wino_rb_tail(a, lds); return; }      // 16-channel tail group: 16-row workgroups
     constexpr int U_FLOATS = 16 * 2 * (2 * MBW) * 64;
     constexpr int BUF = WCK * RAW_PLANE + U_FLOATS;
     const int tid = threadIdx.x;
@@ -418,11 +555,20 @@ int wino_derive(const mr_wino_desc* d, WinoDerived* out) {
     const int groups = (d->out_channels + 32 * mbw - 1) / (32 * mbw);
     if (d->batch >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
     out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)d->batch);
-    if (d->variant != 0 && d->variant != 1) return MR_ERR_BAD_ARGUMENT;
-    const bool regb = d->variant == 1;                                          // the in-register-transform variant (see there)
+    if (d->variant < 0 || d->variant > 2) return MR_ERR_BAD_ARGUMENT;
+    const bool regb = d->variant >= 1;                                          // the in-register-transform variant (see there)
     out->regb = regb;
     out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ufl) + (regb ? 0 : V_FLOATS)) * 4;
     out->mbw = mbw;
+    k.tail_grp = -1;
+    k.tiles_y16 = (d->height + 15) / 16;
+    if (d->variant == 2) {                                                      // 32 a + (1..16) channels: the tail by 16-row workgroups
+        const int rem = d->out_channels % 32;
+        if (mbw != 1 || rem < 1 || rem > 16) return MR_ERR_BAD_ARGUMENT;
+        k.tail_grp = d->out_channels / 32;                                      // = groups - 1
+        const size_t tail_lds = (size_t)2 * BUF_T * 4;
+        if (tail_lds > out->lds_bytes) out->lds_bytes = tail_lds;
+    }
     return 0;
 }
 
@@ -491,6 +637,52 @@ extern "C" int mr_wino_pack_weights_f32(const float* weight, int32_t out_channel
     return 0;
 }
 
+// Variant 2 (out_channels = 32 a + r, 0 < r <= 16): the a full groups exactly as mr_wino_pack_weights_f32(mbw = 1) packs them, then the
+// tail group as [chunk][position][channel quad][64 lanes] (one block of 16 channels), lane l = (cout 32 a + (l & 15), channel l >> 4).
+extern "C" size_t mr_wino_packed_weight_floats_tail(int32_t out_channels, const int32_t* src_channels, int32_t num_src) {
+    if (!src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || out_channels < 1) return 0;
+    const int rem = out_channels % 32;
+    if (rem < 1 || rem > 16) return 0;
+    int nchunks = 0;
+    for (int s = 0; s < num_src; ++s) nchunks += pad8(src_channels[s]) / WCK;
+    return (size_t)(out_channels / 32) * nchunks * (16 * 2 * 2 * 64) + (size_t)nchunks * U_FLOATS_T;
+}
+
+extern "C" int mr_wino_pack_weights_tail_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst) {
+    if (!weight || !dst || mr_wino_packed_weight_floats_tail(out_channels, src_channels, num_src) == 0) return MR_ERR_BAD_ARGUMENT;
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int full = out_channels / 32;
+    if (full > 0) {                                      // the full groups: the standard stream of their 32 a channels, cin layout unchanged
+        // (weights of output channel c start at c * cin_total * 9, so the first 32 a channels are a prefix of the tensor)
+        const int rc = mr_wino_pack_weights_f32(weight, full * 32, src_channels, num_src, 1, dst);
+        if (rc != 0) return rc;
+    }
+    int cin_total = 0, nchunks = 0;
+    for (int s = 0; s < num_src; ++s) { cin_total += src_channels[s]; nchunks += pad8(src_channels[s]) / WCK; }
+    size_t o = (size_t)full * nchunks * (16 * 2 * 2 * 64);
+    int cin_off = 0;
+    for (int s = 0; s < num_src; ++s) {
+        const int cpad = pad8(src_channels[s]);
+        for (int c0 = 0; c0 < cpad; c0 += WCK)
+            for (int p = 0; p < 16; ++p)
+                for (int c4 = 0; c4 < 2; ++c4)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int cout = full * 32 + (lane & 15);
+                        const int cl = c0 + c4 * 4 + (lane >> 4);
+                        double u = 0.0;
+                        if (cout < out_channels && cl < src_channels[s]) {
+                            const float* gw = weight + ((size_t)cout * cin_total + (cin_off + cl)) * 9;
+                            const int pa = p >> 2, pb = p & 3;
+                            for (int i = 0; i < 3; ++i)
+                                for (int j = 0; j < 3; ++j) u += G[pa][i] * (double)gw[i * 3 + j] * G[pb][j];
+                        }
+                        dst[o++] = (float)u;
+                    }
+        cin_off += src_channels[s];
+    }
+    return 0;
+}
+
 extern "C" int64_t mr_conv3x3_winograd_lds_bytes(const mr_wino_desc* desc) {
     WinoDerived dv;
     const int rc = wino_derive(desc, &dv);
@@ -501,6 +693,6 @@ extern "C" int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream) {
     WinoDerived dv;
     const int rc = wino_derive(desc, &dv);
     if (rc != 0) return rc;
-    if (dv.regb) return dv.mbw == 2 ? wino_launch<2, true>(dv, (hipStream_t)stream) : wino_launch<1, true>(dv, (hipStream_t)stream);
+    if (dv.regb) return dv.mbw == 2 ? wino_launch<2, true>(dv, (hipStream_t)stream) : wino_launch<1, true>(dv, (hipStream_t)stream);   // (variant 2: mbw 1)
     return dv.mbw == 2 ? wino_launch<2, false>(dv, (hipStream_t)stream) : wino_launch<1, false>(dv, (hipStream_t)stream);
 }

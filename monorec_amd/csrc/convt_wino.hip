@@ -45,6 +45,8 @@ struct WinoTKArgs {
     int Cout, tiles_x, nchunks, ngroups;
     const float* w;                     // [phase][cout group][chunk][9][2][2 MBW][64]
     long long wgroup_stride, wphase_stride;
+    int tail_grp;                       // variant 2: index of the 16-channel tail group (out_channels % 32 in 1..16) or -1, see convt_rb_tail
+    int tiles_y16;
 };
 
 __device__ __forceinline__ void dma_buffer_x4(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
@@ -224,6 +226,132 @@ __global__ __launch_bounds__(512) void convt4x4_wino_kernel(const WinoTKArgs a) 
         }
 }
 
+// ---- 16-channel tail of the in-register-transform kernel (variant 2; as wino_rb_tail in conv_wino.hip) ---------------------------------
+// out_channels = 32 a + r, 0 < r <= 16 (depth.dec3: 48): the tail channels come from workgroups of 16 x 32 input positions x ONE block of
+// 16 channels (8 tile rows, one per wave) instead of a half-empty 32-channel group.  Raw region 18 rows x 40 columns, U of a chunk 4.5 KiB.
+constexpr int RAW_ROWS_TT = 18, RAW_PLANE_TT = RAW_PITCH * RAW_ROWS_TT;
+constexpr int U_FLOATS_TT = NPOS * 2 * 64;                   // 1152
+constexpr int U_PAD_TT = (U_FLOATS_TT + 255) & ~255;         // 1280
+constexpr int BUF_TT = WCK * RAW_PLANE_TT + U_PAD_TT;
+
+__device__ __forceinline__ void convt_rb_tail(const WinoTKArgs& a, float* lds) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    if (ty_wg >= a.tiles_y16) return;
+    const int ph = (int)blockIdx.z & 3, b = (int)blockIdx.z >> 2;
+    const int py = ph >> 1, px = ph & 1;
+    const int pt = 1 - py, pl = 1 - px;
+    const int y0 = ty_wg * 16, x0 = tx_wg * 32;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / 10, g4 = r - row * 10;
+        const int gy = y0 - pt + row, gx = x0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < RAW_ROWS_TT * 10 ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    // stream: [phase][a full groups (MBW = 1 layout)][tail group: [chunk][9][2][64]]
+    const float* wgrp = a.w + (long long)ph * a.wphase_stride + (long long)a.tail_grp * a.wgroup_stride;
+
+    f32x4 acc[NPOS];
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF_TT * 4;
+        const unsigned u_addr = buf_addr + WCK * RAW_PLANE_TT * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS_TT;
+        constexpr int N1K = U_FLOATS_TT / 256;               // 4 pieces of 1 KiB, then 2 of 256 bytes
+        if (wave < N1K) dma_global_x4(u_addr + wave * 1024, wsrc + wave * 256 + lane * 4);
+        for (int fr = N1K * 4 + wave; fr < U_FLOATS_TT / 64; fr += 8) dma_global_x1(u_addr + fr * 256, wsrc + fr * 64 + lane);
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE_TT * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int tb = wave;
+    const int patch0 = (lane >> 4) * RAW_PLANE_TT + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 4 - pl;
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF_TT;
+        const float* ub = raw + WCK * RAW_PLANE_TT + lane;
+        dma_wait_all();
+        __syncthreads();
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][NPOS];
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE_TT;
+            float d[3][3], t[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[r][c] = rp[r * RAW_PITCH + c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                t[0][c] = d[0][c] - d[1][c];
+                t[1][c] = d[1][c];
+                t[2][c] = d[2][c] - d[1][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                v[c4][r * 3 + 0] = t[r][0] - t[r][1];
+                v[c4][r * 3 + 1] = t[r][1];
+                v[c4][r * 3 + 2] = t[r][2] - t[r][1];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4) {
+                const float av = ub[(p * 2 + c4) * 64];
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c4][p], acc[p], 0, 0, 0);
+            }
+    }
+    const int xo = x0 + 2 * (lane & 15);
+    const int yb = y0 + 2 * tb;
+    if (xo >= W) return;
+    const int OW = 2 * W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cout = a.tail_grp * 32 + (lane >> 4) * 4 + r;
+        if (cout >= a.Cout) continue;
+        float s0[3], s1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s0[c] = acc[0 + c][r] + acc[3 + c][r];
+            s1[c] = acc[3 + c][r] + acc[6 + c][r];
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1];
+        y[0][1] = s0[1] + s0[2];
+        y[1][0] = s1[0] + s1[1];
+        y[1][1] = s1[1] + s1[2];
+        const float bs = a.bias ? a.bias[cout] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int yo = yb + i;
+            if (yo >= H) continue;
+            float* o = a.dst + ((long long)(b * a.Cout + cout) * (2 * H) + (2 * yo + py)) * OW + 2 * xo + px;
+            o[0] = act_t(y[i][0] + bs, a.act, a.p0);
+            if (xo + 1 < W) o[2] = act_t(y[i][1] + bs, a.act, a.p0);
+        }
+    }
+}
+
 // ---- variant with the input transform in registers (mr_wino_desc.variant = 1; same idea as conv3x3_wino_rb_kernel) -----------------
 // The B operand of the MFMA for (position p, channel quad c4) is V[p][4 c4 + (lane >> 4)][tile lane & 15]: the lane that needs it
 // reads the 3x3 patch of its channel at its tile from the raw region (9 LDS reads per channel quad), transforms it (6 subtractions)
@@ -233,6 +361,7 @@ __global__ __launch_bounds__(512) void convt4x4_wino_kernel(const WinoTKArgs a) 
 template <int MBW>
 __global__ __launch_bounds__(512) void convt4x4_wino_rb_kernel(const WinoTKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (MBW == 1 && (int)blockIdx.y == a.tail_grp) { convt_rb_tail(a, lds); return; }    // 16-channel tail group: 16-row workgroups
     constexpr int U_FLOATS = NPOS * 2 * (2 * MBW) * 64;
     constexpr int U_PAD = (U_FLOATS + 255) & ~255;
     constexpr int BUF = WCK * RAW_PLANE + U_PAD;
@@ -406,10 +535,19 @@ int derive_t(const mr_wino_desc* d, WinoTDerived* out) {
     k.wphase_stride = (long long)groups * nchunks * ufl;
     if (d->batch * 4 >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
     out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)(d->batch * 4));
-    if (d->variant != 0 && d->variant != 1) return MR_ERR_BAD_ARGUMENT;
-    out->regb = d->variant == 1;
+    if (d->variant < 0 || d->variant > 2) return MR_ERR_BAD_ARGUMENT;
+    out->regb = d->variant >= 1;
     out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ((ufl + 255) & ~255)) + (out->regb ? 0 : V_FLOATS)) * 4;
     out->mbw = mbw;
+    k.tail_grp = -1;
+    k.tiles_y16 = (d->height + 15) / 16;
+    if (d->variant == 2) {                                   // 32 a + (1..16) channels: the tail by 16-row workgroups
+        const int rem = d->out_channels % 32;
+        if (mbw != 1 || rem < 1 || rem > 16) return MR_ERR_BAD_ARGUMENT;
+        k.tail_grp = d->out_channels / 32;
+        k.wphase_stride = (long long)k.tail_grp * nchunks * ufl + (long long)nchunks * U_FLOATS_TT;
+        if ((size_t)2 * BUF_TT * 4 > out->lds_bytes) out->lds_bytes = (size_t)2 * BUF_TT * 4;
+    }
     return 0;
 }
 
@@ -464,6 +602,53 @@ extern "C" int mr_wino_t_pack_weights_f32(const float* weight, int32_t out_chann
                             for (int mb = 0; mb < 2 * mbw; ++mb)
                                 for (int lane = 0; lane < 64; ++lane) {
                                     const int cout = g * 32 * mbw + mb * 16 + (lane & 15);
+                                    const int cl = c0 + c4 * 4 + (lane >> 4);
+                                    double u = 0.0;
+                                    if (cout < out_channels && cl < src_channels[s]) {
+                                        const float* gw = weight + ((size_t)(cin_off + cl) * out_channels + cout) * 16;
+                                        const int pa = p / 3, pb = p % 3;
+                                        for (int i = 0; i < 2; ++i)
+                                            for (int j = 0; j < 2; ++j) u += G[pa][i] * (double)gw[taps[py][i] * 4 + taps[px][j]] * G[pb][j];
+                                    }
+                                    dst[o++] = (float)u;
+                                }
+                cin_off += src_channels[s];
+            }
+        }
+    }
+    return 0;
+}
+
+// Variant 2 (out_channels = 32 a + r, 0 < r <= 16): per parity the a full groups exactly as mr_wino_t_pack_weights_f32(mbw = 1) lays them
+// out, then the tail group as [chunk][position][channel quad][64 lanes], lane l = (cout 32 a + (l & 15), channel l >> 4).
+extern "C" size_t mr_wino_t_packed_weight_floats_tail(int32_t out_channels, const int32_t* src_channels, int32_t num_src) {
+    if (!src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || out_channels < 1) return 0;
+    const int rem = out_channels % 32;
+    if (rem < 1 || rem > 16) return 0;
+    int nchunks = 0;
+    for (int s = 0; s < num_src; ++s) nchunks += pad8(src_channels[s]) / WCK;
+    return (size_t)4 * ((size_t)(out_channels / 32) * nchunks * (NPOS * 2 * 2 * 64) + (size_t)nchunks * U_FLOATS_TT);
+}
+
+extern "C" int mr_wino_t_pack_weights_tail_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst) {
+    if (!weight || !dst || mr_wino_t_packed_weight_floats_tail(out_channels, src_channels, num_src) == 0) return MR_ERR_BAD_ARGUMENT;
+    static const double G[3][2] = {{1.0, 0.0}, {1.0, 1.0}, {0.0, 1.0}};
+    static const int taps[2][2] = {{3, 1}, {2, 0}};
+    const int full = out_channels / 32;
+    size_t o = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        for (int g = 0; g <= full; ++g) {                    // g == full: the tail group (one block of 16 channels)
+            const int nblk = g < full ? 2 : 1;
+            int cin_off = 0;
+            for (int s = 0; s < num_src; ++s) {
+                const int cpad = pad8(src_channels[s]);
+                for (int c0 = 0; c0 < cpad; c0 += WCK)
+                    for (int p = 0; p < NPOS; ++p)
+                        for (int c4 = 0; c4 < 2; ++c4)
+                            for (int mb = 0; mb < nblk; ++mb)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int cout = g * 32 + mb * 16 + (lane & 15);
                                     const int cl = c0 + c4 * 4 + (lane >> 4);
                                     double u = 0.0;
                                     if (cout < out_channels && cl < src_channels[s]) {

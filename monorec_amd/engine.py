@@ -170,7 +170,8 @@ def winograd_signature(cout, src_channels, h, w, batch):
 
 def choose_winograd(cout, src_channels, h, w, batch):
     """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
-    11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), for a 3x3 stride-1 convolution.  The
+    11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), 21 = variant 2 (11 whose 1..16 tail channels
+    come from 16-row workgroups: the 48-channel layers), for a 3x3 stride-1 convolution.  The
     measured table (tools/bench_wino.py --emit, MI355X) wins; shapes it does not know go to the Winograd kernel when it has enough
     workgroups (8 x 32 output pixels each) to fill the chip - below that the direct kernel's smaller tiles and split-K win
     (measured: every ResNet layer of a batch-1 keyframe) - with the variant that measured faster at that width on every shape of
@@ -462,9 +463,15 @@ class Plan:
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = weight.detach().to(torch.float32).contiguous().cpu()
-        nfl = lib.mr_wino_packed_weight_floats(cout, sc, len(src_channels), mbw)
-        packed = torch.empty(nfl, dtype=torch.float32)
-        _lib.check(lib.mr_wino_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino_pack_weights_f32")
+        if variant == 2:       # 32 a + (1..16) output channels: the tail group by 16-row workgroups (csrc/conv_wino.hip: wino_rb_tail)
+            assert mbw == 1 and 0 < cout % 32 <= 16, (name, cout)
+            nfl = lib.mr_wino_packed_weight_floats_tail(cout, sc, len(src_channels))
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino_pack_weights_tail_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino_pack_weights_tail_f32")
+        else:
+            nfl = lib.mr_wino_packed_weight_floats(cout, sc, len(src_channels), mbw)
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino_pack_weights_f32")
         d = WinoDesc()
         for i, s_ in enumerate(srcs):
             d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
@@ -546,9 +553,15 @@ class Plan:
         assert cin == sum(src_channels) and tuple(wt.shape[2:]) == (4, 4), (name, wt.shape, src_channels)
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = wt.detach().to(torch.float32).contiguous().cpu()
-        nfl = lib.mr_wino_t_packed_weight_floats(cout, sc, len(src_channels), mbw)
-        packed = torch.empty(nfl, dtype=torch.float32)
-        _lib.check(lib.mr_wino_t_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino_t_pack_weights_f32")
+        if variant == 2:       # 32 a + (1..16) output channels: the tail group by 16-row workgroups (csrc/convt_wino.hip: convt_rb_tail)
+            assert mbw == 1 and 0 < cout % 32 <= 16, (name, cout)
+            nfl = lib.mr_wino_t_packed_weight_floats_tail(cout, sc, len(src_channels))
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino_t_pack_weights_tail_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino_t_pack_weights_tail_f32")
+        else:
+            nfl = lib.mr_wino_t_packed_weight_floats(cout, sc, len(src_channels), mbw)
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino_t_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino_t_pack_weights_f32")
         d = WinoDesc()
         for i, s_ in enumerate(srcs):
             assert s_.is_contiguous() and tuple(s_.shape[2:]) == (hs, ws) and s_.shape[0] == n

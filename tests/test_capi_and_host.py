@@ -266,6 +266,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
                                          "mask.dec3.2", "depth.dec4.2"}
     assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
+    assert {c["name"] for c in wino if c.get("wino_variant") == 2} == {"mask.dec3.1", "mask.dec3.2"}     # 48 channels: 32 + a 16-channel tail
     # ... and the two large Refine layers (ConvTranspose2d(4, 2)) on the F(2x2,2x2) kernel (csrc/convt_wino.hip) at 9/16
     wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4]
     assert {c["name"] for c in wino_t} == {"depth.dec2.0", "depth.dec3"}
@@ -662,7 +663,7 @@ def test_winograd_choice_table_and_rule():
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 4, 11, 12, 14}     # + 10: input transform in registers (mr_wino_desc.variant)
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 4, 11, 12, 14, 21} # + 10: input transform in registers, + 20: ... with 16-channel tail workgroups
     assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
     assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
     assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) % 10 == 2    # mask.enc0.*, mask.dec3.1 @ c2

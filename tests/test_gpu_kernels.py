@@ -610,10 +610,13 @@ WINO_CASES = [
     ((5, 11), 40, (13, 20), 3, ACT_NONE, False, 2),                   # ragged everything: C % 8 != 0, H % 8 != 0, W % 32 != 0, cout % 32 != 0
     ((3,), 7, (9, 4), 1, ACT_NONE, False, 1),                         # tiny
     ((96,), 96, (32, 64), 2, ACT_LEAKY_RELU, False, 2),               # two cout groups of 64 (second half empty)
+    ((48,), 48, (40, 96), 2, ACT_LEAKY_RELU, False, 2),               # 48 = 32 + 16 (variant 2: one full group + the tail group); H % 16 != 0
+    ((24, 8), 80, (17, 36), 1, ACT_RELU, True, 2),                    # 80 = 64 + 16, ragged sizes, residual
+    ((10,), 12, (33, 64), 1, ACT_NONE, False, 1),                     # 12 channels: tail group only
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", range(len(WINO_CASES)))
 def test_winograd_conv_matches_torch_fp32(hip_lib, case, variant):
     """mr_conv3x3_winograd_f32 against F.conv2d(padding=1) on the CPU: the transforms round differently from the direct sum, so the
@@ -621,6 +624,10 @@ def test_winograd_conv_matches_torch_fp32(hip_lib, case, variant):
     registers) - they must also agree with each other bit for bit."""
     srcs_c, cout, (h, w), batch, act, residual, mbw = WINO_CASES[case]
     lib = hip_lib
+    if variant == 2:                                  # 16-channel tail workgroups: 32 a + (1..16) output channels, 32 per full workgroup
+        if not 0 < cout % 32 <= 16:
+            pytest.skip("variant 2 is for out_channels = 32 a + r, 0 < r <= 16")
+        mbw = 1
     g = torch.Generator().manual_seed(100 + case)
     srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
     cin = sum(srcs_c)
@@ -632,9 +639,14 @@ def test_winograd_conv_matches_torch_fp32(hip_lib, case, variant):
         ref = ref + res
     ref = _act_ref(ref, act, 0.1, 0.0)
     sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
-    n = lib.mr_wino_packed_weight_floats(cout, sc, len(srcs_c), mbw)
-    packed = torch.empty(n)
-    _lib.check(lib.mr_wino_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+    if variant == 2:
+        n = lib.mr_wino_packed_weight_floats_tail(cout, sc, len(srcs_c))
+        packed = torch.empty(n)
+        _lib.check(lib.mr_wino_pack_weights_tail_f32(wt.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
+    else:
+        n = lib.mr_wino_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+        packed = torch.empty(n)
+        _lib.check(lib.mr_wino_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
     d = _lib.WinoDesc()
     dsrcs = [s.to(DEV) for s in srcs]
     for i, s in enumerate(dsrcs):
@@ -668,8 +680,10 @@ def test_winograd_bad_arguments(hip_lib):
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -2          # width % 4 != 0
     d.width, d.cout_blocks_per_wave = 8, 3
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1
-    d.cout_blocks_per_wave, d.variant = 1, 2
+    d.cout_blocks_per_wave, d.variant = 1, 3
     assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1          # unknown variant
+    d.out_channels, d.variant = 64, 2
+    assert hip_lib.mr_conv3x3_winograd_f32(ctypes.byref(d), _stream()) == -1          # variant 2 needs out_channels = 32 a + (1..16)
 
 
 # ---- ConvTranspose2d(4, 2) + crop as Winograd F(2x2,2x2) (csrc/convt_wino.hip) ------------------------------------------------------
@@ -681,10 +695,11 @@ WINO_T_CASES = [
     ((5, 11), 40, (13, 20), 3, ACT_NONE, 2),                          # ragged: C % 8, h % 8, w % 32, cout % 64
     ((3,), 7, (5, 4), 1, ACT_LEAKY_RELU, 1),
     ((40,), 256, (4, 8), 1, ACT_LEAKY_RELU, 4),                       # two cout groups of 128
+    ((24,), 80, (19, 36), 2, ACT_LEAKY_RELU, 2),                      # 80 = 64 + 16: two full groups + the tail group (variant 2), ragged rows
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", range(len(WINO_T_CASES)))
 def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case, variant):
     """mr_convt4x4s2_winograd_f32 against F.conv_transpose2d(stride=2) cropped by one pixel on every side (layers.Refine,
@@ -692,6 +707,10 @@ def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case, variant):
     agree bit for bit."""
     srcs_c, cout, (h, w), batch, act, mbw = WINO_T_CASES[case]
     lib = hip_lib
+    if variant == 2:
+        if not 0 < cout % 32 <= 16:
+            pytest.skip("variant 2 is for out_channels = 32 a + r, 0 < r <= 16")
+        mbw = 1
     g = torch.Generator().manual_seed(200 + case)
     srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
     cin = sum(srcs_c)
@@ -699,9 +718,14 @@ def test_winograd_transposed_conv_matches_torch_fp32(hip_lib, case, variant):
     bias = torch.randn(cout, generator=g) * 0.1
     ref = _act_ref(F.conv_transpose2d(torch.cat(srcs, 1), wt, bias, stride=2)[:, :, 1:-1, 1:-1], act, 0.1, 0.0)
     sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
-    n = lib.mr_wino_t_packed_weight_floats(cout, sc, len(srcs_c), mbw)
-    packed = torch.empty(n)
-    _lib.check(lib.mr_wino_t_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+    if variant == 2:
+        n = lib.mr_wino_t_packed_weight_floats_tail(cout, sc, len(srcs_c))
+        packed = torch.empty(n)
+        _lib.check(lib.mr_wino_t_pack_weights_tail_f32(wt.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
+    else:
+        n = lib.mr_wino_t_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+        packed = torch.empty(n)
+        _lib.check(lib.mr_wino_t_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
     d = _lib.WinoDesc()
     dsrcs = [s.to(DEV) for s in srcs]
     for i, s in enumerate(dsrcs):
@@ -735,7 +759,7 @@ def test_plan_refine_on_the_transposed_winograd_kernel(hip_lib, monkeypatch):
     bias = torch.randn(48, generator=g) * 0.1
     ref = F.leaky_relu(F.conv_transpose2d(torch.cat(srcs, 1), wt, bias, stride=2)[:, :, 1:-1, 1:-1], 0.1)
     outs = []
-    for code in (0, 12, 1):
+    for code in (0, 12, 1, 21):
         monkeypatch.setitem(engine.WINOGRAD, "t_" + engine.winograd_signature(48, [16, 24], 24, 32, 1), code)
         plan = engine.Plan.bare(DEV, state={"x.conv2d_t.weight": wt, "x.conv2d_t.bias": bias})
         plan.winograd = True

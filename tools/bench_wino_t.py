@@ -57,13 +57,20 @@ def main():
         sc = [int(s.shape[1]) for s in srcs]
         arr = (ctypes.c_int32 * len(sc))(*sc)
         best, best_code = row["direct_us"], 0
-        for code in (1, 2, 4, 11, 12, 14):                   # output-channel blocks per wave; + 10: input transform in registers
+        for code in (1, 2, 4, 11, 12, 14, 21):               # output-channel blocks per wave; + 10: input transform in registers; + 20: ... with tail workgroups
             mbw, variant = code % 10, code // 10
             if 32 * mbw >= 2 * cout and mbw > 1:
                 continue
-            n = lib.mr_wino_t_packed_weight_floats(cout, arr, len(sc), mbw)
-            packed = torch.empty(n)
-            _lib.check(lib.mr_wino_t_pack_weights_f32(wt.data_ptr(), cout, arr, len(sc), mbw, packed.data_ptr()), "pack")
+            if variant == 2:
+                if not 0 < cout % 32 <= 16:
+                    continue
+                n = lib.mr_wino_t_packed_weight_floats_tail(cout, arr, len(sc))
+                packed = torch.empty(n)
+                _lib.check(lib.mr_wino_t_pack_weights_tail_f32(wt.data_ptr(), cout, arr, len(sc), packed.data_ptr()), "pack")
+            else:
+                n = lib.mr_wino_t_packed_weight_floats(cout, arr, len(sc), mbw)
+                packed = torch.empty(n)
+                _lib.check(lib.mr_wino_t_pack_weights_f32(wt.data_ptr(), cout, arr, len(sc), mbw, packed.data_ptr()), "pack")
             d = _lib.WinoDesc()
             for i, s in enumerate(srcs):
                 d.src[i], d.src_channels[i] = s.data_ptr(), sc[i]

@@ -666,7 +666,7 @@ def test_winograd_choice_table_and_rule():
     assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 4, 11, 12, 14, 21} # + 10: input transform in registers, + 20: ... with 16-channel tail workgroups
     assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
     assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
-    assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) % 10 == 2    # mask.enc0.*, mask.dec3.1 @ c2
+    assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) in (2, 12, 21)  # mask.enc0.*, mask.dec3.1 @ c2
     assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
     assert engine.choose_winograd(64, [64], 256, 512, 32) in (2, 11, 12)                                                     # mask.enc0.* @ c3
     assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct

@@ -455,9 +455,11 @@ def main():
                     with torch.cuda.stream(s_result):
                         last[0] = pending.popleft().result()
             else:
+                req = dict(batch_dev)
+                token = model.prepare(req)                       # pose algebra of this request while the device is busy ...
                 if len(pending) >= args.in_flight:
-                    last[0] = pending.popleft().synchronize()
-                pending.append(model.submit(dict(batch_dev)))
+                    last[0] = pending.popleft().synchronize()    # ... then the result whose slot the submit below reuses
+                pending.append(model.submit(req, token))
         return last[0]
 
     def drain():

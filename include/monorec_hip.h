@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 10
+#define MR_ABI_VERSION 11
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -213,6 +213,21 @@ size_t mr_wino_packed_weight_floats_tail(int32_t out_channels, const int32_t* sr
 int mr_wino_pack_weights_tail_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
 int64_t mr_conv3x3_winograd_lds_bytes(const mr_wino_desc* desc);   /* dynamic LDS of the launch, or a negative MR_ERR_* code */
 int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
+
+/*
+ * 3x1 / 1x3, stride 1, zero padding 1 along the filter axis (PadSameConv2d + nn.Conv2d of layers.ConvReLU2, model/layers.py:289-314: the
+ * second pair of every DepthModule encoder stage, dec{1,2}.1, dec4.0 - model/monorec/monorec_model.py:485-513) as 1-D Winograd F(2, 3):
+ * 4 multiplies per (input channel, output channel) and 2 outputs instead of 6.  Same descriptor and conventions as
+ * mr_conv3x3_winograd_f32 (sources concatenated on channels and read in place, bias / activation in the epilogue, dst = (batch,
+ * out_channels, height, width), width % 4 == 0); no residual; `variant` ignored; cout_blocks_per_wave 1..4: a workgroup (8 waves, 8 x 32
+ * output pixels) produces 16 x that many output channels.  axis 0: 1 x 3 (along x), weight (out, in, 1, 3); axis 1: 3 x 1 (along y),
+ * weight (out, in, 3, 1) - three taps per (out, in) in memory either way.
+ */
+size_t mr_wino1d_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
+int mr_wino1d_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                               int32_t cout_blocks_per_wave, float* dst);
+int64_t mr_conv1d3_winograd_lds_bytes(const mr_wino_desc* desc);
+int mr_conv1d3_winograd_f32(const mr_wino_desc* desc, int32_t axis, void* stream);
 
 /*
  * nn.ConvTranspose2d(kernel 4, stride 2) + the centre crop of layers.Refine (model/layers.py:380-400: the decoder stages of the

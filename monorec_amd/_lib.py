@@ -68,7 +68,7 @@ class WinoDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 10            # include/monorec_hip.h
+MR_ABI_VERSION = 11            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -139,6 +139,10 @@ ABI = {
                                          ctypes.c_int32, ctypes.c_void_p]),
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "mr_exact_const_division": (ctypes.c_int, [ctypes.c_float]),
+    "mr_wino1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32]),
+    "mr_wino1d_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv1d3_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_conv1d3_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_int32, ctypes.c_void_p]),
     "mr_wino_t_packed_weight_floats_tail": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
     "mr_wino_t_pack_weights_tail_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
     "mr_wino_packed_weight_floats_tail": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),

@@ -26,6 +26,7 @@ SOURCES = [
     ("heads.hip", []),
     ("conv_wino.hip", []),
     ("convt_wino.hip", []),
+    ("conv1d_wino.hip", []),
 ]
 
 

@@ -1,0 +1,318 @@
+// 3x1 / 1x3 stride-1 convolutions as 1-D Winograd F(2, 3) on the fp32 matrix cores of gfx950 (MI355X).
+//
+// layers.ConvReLU2 (reference model/layers.py:289-314) splits every k x k convolution of the DepthModule
+// (model/monorec/monorec_model.py:485-513) into a k x 1 and a 1 x k one; sixteen of them per keyframe are 3-tap, stride 1, 'same'
+// padded (enc{0..4}.1, dec{1,2}.1, dec4.0: 7.3 of the 27.2 GMAC of the depth net at c2).  F(2, 3) computes 2 outputs along the filter
+// axis from 4 inputs with 4 multiplies per (cin, cout) instead of 6:
+//     y = A^T [ sum_cin (G g) o (B^T d) ],   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
+//     A^T = [1 1 1 0; 0 1 -1 -1]
+// - the 1-D factor of the F(2x2, 3x3) kernel in conv_wino.hip, and the same skeleton as its in-register-transform variant:
+// workgroup = 8 waves, 8 x 32 output pixels, 16 * MBW output channels (every wave sweeps ALL of them: MBW = 3 covers the 48-channel
+// layers without padding), K in chunks of 8 input channels; the haloed region (10 rows x 40 columns, 16-byte aligned; one halo
+// direction is unused) and the chunk's U fragments (G g, formed in double, rounded once; 2 KiB per 16 output channels) arrive by LDS-DMA
+// in one of two pipeline buffers (<= 42 KB: three to four workgroups share a CU); ONE barrier per chunk.
+//   AXIS 0 (1 x 3, along x): wave = output row, lane & 15 = tile of 2 columns; AXIS 1 (3 x 1, along y): wave = (tile of 2 rows, half of
+//   the 32 columns), lane & 15 = column.  Either way a lane reads the 4 inputs of its tile for its channel (lane >> 4 of the quad) from
+//   the raw region, transforms them (4 adds) and holds the 4 values as MFMA B operands; it ends up with the 4 positions of its
+//   (cout, tile) in registers, so the output transform, bias and LeakyReLU run there as well.
+// The sum over cin is the exact-order fp32 FMA chain of every MFMA; the transforms round differently from the direct sum (~1e-6
+// relative on O(1) outputs, like the 2-D kernel).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <atomic>
+
+#include "../../include/monorec_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WCK = 8;                                   // input channels per chunk (one per wave in the DMA phase)
+constexpr int RAW_PITCH = 40, RAW_ROWS = 10, RAW_PLANE = RAW_PITCH * RAW_ROWS;   // rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35
+constexpr int NPOS = 4;
+
+struct W1KArgs {
+    const float* src[MR_MAX_SOURCES];
+    int src_bytes[MR_MAX_SOURCES];
+    int src_c[MR_MAX_SOURCES];
+    int src_cpad[MR_MAX_SOURCES];       // padded to a multiple of WCK
+    int nsrc;
+    int H, W;
+    float* dst;
+    const float* bias;
+    int act;
+    float p0;
+    int Cout, tiles_x, nchunks;
+    const float* w;
+    long long wgroup_stride;            // packed floats per cout group
+};
+
+// LDS-DMA through inline asm (see conv_mfma.hip: the builtins make hipcc drain vmcnt before every sweep)
+__device__ __forceinline__ void dma_buffer_x4(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
+    unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const float* g) {
+    unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ float act1(float v, int act, float p0) {
+    switch (act) {
+        case MR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MR_ACT_LEAKY_RELU: return v > 0.f ? v : v * p0;
+        default: return v;
+    }
+}
+
+template <int AXIS, int MBW>
+__global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int U_FLOATS = NPOS * 2 * MBW * 64;            // U fragments of one chunk: [p][c4][cout block][64 lanes]
+    constexpr int BUF = WCK * RAW_PLANE + U_FLOATS;          // one pipeline buffer: raw input region + U
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    const int oy0 = ty_wg * 8, ox0 = tx_wg * 32;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[2];                                             // lane l owns the 16-byte groups r = l, l + 64 (< 100): row r / 10, group r % 10
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / 10, g4 = r - row * 10;
+        const int gy = oy0 - 1 + row, gx = ox0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < RAW_ROWS * 10 ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)grp * a.wgroup_stride;
+
+    f32x4 acc[NPOS][MBW];
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;                                      // chunk cursor: source, first channel
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF * 4;
+        const unsigned u_addr = buf_addr + WCK * RAW_PLANE * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS;
+        if (wave < U_FLOATS / 256) dma_global_x4(u_addr + wave * 1024, wsrc + wave * 256 + lane * 4);     // 2 MBW <= 8 pieces of 1 KiB
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];            // padded channels read as zero
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    // the 4 inputs of this lane's tile, channel lane >> 4 of a quad: offsets patch0 + i * pstep in its channel plane
+    const int t = lane & 15;
+    const int patch0 = (lane >> 4) * RAW_PLANE + (AXIS == 0 ? (wave + 1) * RAW_PITCH + 2 * t + 3
+                                                            : (2 * (wave >> 1)) * RAW_PITCH + 4 + (wave & 1) * 16 + t);
+    constexpr int pstep = AXIS == 0 ? 1 : RAW_PITCH;
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF;
+        const float* ub = raw + WCK * RAW_PLANE + lane;
+        dma_wait_all();
+        __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][NPOS];                                     // B operands of this lane: (B^T d)[p] of channels 4 c4 + (lane >> 4)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE;
+            const float d0 = rp[0], d1 = rp[pstep], d2 = rp[2 * pstep], d3 = rp[3 * pstep];
+            v[c4][0] = d0 - d2;
+            v[c4][1] = d1 + d2;
+            v[c4][2] = d2 - d1;
+            v[c4][3] = d1 - d3;
+        }
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    const float av = ub[((p * 2 + c4) * MBW + m) * 64];
+                    acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c4][p], acc[p][m], 0, 0, 0);
+                }
+    }
+    // ---- output transform y = A^T m per (cout, tile) in registers, epilogue ------------------------------------------------------
+    const int ox = ox0 + (AXIS == 0 ? 2 * t : (wave & 1) * 16 + t);
+    const int oy = oy0 + (AXIS == 0 ? wave : 2 * (wave >> 1));
+    if (ox >= W || oy >= H) return;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cout = (grp * MBW + m) * 16 + (lane >> 4) * 4 + r;
+            if (cout >= a.Cout) continue;
+            const float bs = a.bias ? a.bias[cout] : 0.f;
+            const float y0 = act1(((acc[0][m][r] + acc[1][m][r]) + acc[2][m][r]) + bs, a.act, a.p0);
+            const float y1 = act1(((acc[1][m][r] - acc[2][m][r]) - acc[3][m][r]) + bs, a.act, a.p0);
+            float* o = a.dst + ((long long)(b * a.Cout + cout) * H + oy) * W + ox;
+            if (AXIS == 0) {
+                *(float2*)o = make_float2(y0, y1);             // W % 4 == 0 and ox even: both columns exist
+            } else {
+                o[0] = y0;
+                if (oy + 1 < H) o[W] = y1;
+            }
+        }
+}
+
+bool valid_mbw1(int m) { return m >= 1 && m <= 4; }
+int pad8(int c) { return (c + 7) & ~7; }
+
+struct W1Derived {
+    W1KArgs k;
+    dim3 grid;
+    size_t lds_bytes;
+    int mbw;
+};
+
+int derive1(const mr_wino_desc* d, W1Derived* out) {
+    if (!d || d->num_src < 1 || d->num_src > MR_MAX_SOURCES || d->batch < 1 || d->height < 1 || d->width < 4 || !d->dst ||
+        !d->packed_weights || d->out_channels < 1)
+        return MR_ERR_BAD_ARGUMENT;
+    if (d->width % 4) return MR_ERR_UNSUPPORTED;              // 16-byte groups entirely inside or outside the image
+    if (d->residual) return MR_ERR_UNSUPPORTED;
+    if (!valid_mbw1(d->cout_blocks_per_wave)) return MR_ERR_BAD_ARGUMENT;
+    if (d->activation != MR_ACT_NONE && d->activation != MR_ACT_RELU && d->activation != MR_ACT_LEAKY_RELU) return MR_ERR_UNSUPPORTED;
+    W1KArgs& k = out->k;
+    memset(&k, 0, sizeof(k));
+    int nchunks = 0;
+    for (int s = 0; s < d->num_src; ++s) {
+        if (!d->src[s] || d->src_channels[s] < 1) return MR_ERR_BAD_ARGUMENT;
+        const long long bytes = (long long)d->batch * d->src_channels[s] * d->height * d->width * 4;
+        if (bytes >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
+        k.src[s] = d->src[s];
+        k.src_bytes[s] = (int)bytes;
+        k.src_c[s] = d->src_channels[s];
+        k.src_cpad[s] = pad8(d->src_channels[s]);
+        nchunks += k.src_cpad[s] / WCK;
+    }
+    if ((long long)d->batch * d->out_channels * d->height * d->width * 4 >= (1ll << 33)) return MR_ERR_UNSUPPORTED;
+    k.nsrc = d->num_src;
+    k.H = d->height; k.W = d->width;
+    k.dst = d->dst; k.bias = d->bias;
+    k.act = d->activation; k.p0 = d->act_p0;
+    k.Cout = d->out_channels;
+    k.tiles_x = (d->width + 31) / 32;
+    k.nchunks = nchunks;
+    k.w = d->packed_weights;
+    const int mbw = d->cout_blocks_per_wave;
+    const int ufl = NPOS * 2 * mbw * 64;
+    k.wgroup_stride = (long long)nchunks * ufl;
+    const int groups = (d->out_channels + 16 * mbw - 1) / (16 * mbw);
+    if (d->batch >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
+    out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)d->batch);
+    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ufl)) * 4;
+    out->mbw = mbw;
+    return 0;
+}
+
+template <int AXIS, int MBW>
+int launch1(const W1Derived& dv, hipStream_t stream) {
+    hipLaunchKernelGGL((conv1d3_wino_kernel<AXIS, MBW>), dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);   // <= 42 KB of LDS: no attribute needed
+    return (int)hipGetLastError();
+}
+
+template <int AXIS>
+int launch1_mbw(const W1Derived& dv, hipStream_t stream) {
+    switch (dv.mbw) {
+        case 1: return launch1<AXIS, 1>(dv, stream);
+        case 2: return launch1<AXIS, 2>(dv, stream);
+        case 3: return launch1<AXIS, 3>(dv, stream);
+        default: return launch1<AXIS, 4>(dv, stream);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mr_wino1d_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t mbw) {
+    if (!src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || !valid_mbw1(mbw) || out_channels < 1) return 0;
+    int nchunks = 0;
+    for (int s = 0; s < num_src; ++s) nchunks += pad8(src_channels[s]) / WCK;
+    const int groups = (out_channels + 16 * mbw - 1) / (16 * mbw);
+    return (size_t)groups * nchunks * (NPOS * 2 * mbw * 64);
+}
+
+// weight: (out_channels, sum(src_channels), 3, 1) or (out_channels, sum(src_channels), 1, 3) fp32, nn.Conv2d layout - three taps per
+// (cout, cin) either way.  U = G g in double, rounded once to fp32; stream order
+// [cout group of 16 mbw][chunk (source-major, 8 channels)][position][channel quad][cout block of the group][64 lanes],
+// lane l = (cout l & 15 of the block, channel l >> 4 of the quad).
+extern "C" int mr_wino1d_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                          int32_t mbw, float* dst) {
+    if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || !valid_mbw1(mbw) || out_channels < 1)
+        return MR_ERR_BAD_ARGUMENT;
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    int cin_total = 0;
+    for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
+    const int groups = (out_channels + 16 * mbw - 1) / (16 * mbw);
+    size_t o = 0;
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = pad8(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += WCK)
+                for (int p = 0; p < NPOS; ++p)
+                    for (int c4 = 0; c4 < 2; ++c4)
+                        for (int mb = 0; mb < mbw; ++mb)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int cout = (g * mbw + mb) * 16 + (lane & 15);
+                                const int cl = c0 + c4 * 4 + (lane >> 4);
+                                double u = 0.0;
+                                if (cout < out_channels && cl < src_channels[s]) {
+                                    const float* gw = weight + ((size_t)cout * cin_total + (cin_off + cl)) * 3;
+                                    for (int i = 0; i < 3; ++i) u += G[p][i] * (double)gw[i];
+                                }
+                                dst[o++] = (float)u;
+                            }
+            cin_off += src_channels[s];
+        }
+    }
+    return 0;
+}
+
+extern "C" int64_t mr_conv1d3_winograd_lds_bytes(const mr_wino_desc* desc) {
+    W1Derived dv;
+    const int rc = derive1(desc, &dv);
+    return rc != 0 ? rc : (int64_t)dv.lds_bytes;
+}
+
+extern "C" int mr_conv1d3_winograd_f32(const mr_wino_desc* desc, int32_t axis, void* stream) {
+    W1Derived dv;
+    const int rc = derive1(desc, &dv);
+    if (rc != 0) return rc;
+    if (axis == 0) return launch1_mbw<0>(dv, (hipStream_t)stream);
+    if (axis == 1) return launch1_mbw<1>(dv, (hipStream_t)stream);
+    return MR_ERR_BAD_ARGUMENT;
+}

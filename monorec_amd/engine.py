@@ -198,6 +198,15 @@ def choose_winograd_t(cout, src_channels, h, w, batch):
     return WINOGRAD.get("t_" + winograd_signature(cout, src_channels, h, w, batch), 0)
 
 
+def choose_winograd_1d(axis, cout, src_channels, h, w, batch):
+    """3-tap stride-1 'same' convolution along x (axis 0: 1 x 3) or y (axis 1: 3 x 1) - the second pair of every layers.ConvReLU2 stage
+    of the DepthModule: 0 = direct MFMA kernel, 1..4 = the 1-D Winograd F(2,3) kernel (csrc/conv1d_wino.hip) with 16 x that many
+    output channels per workgroup.  Only what the measured table says (tools/bench_wino1d.py --emit; keys prefixed `x_` / `y_`)."""
+    if w % 4:
+        return 0
+    return WINOGRAD.get(("x_", "y_")[axis] + winograd_signature(cout, src_channels, h, w, batch), 0)
+
+
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
     """`mixed_phases`: the phases sweep different tap counts (phase-decomposed Upconv: 1, 2, 2 and 4 taps of a 2x2 tile)."""
     return (f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{sh}x{sw}_o{out_h}x{out_w}_b{batch}_p{phases}"
@@ -385,6 +394,14 @@ class Plan:
             mbw = choose_winograd(cout, src_channels, hs, ws, n)
             if mbw:
                 return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw % 10, mbw // 10)
+        if (self.winograd and phases is None and (kh, kw) in ((1, 3), (3, 1)) and tuple(stride) == (1, 1) and tuple(pad) == (kh // 2, kw // 2) and
+                in_mode == IN_DIRECT and tf == TF_NONE and tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0) and out_ch_offset == 0 and
+                out.shape[1] == cout and tuple(grid) == (hs, ws) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY_RELU) and self.bf16 == 0 and
+                residual is None and name not in self.schedule_override):
+            axis = 0 if kw == 3 else 1
+            mbw = choose_winograd_1d(axis, cout, src_channels, hs, ws, n)
+            if mbw:
+                return self._conv_winograd_1d(stage, name, srcs, weight, bias, out, act, p0, axis, mbw)
         if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
             kh, kw = max(p[0].shape[2] for p in phases), max(p[0].shape[3] for p in phases)
         mixed = phases is not None and any(tuple(p[0].shape[2:]) != (kh, kw) for p in phases)
@@ -501,6 +518,49 @@ class Plan:
 
         def run(stream):
             _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), name)
+        self.stages[stage].append((name, run))
+        return out
+
+    def _conv_winograd_1d(self, stage, name, srcs, weight, bias, out, act, p0, axis, mbw):
+        """One mr_conv1d3_winograd_f32 launch (csrc/conv1d_wino.hip: F(2,3), 4 instead of 6 multiplies per output pair) in place of a
+        3 x 1 / 1 x 3 stride-1 mr_conv2d_f32 launch."""
+        lib = self.lib
+        n, _, hs, ws = srcs[0].shape
+        src_channels = [int(s_.shape[1]) for s_ in srcs]
+        cout, cin = int(weight.shape[0]), int(weight.shape[1])
+        assert tuple(weight.shape[2:]) == ((1, 3) if axis == 0 else (3, 1)) and cin == sum(src_channels), (name, weight.shape)
+        sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
+        w = weight.detach().to(torch.float32).contiguous().cpu()
+        nfl = lib.mr_wino1d_packed_weight_floats(cout, sc, len(src_channels), mbw)
+        packed = torch.empty(nfl, dtype=torch.float32)
+        _lib.check(lib.mr_wino1d_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino1d_pack_weights_f32")
+        d = WinoDesc()
+        for i, s_ in enumerate(srcs):
+            d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
+            if "keyframe" in self.buf and s_ is self.buf["keyframe"]:
+                self._input_srcs.append((d, i, "keyframe"))
+        d.num_src, d.batch, d.height, d.width = len(srcs), n, hs, ws
+        assert out.is_contiguous() and tuple(out.shape) == (n, cout, hs, ws)
+        d.dst, d.out_channels = out.data_ptr(), cout
+        d.packed_weights = self._dev(packed).data_ptr()
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        d.activation, d.act_p0, d.cout_blocks_per_wave = act, p0, mbw
+        lds = lib.mr_conv1d3_winograd_lds_bytes(ctypes.byref(d))
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name} winograd-1d")
+        ref = n * hs * ws * cout * cin * 3
+        wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (16 * mbw))
+        kk = (1, 3) if axis == 0 else (3, 1)
+        self.conv_log.append(dict(name=name, macs=ref * 2 // 3, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+                                  cout=cout, cin=cin, k=kk, out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=0, wino_axis=axis, bf16=0,
+                                  sig=("x_", "y_")[axis] + winograd_signature(cout, src_channels, hs, ws, n),
+                                  spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin) + kk, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2),
+                                            grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=act, p0=p0, p1=0.0, residual=False,
+                                            out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
+        self.keep += [d, out] + list(srcs)
+
+        def run(stream):
+            _lib.check(lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, stream), name)
         self.stages[stage].append((name, run))
         return out
 

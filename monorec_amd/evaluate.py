@@ -103,9 +103,11 @@ class Evaluater:
                     continue
                 data = self._to(data, device)
                 data["target"] = self._to(target, device)
+                token = self.model.prepare(data) if hasattr(self.model, "prepare") else None    # pose algebra while the device is busy
                 if len(pending) >= self.in_flight:                  # the slot the next submit reuses: reduce its result first
                     collect()
-                pending.append((data, self.model.submit(data), rank + i * world if presharded else i))
+                handle = self.model.submit(data, token) if token is not None else self.model.submit(data)
+                pending.append((data, handle, rank + i * world if presharded else i))
             while pending:
                 collect()
         per_batch = []

@@ -181,13 +181,44 @@ class DepthModule(_ParamsOnly):
 
 
 # --------------------------------------------------------------------------------------------------
+_KINV_CACHE = {}    # bytes of the (B, 4, 4) keyframe intrinsics -> kinv (B, 9): a dataset has one intrinsics matrix, every keyframe brings it again
+
+
 def host_geometry(keyframe_intrinsics, keyframe_pose, intrinsics, poses):
     """The 4x4 algebra of CostVolumeModule.forward on CPU fp32 tensors, operation for operation
     (monorec_model.py:171 inverse(pose); :198 inverse(K_kf); :207 ext @ pose_kf; layers.py:65 K @ T).
 
     Done on the host with the same ATen CPU operators as the reference so that the matrices handed to
     the kernel are bit-identical to the reference's (the only ill-conditioned step of the path,
-    SURVEY.md section 0).  Returns kinv (B,9) and proj (B,F,12)."""
+    SURVEY.md section 0).  Returns kinv (B,9) and proj (B,F,12).
+
+    It sits on the critical path of every keyframe (the cost volume cannot start before it), so it is kept short: the F pose
+    inversions are ONE batched call (the CPU kernel loops over the matrices with the same LAPACK routine - bit-identical to F
+    calls, asserted in tests/test_capi_and_host.py) and the inverse of the keyframe intrinsics is remembered by content."""
+    b = keyframe_pose.shape[0]
+    nf = len(poses)
+    key = keyframe_intrinsics.detach().contiguous().numpy().tobytes()
+    kinv = _KINV_CACHE.get(key)
+    if kinv is None:
+        kinv = torch.empty(b, 9)
+        for n in range(b):
+            kinv[n] = torch.inverse(keyframe_intrinsics[n]).unsqueeze(0)[:, :3, :3].reshape(9)
+        if len(_KINV_CACHE) >= 16:
+            _KINV_CACHE.clear()
+        _KINV_CACHE[key] = kinv
+    proj = torch.empty(b, nf, 12)
+    if nf:
+        extr = torch.inverse(torch.stack([p for p in poses]))           # (F, B, 4, 4)
+        for n in range(b):
+            kp = keyframe_pose[n]
+            for f in range(nf):
+                t = extr[f, n] @ kp
+                proj[n, f] = torch.matmul(intrinsics[f][n].unsqueeze(0), t.unsqueeze(0))[:, :3, :].reshape(12)
+    return kinv, proj
+
+
+def host_geometry_reference_form(keyframe_intrinsics, keyframe_pose, intrinsics, poses):
+    """host_geometry as the reference writes it - one torch.inverse per matrix, no cache.  Test oracle for host_geometry only."""
     b = keyframe_pose.shape[0]
     nf = len(poses)
     extr = [torch.inverse(p) for p in poses]
@@ -279,6 +310,7 @@ class MonoRecModel(nn.Module):
         self._streams = {}
         self._consts = {}
         self._packed_state = None
+        self._prep_pinned = {}           # (device, matrices, batch) -> (pinned host buffer, stream) of prepare()'s gather launch
         self._lock = threading.RLock()   # one enqueue at a time per model object (nn.DataParallel calls replicas from threads)
         self._warned_encoder = False
         self._geometry_override = None   # (kinv (B,9), proj (B,F,12)) CPU tensors replacing host_geometry's result; tests only
@@ -356,7 +388,7 @@ class MonoRecModel(nn.Module):
 
     def __getstate__(self):          # copy.deepcopy / pickle: device plans, streams, graphs and the lock are rebuilt on demand
         state = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
-        for k in ("_plans", "_graphs", "_streams", "_consts"):
+        for k in ("_plans", "_graphs", "_streams", "_consts", "_prep_pinned"):
             state[k] = {}
         state["_packed_state"] = None
         state["_open_group"] = None
@@ -409,7 +441,10 @@ class MonoRecModel(nn.Module):
         # plans) may land on the same slot, and the next enqueue on a slot overwrites the buffers these copies read - enqueued
         # under the lock, the copies sit on the caller's stream in front of the event the next forward's launches wait for
         with self._lock:
-            out = self.submit(data_dict).result()
+            # stream order makes consecutive forward() calls sequential whatever the number of slots, so they all use slot 0: one
+            # set of resident buffers and packed weights stays hot (alternating two slots measured 2.1 -> 2.8 ms per forward)
+            self._flush_open_group()
+            out = self._submit_one(data_dict, slot=0).result()
             with torch.cuda.device(out["keyframe"].device):
                 self._own_outputs(out)
         if self.pretrain_mode == 2:                           # :723-727, same aliasing as the reference
@@ -475,17 +510,15 @@ class MonoRecModel(nn.Module):
             else:
                 out[k][i] = c
 
-    def _submit_one(self, data_dict):
-        """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
-        wait for it.  Keyframes are independent, so a stream of keyframes is served with `hip_in_flight` (default 2)
-        of them on the GPU at once - on separate HIP streams and resident buffers - which fills the launch
-        head/tail bubbles that a single batch-1 keyframe leaves on 256 CUs:
+    def prepare(self, data_dict):
+        """Optional first half of `submit()`: everything a forward needs from its inputs but not from a free slot - the checks and the
+        host-side pose algebra (with the 4x4s on the device: one gather launch into pinned host memory, awaited here).  A pipelined
+        loop calls it BEFORE it waits for the result whose slot the next submit reuses:
 
-            pending.append(model.submit(batch));  out = pending.popleft().result() once len(pending) == hip_in_flight
+            token = model.prepare(batch);  out = pending.popleft().synchronize();  pending.append(model.submit(batch, token))
 
-        The inputs must stay unmodified until `.result()`.  Zero-copy: the outputs are VIEWS of the slot's resident buffers
-        and are overwritten by the submit that reuses the slot (`hip_in_flight` submits later) - consume or clone them
-        before that.  `forward()` returns owned tensors instead."""
+        so that ~0.1-0.2 ms of host work per keyframe overlap the device instead of preceding the first launch of the keyframe.
+        Returns a token for `submit(data_dict, token)`; the inputs must not change in between."""
         if self.training:
             raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
         keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
@@ -511,21 +544,76 @@ class MonoRecModel(nn.Module):
                           "importable / has no cached weights; the reference builds resnet18(pretrained=True), "
                           "monorec_model.py:104-113) nor `_feature_extractor.*` entries from a checkpoint or state dict: "
                           "it runs with its random initialisation")
-        data_dict.pop(_METRIC_CACHE_KEY, None)                # cached metric sums of an earlier forward on this dict are stale now
         cv_depths = data_dict.get("cv_depths")                # per-pixel depth hypotheses (monorec_model.py:181-182)
         if cv_depths is not None and self._hip_graph:
             raise NotImplementedError("cv_depths with hip_graph=True: the captured launch has no per-pixel depth pointer")
         b, c, h, w = keyframe.shape
         nf = len(frames)
         device = keyframe.device
+        mat_list = [kf_intrinsics, kf_pose] + intrinsics + poses
         with self._lock, torch.cuda.device(device):
-            return self._submit_locked(data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device)
+            caller = torch.cuda.current_stream(device)
+            # The HOST waits for the caller's stream to reach this point: the inputs exist now, and nothing below (here or in submit)
+            # is enqueued behind an unsatisfied stream dependency - a launch parked in its hardware queue as a blocked barrier packet
+            # slows the OTHER queues down (measured, round 3: sequential forwards 2.1 -> 3.2 ms with the next forward's encoder
+            # pre-enqueued behind such a wait; a request stream enqueued one forward ahead 5-7 % slower).
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(caller)
+            _host_wait(inputs_ready)
+            if all(not m.is_cuda for m in mat_list):
+                # matrices on the host (a loader that keeps the 4x4s on the CPU, kitti.KittiOdometryDataset): used where they are
+                hm = [m.detach().float() for m in mat_list]
+            else:
+                # matrices on the device: one gather launch into device-writable pinned host memory, awaited at once
+                dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
+                      m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
+                if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
+                    ev = torch.cuda.Event()
+                    ev.record(caller)
+                    _host_wait(ev)
+                pk = (str(device), len(dm), b)
+                pinned = self._prep_pinned.get(pk)
+                if pinned is None:
+                    pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), torch.cuda.Stream(device))
+                hm, gs = pinned
+                ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
+                _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")
+                done = torch.cuda.Event()
+                done.record(gs)
+                for m in dm:
+                    m.record_stream(gs)
+                _host_wait(done)
+            # host 4x4 algebra with the same ATen CPU operators as the reference: bit-identical matrices (~0.1 ms)
+            kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+            if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
+                kinv, proj = self._geometry_override
+        return _Prepared(data_dict, keyframe, frames, cv_depths, (b, h, w, nf), device, kinv.reshape(-1).clone(), proj.reshape(-1).clone())
+
+    def _submit_one(self, data_dict, prepared=None, slot=None):
+        """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
+        wait for it.  Keyframes are independent, so a stream of keyframes is served with `hip_in_flight` (default 2)
+        of them on the GPU at once - on separate HIP streams and resident buffers - which fills the launch
+        head/tail bubbles that a single batch-1 keyframe leaves on 256 CUs:
+
+            if len(pending) == hip_in_flight: out = pending.popleft().synchronize()
+            pending.append(model.submit(batch))
+
+        The inputs must stay unmodified until the result is taken.  Zero-copy: the outputs are VIEWS of the slot's resident buffers
+        and are overwritten by the submit that reuses the slot (`hip_in_flight` submits later) - consume or clone them
+        before that.  `forward()` returns owned tensors instead."""
+        if prepared is None:
+            prepared = self.prepare(data_dict)
+        elif prepared.data is not data_dict:
+            raise ValueError("submit(data_dict, prepared): the token was prepared for another dict")
+        data_dict.pop(_METRIC_CACHE_KEY, None)                # cached metric sums of an earlier forward on this dict are stale now
+        with self._lock, torch.cuda.device(prepared.device):
+            return self._submit_locked(data_dict, prepared, slot)
 
     # keys of a request that dynamic batching concatenates along the batch dimension (tensors, or lists of tensors)
     _BATCHED_INPUTS = ("keyframe", "keyframe_intrinsics", "keyframe_pose", "frames", "intrinsics", "poses",
                        "stereoframe", "stereoframe_intrinsics", "stereoframe_pose")
 
-    def submit(self, data_dict):
+    def submit(self, data_dict, prepared=None):
         """Enqueue one forward and return a handle (`.result()` -> the filled dict, outputs are views: see `_submit_one`).
 
         With `hip_batch_keyframes = K > 1`, K consecutive requests of equal shapes are coalesced into one launch of the path over
@@ -534,7 +622,7 @@ class MonoRecModel(nn.Module):
         extras (`cv_depths`, `mvobj_mask` with pretrain_mode 3, `simple_mask`'s previous prediction) are launched on their own."""
         if self._batch_keyframes <= 1 or self.simple_mask or self.pretrain_mode == 3 or data_dict.get("cv_depths") is not None:
             self._flush_open_group()
-            return self._submit_one(data_dict)
+            return self._submit_one(data_dict, prepared)
         with self._lock:
             data_dict.pop(_METRIC_CACHE_KEY, None)            # cached metric sums of an earlier forward on this dict are stale now
             # a request is checked when it is submitted, not when some later call happens to launch its group
@@ -607,7 +695,10 @@ class MonoRecModel(nn.Module):
                 m["result"] = m["predicted_inverse_depths"][0]
                 m["mask"] = m["cv_mask"]
 
-    def _submit_locked(self, data_dict, keyframe, kf_intrinsics, kf_pose, frames, poses, intrinsics, cv_depths, b, h, w, nf, device):
+    def _submit_locked(self, data_dict, prepared, slot=None):
+        keyframe, frames, cv_depths, device = prepared.keyframe, prepared.frames, prepared.cv_depths, prepared.device
+        b, h, w, nf = prepared.shape
+        geo = (prepared.kinv, prepared.proj)
         # the three constants of :675-677: built once per device (a `new_tensor` from a Python list is a blocking pageable H2D copy on
         # the caller's stream, three of them per keyframe); forward() hands out copies like every other output
         consts = self._consts.get(str(device))
@@ -619,64 +710,25 @@ class MonoRecModel(nn.Module):
             self._consts[str(device)] = consts
         data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = consts
 
-        slot = self._slot_counter[0]
-        self._slot_counter[0] = (slot + 1) % self._in_flight
+        if slot is None:
+            slot = self._slot_counter[0]
+            self._slot_counter[0] = (slot + 1) % self._in_flight
         key, plan = self._plan_for(slot, b, h, w, nf, device)
         streams = self._slot_streams(slot, device)
-        main, enc, geom = streams["main"], streams["enc"], streams["geom"]
+        main, enc = streams["main"], streams["enc"]
         caller = torch.cuda.current_stream(device)
-        mat_list = [kf_intrinsics, kf_pose] + intrinsics + poses
-        mats_on_host = all(not m.is_cuda for m in mat_list)
-
-        def geometry(hm):
-            # host 4x4 algebra with the same ATen CPU operators as the reference: bit-identical matrices (~0.1 ms)
-            kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
-            if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
-                kinv, proj = self._geometry_override
-            return kinv, proj
-
-        # Matrices that already live on the host (a loader that keeps the 4x4s on the CPU, kitti.DeviceLoader) need no device round
-        # trip - and their algebra does not need the slot: it is done BEFORE the host waits for the slot to come free, and the cost
-        # volume (head of the longest launch chain: cost volume -> mask encoder -> mask decoder -> depth) is launched first.
-        geo = geometry([m.detach().float() for m in mat_list]) if mats_on_host else None
         # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time
         while len(plan.enqueued) >= self._queue_depth:
             _host_wait(plan.enqueued.popleft())
         start_time = time.time()
-
-        # The host - not the device - waits for the caller's stream to reach this point and for the streams that took results of this
-        # slot (`.result()` under another current stream; the launches below overwrite what they read).  A launch enqueued behind an
-        # unsatisfied stream dependency sits in its hardware queue as a blocked barrier packet, and blocked packets slow the OTHER
-        # queues down (measured, round 3: sequential forwards 2.1 -> 3.2 ms with the next forward's encoder pre-enqueued behind such a
-        # wait; a stream of requests enqueued one forward ahead 5-7 % slower).  Everything below is therefore enqueued ready to run.
-        inputs_ready = torch.cuda.Event()
-        inputs_ready.record(caller)
-        _host_wait(inputs_ready)
-        for cs in plan.consumers:
-            if cs != caller:
-                ev = torch.cuda.Event()
-                ev.record(cs)
-                _host_wait(ev)
+        # The launches below overwrite the slot's previous outputs: the host waits for whatever the caller's stream - and any other
+        # stream that took results of this slot through `.result()` - has been given to do with them so far (host waits, not stream
+        # waits: no blocked packets, see prepare(); an idle stream costs a few microseconds).
+        for cs in [caller] + [c for c in plan.consumers if c != caller]:
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            _host_wait(ev)
         plan.consumers.clear()
-        # Matrices on the device: one gather launch into device-writable pinned host memory on the slot's geometry stream, awaited at
-        # once (~15 us: everything it reads is ready) - then the same order as with host matrices.  (Round 2 hid the round trip behind
-        # the encoder launches; the cost volume then started ~0.2 ms later, and it heads the longest chain.)
-        if not mats_on_host:
-            dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
-                  m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
-            if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
-                ev = torch.cuda.Event()
-                ev.record(caller)
-                _host_wait(ev)
-            ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
-            _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, plan.host_mats.data_ptr(), geom.cuda_stream),
-                       "mr_gather_small_f32")
-            mats_done = torch.cuda.Event()
-            mats_done.record(geom)
-            for m in dm:
-                m.record_stream(geom)
-            _host_wait(mats_done)
-            geo = geometry(plan.host_mats)
         with torch.cuda.stream(main):
             # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
             # captured launches keep their pointers - goes through the slot's resident buffers
@@ -701,8 +753,8 @@ class MonoRecModel(nn.Module):
                 # one H2D copy of 9 + 12 F floats per sample, then cost volume + mask encoder (concurrent with the ResNet stage)
                 if plan.geom_uploaded is not None:
                     _host_wait(plan.geom_uploaded)            # the slot's previous upload has left the pinned buffer (long ago)
-                plan.host_geom[: b * 9].copy_(kinv.reshape(-1))
-                plan.host_geom[b * 9:].copy_(proj.reshape(-1))
+                plan.host_geom[: b * 9] = kinv
+                plan.host_geom[b * 9:] = proj
                 plan.buf["geom"].copy_(plan.host_geom, non_blocking=True)
                 plan.geom_uploaded = torch.cuda.Event()
                 plan.geom_uploaded.record(main)
@@ -772,6 +824,14 @@ class MonoRecModel(nn.Module):
             entry = graph
         with torch.cuda.stream(stream):
             entry.replay()
+
+
+class _Prepared:
+    """Token of MonoRecModel.prepare(): the parsed inputs of one forward and its projection matrices."""
+
+    def __init__(self, data, keyframe, frames, cv_depths, shape, device, kinv, proj):
+        self.data, self.keyframe, self.frames, self.cv_depths = data, keyframe, frames, cv_depths
+        self.shape, self.device, self.kinv, self.proj = shape, device, kinv, proj
 
 
 class _Group:

@@ -262,7 +262,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert abs((plan.conv_ref_macs() + aux) / 1e9 - 61.07) < 0.01
     # executed: the four mask-decoder Upconv layers (3.934 GMAC in the reference) run phase-decomposed at 9/16 of their taps, and the
     # 3x3 layers the measured table sends to the Winograd kernel (csrc/conv_wino.hip) at 16/36 of their multiplies
-    wino = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 1]
+    wino = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3)]
     assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
                                          "mask.dec3.2", "depth.dec4.2"}
     assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
@@ -271,7 +271,11 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4]
     assert {c["name"] for c in wino_t} == {"depth.dec2.0", "depth.dec3"}
     assert all(c["macs"] * 16 == c["ref_macs"] * 9 and c["lds"] <= 160 * 1024 and c["sig"].startswith("t_") for c in wino_t)
-    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t)
+    # ... and twelve of the sixteen 3 x 1 / 1 x 3 stride-1 layers of the depth net on the 1-D F(2,3) kernel (csrc/conv1d_wino.hip) at 4/6
+    wino_1d = [c for c in plan.conv_log if c.get("winograd") and tuple(c["k"]) in ((1, 3), (3, 1))]
+    assert {c["name"] for c in wino_1d} == {f"depth.{s}.conv_{a}" for s in ("enc0.1", "enc1.1", "enc2.1", "dec1.1", "dec2.1", "dec4.0") for a in "yx"}
+    assert all(c["macs"] * 3 == c["ref_macs"] * 2 and c["lds"] <= 64 * 1024 and c["sig"][:2] in ("x_", "y_") for c in wino_1d)
+    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t + wino_1d)
     assert abs((plan.conv_macs() + aux + wino_saved) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
     direct = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)               # A/B aid: every 3x3 layer on the direct kernel
     assert not any(c.get("winograd") for c in direct.conv_log) and abs((direct.conv_macs() + aux) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
@@ -281,6 +285,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log if not c.get("winograd"))
+    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 12
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
@@ -533,7 +538,7 @@ class _FakePending:
 
 def _stub_submit_one(model, calls):
     """Replace the launch path by a CPU stand-in: outputs are simple functions of the (possibly concatenated) inputs."""
-    def submit_one(data):
+    def submit_one(data, prepared=None, slot=None):
         calls.append(int(data["keyframe"].shape[0]))
         kf = data["keyframe"]
         data["predicted_inverse_depths"] = [kf[:, :1] * 2.0, kf[:, :1, ::2, ::2], kf[:, :1, ::4, ::4], kf[:, :1, ::8, ::8]]
@@ -663,7 +668,8 @@ def test_winograd_choice_table_and_rule():
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 4, 11, 12, 14, 21} # + 10: input transform in registers, + 20: ... with 16-channel tail workgroups
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 11, 12, 14, 21}   # + 10: input transform in registers, + 20: ... with 16-channel tail workgroups
+    assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1) == 3 and engine.choose_winograd_1d(1, 256, [256], 16, 32, 1) == 0 and engine.choose_winograd_1d(0, 48, [48], 256, 510, 1) == 0
     assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
     assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
     assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) in (2, 12, 21)  # mask.enc0.*, mask.dec3.1 @ c2
@@ -673,3 +679,88 @@ def test_winograd_choice_table_and_rule():
     assert engine.choose_winograd(32, [32], 256, 768, 3) == 11         # unknown, 2304 workgroups, 32 couts: transform in registers
     assert engine.choose_winograd(96, [96], 256, 768, 3) == 2
     assert engine.choose_winograd(32, [32], 256, 510, 4) == 0          # width % 4
+
+
+def test_winograd_1d_weight_packing_and_algebra(hip_lib):
+    """mr_wino1d_pack_weights_f32: U = G g (double, rounded once) in the stream order conv1d_wino.hip reads - [cout group of 16 mbw]
+    [chunk of 8 channels, source-major][position][channel quad][cout block][64 lanes], lane = (cout l & 15, channel l >> 4) - and the
+    F(2,3) identity y = A^T [(G g) o (B^T d)] == correlation, evaluated from the packed stream in numpy along both axes."""
+    g = torch.Generator().manual_seed(11)
+    srcs_c, cout, mbw = [5, 11], 40, 2
+    cin = sum(srcs_c)
+    for axis, kk in ((0, (1, 3)), (1, (3, 1))):
+        w = torch.randn(cout, cin, *kk, generator=g)
+        sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+        n = hip_lib.mr_wino1d_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+        cpads = [(c + 7) // 8 * 8 for c in srcs_c]
+        groups = (cout + 16 * mbw - 1) // (16 * mbw)
+        assert n == groups * sum(cpads) // 8 * (4 * 2 * mbw * 64)
+        packed = torch.empty(n)
+        _lib.check(hip_lib.mr_wino1d_pack_weights_f32(w.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+        U = np.zeros((4, groups * mbw * 16, sum(cpads)), np.float64)          # [p][cout][padded cin]
+        st = packed.numpy().reshape(groups, sum(cpads) // 8, 4, 2, mbw, 64)
+        for gi in range(groups):
+            for q in range(sum(cpads) // 8):
+                for p_ in range(4):
+                    for c4 in range(2):
+                        for m in range(mbw):
+                            for lane in range(64):
+                                U[p_, (gi * mbw + m) * 16 + (lane & 15), q * 8 + c4 * 4 + (lane >> 4)] = st[gi, q, p_, c4, m, lane]
+        x = torch.randn(1, cin, 6, 8, generator=g)
+        ref = F.conv2d(x, w, padding=(kk[0] // 2, kk[1] // 2)).numpy()[0]
+        xp = np.zeros((sum(cpads), 6 + 2, 8 + 2))                             # padded channels (zero) + halo
+        off = 0
+        for s_, (c, cp) in enumerate(zip(srcs_c, cpads)):
+            xp[off:off + c, 1:-1, 1:-1] = x[0, sum(srcs_c[:s_]):sum(srcs_c[:s_]) + c].numpy()
+            off += cp
+        out = np.zeros((cout, 6, 8))
+        Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+        At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+        for y in range(0, 6, 2 if axis == 1 else 1):
+            for xx in range(0, 8, 2 if axis == 0 else 1):
+                d = xp[:, y + 1, xx:xx + 4] if axis == 0 else xp[:, y:y + 4, xx + 1]       # inputs j - 1 .. j + 2 along the axis
+                v = d @ Bt.T                                                                # (cin, 4)
+                mprod = np.einsum("pok,kp->po", U, v)                                       # (4, cout)
+                yy = At @ mprod                                                             # (2, cout)
+                if axis == 0:
+                    out[:, y, xx:xx + 2] = yy[:, :cout].T
+                else:
+                    out[:, y:y + 2, xx] = yy[:, :cout].T
+        assert np.abs(out - ref).max() <= 1e-5, axis
+
+
+def _check_host_geometry_against_the_reference_form():
+    from monorec_amd.model import host_geometry_reference_form
+    import monorec_amd.model as mm
+    for hard in (False, True):
+        for b, f, seed in ((1, 2, 3), (2, 4, 4), (8, 4, 5), (1, 1, 6)):
+            batch = synth.make_batch(b, 64, 96, f, seed=seed, hard_pose=hard)
+            a = (batch["keyframe_intrinsics"], batch["keyframe_pose"], batch["intrinsics"], batch["poses"])
+            mm._KINV_CACHE.clear()
+            k0, p0 = host_geometry_reference_form(*a)
+            for _ in range(2):                               # second call: the intrinsics inverse comes from the cache
+                k1, p1 = host_geometry(*a)
+                assert torch.equal(k1, k0) and torch.equal(p1, p0), (hard, b, f)
+    g = torch.Generator().manual_seed(0)
+    for trial in range(200):                                 # random rigid poses up to ~100 m from the origin, one batched inversion vs F calls
+        poses = []
+        for _ in range(3):
+            m = torch.eye(4)
+            m[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+            m[:3, 3] = torch.randn(3, generator=g) * (100.0 if trial % 2 else 1.0)
+            poses.append(m.unsqueeze(0))
+        k = torch.tensor([[[489.23, 0, 248.31, 0], [0, 489.23, 126.69, 0], [0, 0, 1, 0], [0, 0, 0, 1]]])
+        a = (k, poses[0], [k, k], poses[1:])
+        assert all(torch.equal(x, y) for x, y in zip(host_geometry(*a), host_geometry_reference_form(*a))), trial
+
+
+def test_host_geometry_shortcuts_are_bit_identical_to_the_reference_form():
+    """model.host_geometry batches the F pose inversions into one ATen call and remembers the intrinsics inverse by content; both
+    must reproduce the reference's one-call-per-matrix algebra (monorec_model.py:171,198,207) bit for bit on this host's CPU."""
+    _check_host_geometry_against_the_reference_form()
+
+
+@pytest.mark.gpu
+def test_host_geometry_shortcuts_on_the_gpu_box_host(hip_lib):
+    """The same statement on the GPU box's host CPU (another LAPACK / MKL code path than the build container's)."""
+    _check_host_geometry_against_the_reference_form()

@@ -832,3 +832,79 @@ def test_gather_small_into_pinned_host_memory(hip_lib):
     ev.synchronize()
     assert torch.equal(host, torch.stack(mats))
     assert hip_lib.mr_gather_small_f32(ptrs, 0, 32, host.data_ptr(), None) == -1 and hip_lib.mr_gather_small_f32(ptrs, 19, 32, host.data_ptr(), None) == -1
+
+
+# ---- 1-D Winograd F(2,3) kernel (csrc/conv1d_wino.hip) ---------------------------------------------------------------------------
+WINO_1D_CASES = [
+    # (srcs_c, cout, (H, W), batch, act, mbw)
+    ((48,), 48, (40, 96), 2, ACT_LEAKY_RELU, 3),                      # depth.enc0.1: 48 channels = 3 blocks, no padding
+    ((64,), 64, (24, 64), 1, ACT_LEAKY_RELU, 4),
+    ((32, 64), 32, (16, 32), 2, ACT_LEAKY_RELU, 2),                   # depth.dec4.0.conv_y: two concatenated sources
+    ((5, 11), 40, (13, 20), 3, ACT_NONE, 2),                          # ragged: C % 8, H % 8, W % 32, cout % 32
+    ((3,), 7, (9, 4), 1, ACT_RELU, 1),
+    ((128,), 128, (8, 36), 1, ACT_LEAKY_RELU, 4),                     # two cout groups of 64
+]
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("case", range(len(WINO_1D_CASES)))
+def test_winograd_1d_conv_matches_torch_fp32(hip_lib, case, axis):
+    """mr_conv1d3_winograd_f32 against F.conv2d with a 1 x 3 (axis 0) / 3 x 1 (axis 1) filter, zero padding 1 along the filter axis
+    (layers.ConvReLU2, model/layers.py:289-314), + bias + activation on the CPU."""
+    srcs_c, cout, (h, w), batch, act, mbw = WINO_1D_CASES[case]
+    lib = hip_lib
+    g = torch.Generator().manual_seed(300 + case)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    kk = (1, 3) if axis == 0 else (3, 1)
+    wt = torch.randn(cout, cin, *kk, generator=g) * (1.0 / math.sqrt(3.0 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = _act_ref(F.conv2d(torch.cat(srcs, 1), wt, bias, padding=(kk[0] // 2, kk[1] // 2)), act, 0.1, 0.0)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_wino1d_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+    packed = torch.empty(n)
+    _lib.check(lib.mr_wino1d_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s.to(DEV) for s in srcs]
+    for i, s in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, h, w), float("nan"), device=DEV)
+    pk, bs = packed.to(DEV), bias.to(DEV)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), None
+    d.activation, d.act_p0, d.cout_blocks_per_wave = act, 0.1, mbw
+    assert 0 < lib.mr_conv1d3_winograd_lds_bytes(ctypes.byref(d)) <= 64 * 1024
+    _lib.check(lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, _stream()), "mr_conv1d3_winograd_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+    if case == 0:
+        assert lib.mr_conv1d3_winograd_f32(ctypes.byref(d), 2, _stream()) == -1           # unknown axis
+        d.cout_blocks_per_wave = 5
+        assert lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, _stream()) == -1
+
+
+def test_plan_routes_3tap_layers_to_the_1d_winograd_kernel(hip_lib, monkeypatch):
+    """Plan.conv sends a 3 x 1 / 1 x 3 stride-1 'same' convolution to mr_conv1d3_winograd_f32 when the measured table names it (keys
+    `x_` / `y_`), and leaves everything else (other strides, unknown shapes) on the direct kernel."""
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(1, 24, 24, 32, generator=g)
+    for axis, kk in ((0, (1, 3)), (1, (3, 1))):
+        wt = torch.randn(48, 24, *kk, generator=g) * (1.0 / math.sqrt(72.0))
+        bias = torch.randn(48, generator=g) * 0.1
+        ref = F.leaky_relu(F.conv2d(x, wt, bias, padding=(kk[0] // 2, kk[1] // 2)), 0.1)
+        sig = ("x_", "y_")[axis] + engine.winograd_signature(48, [24], 24, 32, 1)
+        for code in (0, 3):
+            monkeypatch.setitem(engine.WINOGRAD, sig, code)
+            plan = engine.Plan.bare(DEV)
+            plan.winograd = True
+            out = torch.full((1, 48, 24, 32), float("nan"), device=DEV)
+            plan.conv("main", "t", [x.to(DEV)], wt, bias, out, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2), grid=(24, 32), act=ACT_LEAKY_RELU, p0=0.1)
+            plan.finalize()
+            assert bool(plan.conv_log[0].get("winograd")) == bool(code)
+            assert plan.conv_log[0]["ref_macs"] == 24 * 32 * 48 * 24 * 3
+            plan.run_stage("main", _stream())
+            torch.cuda.synchronize()
+            assert float((out.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (axis, code)

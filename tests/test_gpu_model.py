@@ -676,3 +676,39 @@ def test_forward_outputs_are_owned_and_made_by_one_copy_launch(hip_lib):
         for a, b in zip(out[k] if isinstance(v, list) else [out[k]], v if isinstance(v, list) else [v]):
             assert a.data_ptr() not in resident, k
             assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_mats", [False, True])
+def test_prepare_then_submit_pipeline(hip_lib, host_mats):
+    """The pipelined loop of bench.py / Evaluater: prepare(request i) - pose algebra, with device-side 4x4s one gather launch - while
+    the device is busy, host-side wait for the result whose slot request i reuses, submit(request i, token).  Every keyframe equals
+    the plain forward; a token is bound to its dict."""
+    import collections
+    plain, sd = _model(8, graph=False)
+    cpu = [synth.make_batch(1, 64, 96, 2, seed=400 + i) for i in range(7)]
+    batches = [_to_dev(b) for b in cpu]
+    with torch.no_grad():
+        want = [plain(dict(b))["result"].clone() for b in batches]
+    if host_mats:
+        for d, c in zip(batches, cpu):
+            for k in ("keyframe_intrinsics", "keyframe_pose", "intrinsics", "poses"):
+                d[k] = c[k]
+    m = MonoRecModel(cv_depth_steps=8, hip_in_flight=2)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    pending, got = collections.deque(), []
+    with torch.no_grad():
+        for b in batches:
+            req = dict(b)
+            token = m.prepare(req)
+            if len(pending) >= 2:
+                got.append(pending.popleft().synchronize()["result"].clone())
+            pending.append(m.submit(req, token))
+        while pending:
+            got.append(pending.popleft().synchronize()["result"].clone())
+        with pytest.raises(ValueError):
+            m.submit(dict(batches[0]), m.prepare(dict(batches[0])))
+    torch.cuda.synchronize()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), i

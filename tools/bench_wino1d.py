@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""The 1-D Winograd F(2,3) kernel (mr_conv1d3_winograd_f32) next to the direct MFMA kernel (mr_conv2d_f32 with its tuned schedule) on
+the 3 x 1 / 1 x 3 stride-1 layers of a plan: max |difference| and HIP-event times; --emit merges the fastest choice per layer shape
+(keys x_<sig> / y_<sig>: 0 direct, 1..4 = 16 x that many output channels per workgroup) into the measured table.
+
+    python tools/bench_wino1d.py [--batch 1 --frames 2 --depths 32 --height 256 --width 512] [--emit monorec_amd/tuned_winograd.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monorec_amd import _lib, engine, synth                        # noqa: E402
+from monorec_amd.model import MonoRecModel                         # noqa: E402
+from tools.bench_wino import timed                                  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--depths", type=int, default=32)
+    ap.add_argument("--emit", default=None)
+    a = ap.parse_args()
+    _lib.load()
+    m = MonoRecModel(cv_depth_steps=a.depths)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    ref_plan = engine.Plan(sd, a.batch, a.height, a.width, a.frames, a.depths, (0.33, 0.0025), "cpu", winograd=False)
+    g = torch.Generator().manual_seed(0)
+    table, tot_d, tot_b = {}, 0.0, 0.0
+    for c in ref_plan.conv_log:
+        sp = c["spec"]
+        if tuple(c["k"]) not in ((1, 3), (3, 1)) or tuple(sp["stride"]) != (1, 1) or c["phases"] != 1 or sp["in_mode"] != 0 or sp["tf"] != 0:
+            continue
+        axis = 0 if tuple(c["k"]) == (1, 3) else 1
+        srcs = [torch.randn(*s, generator=g).to(DEV) for s in sp["src_shapes"]]
+        cout, cin = sp["w_shape"][0], sp["w_shape"][1]
+        w = torch.randn(cout, cin, *c["k"], generator=g) * (1.0 / (3.0 * cin) ** 0.5)
+        bias = torch.randn(cout, generator=g) * 0.1
+        sc = [int(s.shape[1]) for s in srcs]
+        sig = ("x_", "y_")[axis] + engine.winograd_signature(cout, sc, sp["grid"][0], sp["grid"][1], sp["out_shape"][0])
+        row = {"name": c["name"], "sig": sig, "cin": cin, "cout": cout, "hw": list(sp["grid"]), "n": sp["out_shape"][0]}
+        outs = {}
+        for code in (0, 1, 2, 3, 4):
+            if code and 16 * code >= 2 * cout and code > 1:
+                continue
+            engine.WINOGRAD[sig] = code
+            plan = engine.Plan.bare(DEV)
+            plan.winograd = True
+            out = torch.full(sp["out_shape"], float("nan"), device=DEV)
+            plan.conv("main", c["name"], srcs, w, bias, out, stride=(1, 1), pad=sp["pad"], grid=sp["grid"], act=sp["act"], p0=sp["p0"])
+            plan.finalize()
+            assert bool(plan.conv_log[0].get("winograd")) == bool(code)
+            fn = plan.stages["main"][0][1]
+            fn(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs[code] = out
+            row["direct_us" if code == 0 else f"wino{code}_us"] = round(timed(fn), 1)
+            if code:
+                row[f"wino{code}_maxdiff"] = float((out - outs[0]).abs().max())
+        best, tb = 0, 0.97 * row["direct_us"]
+        for code in (1, 2, 3, 4):
+            if f"wino{code}_us" in row and row[f"wino{code}_us"] < tb:
+                best, tb = code, row[f"wino{code}_us"]
+        row["best"] = best
+        table[sig] = best
+        tot_d += row["direct_us"]
+        tot_b += min(row["direct_us"], tb if best else 1e9)
+        print(json.dumps(row), flush=True)
+    print(json.dumps({"direct_total_us": round(tot_d, 1), "best_of_both_total_us": round(tot_b, 1)}))
+    if a.emit:
+        old = json.load(open(a.emit)) if os.path.exists(a.emit) else {}
+        old.update(table)
+        with open(a.emit, "w") as f:
+            json.dump(old, f, indent=0, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--queue-depth", type=int, default=1,
                     help="MonoRecModel(hip_queue_depth=): forwards per in-flight slot the host may have enqueued (run-ahead bound)")
     ap.add_argument("--no-forward-api", action="store_true", help="skip the forward_api measurement")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="profiling aid: all stages of a keyframe on one stream (with --in-flight 1: a kernel trace of isolated kernel durations)")
     ap.add_argument("--stream-collect", action="store_true",
                     help="collect results with handle.result() (the caller's stream waits for the forward) right after the next submit, "
                          "as before round 3, instead of handle.synchronize() (the host waits) right before the submit that reuses the slot")
@@ -162,7 +164,7 @@ def committed_kernel_stats(cfg):
         forwards = 0
         for r in list(csv.reader(open(path)))[1:]:
             name, calls, total = r[0], int(r[1]), float(r[2])
-            if "conv_mfma_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name:
+            if "conv_mfma_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name or "conv1d3_wino" in name:
                 conv_us += total
                 conv_n += calls
             elif "splitk_epilogue_kernel" in name:
@@ -421,7 +423,7 @@ def main():
     from monorec_amd import MonoRecModel, synth
 
     model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16,
-                         hip_bf16x3=args.bf16x3, hip_queue_depth=args.queue_depth)
+                         hip_bf16x3=args.bf16x3, hip_queue_depth=args.queue_depth, hip_single_stream=args.single_stream)
     sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -550,12 +552,13 @@ def main():
                              "valu_frac_note": "SQ_INSTS_VALU x 64 lanes / sad-kernel time / 78.6e12 lane-instr/s", "counters_source": pmc_src})
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
-        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1)
+        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3))
+        n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and tuple(c["k"]) in ((1, 3), (3, 1)))
         n_wino_t = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 4)
         roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
                  f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches) + convt4x4_wino[_rb]_kernel "
-                 f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}); all fp32 v_mfma_f32_16x16x4_f32"),
+                 f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d}); all fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "frac_executed": conv_flops_executed / conv_s / 1e12 / peak,
                 "frac_note": "frac counts the reference's multiply-adds (SURVEY 8d) over the measured conv time; frac_executed counts what the "
@@ -566,7 +569,8 @@ def main():
                 "algorithmic_gflop_per_step": conv_flops / 1e9, "executed_gflop_per_step": conv_flops_executed / 1e9,
                 "algorithmic_note": "the reference's Conv2d / ConvTranspose2d MACs x 2 (SURVEY 8d); executed is lower where Upconv runs "
                                     "phase-decomposed on the low-resolution input (9 of 16 taps), where a 3x3 convolution runs as Winograd "
-                                    "F(2x2,3x3) (16 of 36 multiplies) and where a ConvTranspose2d(4,2) runs as F(2x2,2x2) (9 of 16)",
+                                    "F(2x2,3x3) (16 of 36 multiplies), where a ConvTranspose2d(4,2) runs as F(2x2,2x2) (9 of 16) and where a 3x1 / 1x3 convolution "
+                                    "runs as F(2,3) (4 of 6)",
                 "conv_ms_per_step": conv_s * 1e3}
         if kst:
             roof.update({"rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 11
+#define MR_ABI_VERSION 12
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -228,6 +228,18 @@ int mr_wino1d_pack_weights_f32(const float* weight, int32_t out_channels, const 
                                int32_t cout_blocks_per_wave, float* dst);
 int64_t mr_conv1d3_winograd_lds_bytes(const mr_wino_desc* desc);
 int mr_conv1d3_winograd_f32(const mr_wino_desc* desc, int32_t axis, void* stream);
+
+/*
+ * layers.Upconv (model/layers.py:349-356: nn.Upsample(2, nearest) -> pad (0,1,0,1) -> nn.Conv2d(2); the first layer of every MaskModule
+ * decoder stage, model/monorec/monorec_model.py:318-338) with 4 multiplies per (input channel, output channel) and 2x2 output block
+ * instead of 16 (9 as four parity phases of mr_conv2d_f32): the block of input position (y, x) is a bilinear form of the 2x2 input patch
+ * at (y, x), evaluated on differences of neighbouring inputs.  Same descriptor as the functions above: sources (batch, C_s, height, width)
+ * are the LOW-resolution input, dst = (batch, out_channels, 2 height, 2 width), bias / activation in the epilogue, no residual,
+ * cout_blocks_per_wave 1 or 2 (16 or 32 output channels per workgroup), width % 4 == 0.
+ */
+int mr_upconv_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                               int32_t cout_blocks_per_wave, float* dst);      /* size: mr_wino1d_packed_weight_floats */
+int mr_upconv2x2_winograd_f32(const mr_wino_desc* desc, void* stream);
 
 /*
  * nn.ConvTranspose2d(kernel 4, stride 2) + the centre crop of layers.Refine (model/layers.py:380-400: the decoder stages of the

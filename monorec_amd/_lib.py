@@ -68,7 +68,7 @@ class WinoDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 11            # include/monorec_hip.h
+MR_ABI_VERSION = 12            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -139,6 +139,8 @@ ABI = {
                                          ctypes.c_int32, ctypes.c_void_p]),
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "mr_exact_const_division": (ctypes.c_int, [ctypes.c_float]),
+    "mr_upconv_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "mr_upconv2x2_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_wino1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32]),
     "mr_wino1d_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv1d3_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),

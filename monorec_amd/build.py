@@ -74,17 +74,32 @@ def build(force=False, verbose=False):
 TIMELINE_LIB_PATH = os.path.join(HERE, "libmonorec_hip_timeline.so")
 
 
+# sources whose diagnostic switches are compiled in only for the diagnostic library: (source, define)
+DIAGNOSTIC = {"conv_mfma.hip": "-DMR_CONV_TIMELINE",     # per-workgroup timestamps / ablation bits (MR_CONV_DBG; ~3 % slower even when off)
+              "cost_volume.hip": "-DMR_TUNING_ENV",      # MR_CV_MARCH_TY / MR_CV_MARCH_DP / MR_CV_NO_KF_PREPASS (tools/bench_cv.py sweeps)
+              "heads.hip": "-DMR_TUNING_ENV"}            # MR_HEADS_QUAD_MIN (tools/bench_heads.py)
+
+
 def build_timeline(verbose=False):
-    """Diagnostic variant for tools/wg_timeline.py: conv_mfma.hip with -DMR_CONV_TIMELINE (per-workgroup timestamps;
-    ~3 % slower even when the stamps are off, hence not in the product library).  Select it with MR_HIP_LIBRARY."""
+    """Diagnostic variant of the library (tools/wg_timeline.py, the MR_* tuning sweeps): the sources in DIAGNOSTIC recompiled with
+    their switches; the product library reads no environment variable on any launch path.  Select it with MR_HIP_LIBRARY."""
     build(verbose=verbose)
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
-    o = os.path.join(objdir, "conv_mfma_timeline.o")
-    src = os.path.join(CSRC, "conv_mfma.hip")
-    if _stale(o, [src, os.path.join(CSRC, "conv_layout.h")]):
-        subprocess.run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-DMR_CONV_TIMELINE", "-c", src, "-o", o], check=True)
-    objs = [o] + [os.path.join(objdir, s.replace(".hip", ".o")) for s, _ in SOURCES if s != "conv_mfma.hip"]
+    flags = dict(SOURCES)
+    objs = []
+    for src, _ in SOURCES:
+        if src not in DIAGNOSTIC:
+            objs.append(os.path.join(objdir, src.replace(".hip", ".o")))
+            continue
+        o = os.path.join(objdir, src.replace(".hip", "_diag.o"))
+        s = os.path.join(CSRC, src)
+        if _stale(o, [s, os.path.join(CSRC, "conv_layout.h")]):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", DIAGNOSTIC[src], "-c", s, "-o", o] + flags[src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        objs.append(o)
     if _stale(TIMELINE_LIB_PATH, objs):
         subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", TIMELINE_LIB_PATH] + objs, check=True)
     return TIMELINE_LIB_PATH

@@ -188,6 +188,121 @@ __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
         }
 }
 
+// ---- layers.Upconv (nearest x2 -> pad (0,1,0,1) -> conv 2x2; model/layers.py:349-356) with 4 multiplies per 2x2 output block ----------
+// The four outputs of the block that input position (y, x) expands to read the 2x2 input patch a = in(y, x), b = in(y, x+1),
+// c = in(y+1, x), d = in(y+1, x+1) (zero beyond the bottom / right edge = the pad):
+//     o00 = a (w00+w01+w10+w11)      o01 = a (w00+w10) + b (w01+w11)      o10 = a (w00+w01) + c (w10+w11)      o11 = a w00 + b w01 + c w10 + d w11
+// - 9 multiplies as the plan's phase decomposition runs them (16 in the reference).  Writing b = a + (b - a) etc. leaves 4:
+//     V = [a, b - a; c - a, d - b - c + a],   U = [sum w, w01 + w11; w10 + w11, w11],   M = sum_cin U o V,
+//     o00 = M00,  o01 = M00 + M01,  o10 = M00 + M10,  o11 = (M00 + M01) + (M10 + M11)
+// (the 2-D tensor product of  out_even = a (g0 + g1), out_odd = out_even + (b - a) g1).  All transform coefficients are +-1.
+// Same skeleton as the F(2,3) kernel above: workgroup = 8 waves, 8 x 32 INPUT positions (16 x 64 output pixels), 16 * MBW output
+// channels; wave = input row, two blocks of 16 columns each; 4 positions -> acc[2][4][MBW].
+template <int MBW>
+__global__ __launch_bounds__(512) void upconv2x2_wino_kernel(const W1KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int U_FLOATS = NPOS * 2 * MBW * 64;
+    constexpr int BUF = WCK * RAW_PLANE + U_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    const int iy0 = ty_wg * 8, ix0 = tx_wg * 32;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / 10, g4 = r - row * 10;
+        const int gy = iy0 - 1 + row, gx = ix0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < RAW_ROWS * 10 ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)grp * a.wgroup_stride;
+
+    f32x4 acc[2][NPOS][MBW];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) acc[nb][p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF * 4;
+        const unsigned u_addr = buf_addr + WCK * RAW_PLANE * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS;
+        if (wave < U_FLOATS / 256) dma_global_x4(u_addr + wave * 1024, wsrc + wave * 256 + lane * 4);
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int t = lane & 15;
+    const int patch0 = (lane >> 4) * RAW_PLANE + (wave + 1) * RAW_PITCH + 4 + t;      // input (iy0 + wave, ix0 + t) of channel lane >> 4
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF;
+        const float* ub = raw + WCK * RAW_PLANE + lane;
+        dma_wait_all();
+        __syncthreads();
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][2][NPOS];                                  // [column block][channel quad][position]
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4) {
+                const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE + nb * 16;
+                const float pa = rp[0], pb_ = rp[1], pc = rp[RAW_PITCH], pd = rp[RAW_PITCH + 1];
+                v[nb][c4][0] = pa;
+                v[nb][c4][1] = pb_ - pa;
+                v[nb][c4][2] = pc - pa;
+                v[nb][c4][3] = (pd - pb_) - (pc - pa);
+            }
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    const float av = ub[((p * 2 + c4) * MBW + m) * 64];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) acc[nb][p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[nb][c4][p], acc[nb][p][m], 0, 0, 0);
+                }
+    }
+    const int iy = iy0 + wave;
+    if (iy >= H) return;
+    const int OW = 2 * W;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int ix = ix0 + nb * 16 + t;
+        if (ix >= W) continue;
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = (grp * MBW + m) * 16 + (lane >> 4) * 4 + r;
+                if (cout >= a.Cout) continue;
+                const float bs = a.bias ? a.bias[cout] : 0.f;
+                const float m00 = acc[nb][0][m][r], m01 = acc[nb][1][m][r], m10 = acc[nb][2][m][r], m11 = acc[nb][3][m][r];
+                const float o01 = m00 + m01;
+                float* o = a.dst + ((long long)(b * a.Cout + cout) * (2 * H) + 2 * iy) * OW + 2 * ix;
+                *(float2*)o = make_float2(act1(m00 + bs, a.act, a.p0), act1(o01 + bs, a.act, a.p0));
+                *(float2*)(o + OW) = make_float2(act1((m00 + m10) + bs, a.act, a.p0), act1((o01 + (m10 + m11)) + bs, a.act, a.p0));
+            }
+    }
+}
+
 bool valid_mbw1(int m) { return m >= 1 && m <= 4; }
 int pad8(int c) { return (c + 7) & ~7; }
 
@@ -315,4 +430,52 @@ extern "C" int mr_conv1d3_winograd_f32(const mr_wino_desc* desc, int32_t axis, v
     if (axis == 0) return launch1_mbw<0>(dv, (hipStream_t)stream);
     if (axis == 1) return launch1_mbw<1>(dv, (hipStream_t)stream);
     return MR_ERR_BAD_ARGUMENT;
+}
+
+// layers.Upconv: weight (out_channels, sum(src_channels), 2, 2) fp32.  U = [sum w, w01 + w11; w10 + w11, w11] in double, rounded once;
+// stream order as mr_wino1d_pack_weights_f32 (position p = 2 i + j).
+extern "C" int mr_upconv_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                          int32_t mbw, float* dst) {
+    if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || !valid_mbw1(mbw) || out_channels < 1)
+        return MR_ERR_BAD_ARGUMENT;
+    int cin_total = 0;
+    for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
+    const int groups = (out_channels + 16 * mbw - 1) / (16 * mbw);
+    size_t o = 0;
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = pad8(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += WCK)
+                for (int p = 0; p < NPOS; ++p)
+                    for (int c4 = 0; c4 < 2; ++c4)
+                        for (int mb = 0; mb < mbw; ++mb)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int cout = (g * mbw + mb) * 16 + (lane & 15);
+                                const int cl = c0 + c4 * 4 + (lane >> 4);
+                                double u = 0.0;
+                                if (cout < out_channels && cl < src_channels[s]) {
+                                    const float* gw = weight + ((size_t)cout * cin_total + (cin_off + cl)) * 4;     // w00 w01 w10 w11
+                                    const double w00 = gw[0], w01 = gw[1], w10 = gw[2], w11 = gw[3];
+                                    u = p == 0 ? ((w00 + w01) + (w10 + w11)) : p == 1 ? (w01 + w11) : p == 2 ? (w10 + w11) : w11;
+                                }
+                                dst[o++] = (float)u;
+                            }
+            cin_off += src_channels[s];
+        }
+    }
+    return 0;
+}
+
+// desc: sources (batch, C_s, height, width) = the LOW-resolution input, dst = (batch, out_channels, 2 height, 2 width); bias and
+// activation in the epilogue; packed_weights from mr_upconv_pack_weights_f32 (size: mr_wino1d_packed_weight_floats).
+extern "C" int mr_upconv2x2_winograd_f32(const mr_wino_desc* desc, void* stream) {
+    W1Derived dv;
+    const int rc = derive1(desc, &dv);
+    if (rc != 0) return rc;
+    if ((long long)desc->batch * desc->out_channels * desc->height * desc->width * 16 >= (1ll << 33)) return MR_ERR_UNSUPPORTED;
+    if (dv.mbw > 2) return MR_ERR_BAD_ARGUMENT;              // two column blocks per wave: accumulators of at most 32 channels
+    if (dv.mbw == 1) hipLaunchKernelGGL((upconv2x2_wino_kernel<1>), dv.grid, dim3(512), dv.lds_bytes, (hipStream_t)stream, dv.k);
+    else hipLaunchKernelGGL((upconv2x2_wino_kernel<2>), dv.grid, dim3(512), dv.lds_bytes, (hipStream_t)stream, dv.k);
+    return (int)hipGetLastError();
 }

@@ -1089,7 +1089,11 @@ MarchGeom march_geometry(const CvArgs& a, int dp) {
     g.strips = (a.W + 59) / 60;
     g.pitch = (a.W + g.strips - 1) / g.strips;
     g.npairs = a.D / dp;
-    static const int forced = [] { const char* e = getenv("MR_CV_MARCH_TY"); return e ? atoi(e) : 0; }();   // tuning aid
+#ifdef MR_TUNING_ENV         // tuning aids: diagnostic library only (python -m monorec_amd.build --timeline); the product reads no environment
+    static const int forced = [] { const char* e = getenv("MR_CV_MARCH_TY"); return e ? atoi(e) : 0; }();
+#else
+    const int forced = 0;
+#endif
     int best_ty = 64;
     if (forced >= 4) best_ty = forced;
     else {
@@ -1119,7 +1123,11 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         // One plane per wave instead of two when two would leave the 1024 SIMDs with fewer than 4 waves each (a wave issues one
         // VALU instruction per ~4.6 cycles on its own, a SIMD takes one per ~1.6 from 4 waves): c2 2016 -> 4032 waves, 143 -> 133 us;
         // no difference once the chip is full (c3).  MR_CV_MARCH_DP=1 / 2 forces either (tuning aid, read once).
+#ifdef MR_TUNING_ENV
         static const int dp_env = [] { const char* e = getenv("MR_CV_MARCH_DP"); return e ? atoi(e) : 0; }();
+#else
+        const int dp_env = 0;
+#endif
         bool dp1 = false;
         if (!a.pix_depths && a.D >= 6) {
             const MarchGeom g2 = march_geometry(a, 2);
@@ -1128,7 +1136,11 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         }
         const MarchGeom g = march_geometry(a, dp1 ? 1 : 2);
         const dim3 grid((unsigned)(g.strips * g.ysegs), (unsigned)(a.F * ((g.npairs + 3) / 4)), (unsigned)a.B);
+#ifdef MR_TUNING_ENV
         static const bool no_prepass = getenv("MR_CV_NO_KF_PREPASS") != nullptr;           // A/B aid
+#else
+        const bool no_prepass = false;
+#endif
         const bool fd = a.fast_w && a.fast_h;  // both constant divisions by the exact 3-instruction sequence (checked on the host)
         const bool kfs = dp1 || (a.D >= 6 && !no_prepass);
         if (kfs)                             // keyframe window statistics once, into planes 0..5 of the cost-volume buffer

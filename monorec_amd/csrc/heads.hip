@@ -239,7 +239,11 @@ extern "C" int mr_depth_heads_f32(const mr_head_desc* heads, int32_t num_heads, 
     if (!heads || num_heads < 1 || num_heads > MR_MAX_HEADS) return MR_ERR_BAD_ARGUMENT;
     // pixels from which a head runs in quad mode (MR_HEADS_QUAD_MIN: tuning aid, read once per process).  Measured at the c2 decoder
     // sizes (2 048 / 8 192 / 32 768 / 131 072 pixels): quad mode wins from 32 768 pixels up, pixel mode below (tools/bench_heads.py)
+#ifdef MR_TUNING_ENV         // tuning aid: diagnostic library only; the product reads no environment
     static const long long quad_min = [] { const char* e = getenv("MR_HEADS_QUAD_MIN"); return e ? atoll(e) : 16384ll; }();
+#else
+    const long long quad_min = 16384ll;    // measured (tools/bench_heads.py): quad mode from 16 384 pixels up
+#endif
     HeadsArgs a;
     a.n = num_heads;
     a.p0 = act_p0;

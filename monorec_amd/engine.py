@@ -655,10 +655,55 @@ class Plan:
         phases of ONE launch with 1, 2, 2 and 4 taps (upconv_phase_weights) - 2.25 instead of 4 multiply-adds per output, the
         input staged by the direct dwordx4 LDS-DMA path instead of the upsampling dword reads."""
         h, w = srcs[0].shape[2], srcs[0].shape[3]
-        phases = [(wp, 0, 0, py, px) for (py, px), wp in upconv_phase_weights(self.sd[wkey]).items()]
         cout, cin = self.sd[wkey].shape[:2]
+        if self.winograd and self.bf16 == 0 and name not in self.schedule_override and w % 4 == 0 and tuple(out.shape[2:]) == (2 * h, 2 * w):
+            mbw = WINOGRAD.get("u_" + winograd_signature(int(cout), [int(s_.shape[1]) for s_ in srcs], h, w, int(srcs[0].shape[0])), 0)
+            if mbw:        # measured table (tools/bench_wino1d.py --emit): the 4-multiply kernel, 16 * mbw output channels per workgroup
+                return self._upconv_winograd(stage, name, srcs, self.sd[wkey], self.sd[bkey] if bkey else None, out, mbw)
+        phases = [(wp, 0, 0, py, px) for (py, px), wp in upconv_phase_weights(self.sd[wkey]).items()]
         return self.conv(stage, name, srcs, None, self.sd[bkey] if bkey else None, out, stride=(1, 1), grid=(h, w), act=ACT_NONE,
                          out_step=(2, 2), phases=phases, ref_macs=srcs[0].shape[0] * 4 * h * w * cout * cin * 4)
+
+    def _upconv_winograd(self, stage, name, srcs, weight, bias, out, mbw):
+        """One mr_upconv2x2_winograd_f32 launch (csrc/conv1d_wino.hip: 4 multiplies per 2x2 output block instead of the 9 of the four
+        parity phases / the 16 of the reference) for a layers.Upconv."""
+        lib = self.lib
+        n, _, hs, ws = srcs[0].shape
+        src_channels = [int(s_.shape[1]) for s_ in srcs]
+        cout, cin = int(weight.shape[0]), int(weight.shape[1])
+        assert tuple(weight.shape[2:]) == (2, 2) and cin == sum(src_channels), (name, weight.shape)
+        sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
+        w = weight.detach().to(torch.float32).contiguous().cpu()
+        nfl = lib.mr_wino1d_packed_weight_floats(cout, sc, len(src_channels), mbw)
+        packed = torch.empty(nfl, dtype=torch.float32)
+        _lib.check(lib.mr_upconv_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_upconv_pack_weights_f32")
+        d = WinoDesc()
+        for i, s_ in enumerate(srcs):
+            assert s_.is_contiguous() and tuple(s_.shape[2:]) == (hs, ws) and s_.shape[0] == n
+            d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
+        d.num_src, d.batch, d.height, d.width = len(srcs), n, hs, ws
+        assert out.is_contiguous() and tuple(out.shape) == (n, cout, 2 * hs, 2 * ws)
+        d.dst, d.out_channels = out.data_ptr(), cout
+        d.packed_weights = self._dev(packed).data_ptr()
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        d.activation, d.act_p0, d.cout_blocks_per_wave = ACT_NONE, 0.0, mbw
+        lds = lib.mr_conv1d3_winograd_lds_bytes(ctypes.byref(d))
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name} upconv-winograd")
+        ref = n * 4 * hs * ws * cout * cin * 4
+        wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (16 * mbw))
+        self.conv_log.append(dict(name=name, macs=ref // 4, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+                                  cout=cout, cin=cin, k=(2, 2), out=(hs, ws), batch=n, phases=4, winograd=mbw, wino_variant=0, upconv=True, bf16=0,
+                                  sig="u_" + winograd_signature(cout, src_channels, hs, ws, n),
+                                  spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 2, 2), stride=(1, 1), pad=(0, 0),
+                                            grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=ACT_NONE, p0=0.0, p1=0.0, residual=False,
+                                            out_shape=tuple(out.shape), out_step=(2, 2), out_off=(0, 0), phases=None)))
+        self.keep += [d, out] + list(srcs)
+
+        def run(stream):
+            _lib.check(lib.mr_upconv2x2_winograd_f32(ctypes.byref(d), stream), name)
+        self.stages[stage].append((name, run))
+        return out
 
     def add(self, stage, name, fn):
         self.stages[stage].append((name, fn))

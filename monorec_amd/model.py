@@ -257,7 +257,7 @@ class MonoRecModel(nn.Module):
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1, hip_queue_depth=1):
+                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -299,6 +299,9 @@ class MonoRecModel(nn.Module):
         # Measured (round 3, 48-run grid tools/sessions/r03_s3.sh): 1 is best - a forward enqueued while its slot is still busy
         # (depth 2 and more) costs 5-7 % keyframes/s, whatever stream the requests come in on.
         self._queue_depth = max(1, int(hip_queue_depth))
+        # profiling aid: encoder and main stages on ONE stream, so that a kernel trace of `hip_in_flight=1` shows isolated kernel
+        # durations (with two streams the ResNet launches overlap the cost volume / mask encoder and inflate each other)
+        self._single_stream = bool(hip_single_stream)
         self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
@@ -403,6 +406,8 @@ class MonoRecModel(nn.Module):
         st = self._streams.get((slot, str(device)))
         if st is None:
             st = {n: torch.cuda.Stream(device) for n in ("main", "enc", "geom")}
+            if self._single_stream:
+                st["enc"] = st["main"]
             self._streams[(slot, str(device))] = st
         return st
 

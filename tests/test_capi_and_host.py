@@ -268,15 +268,20 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
     assert {c["name"] for c in wino if c.get("wino_variant") == 2} == {"mask.dec3.1", "mask.dec3.2"}     # 48 channels: 32 + a 16-channel tail
     # ... and the two large Refine layers (ConvTranspose2d(4, 2)) on the F(2x2,2x2) kernel (csrc/convt_wino.hip) at 9/16
-    wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4]
+    wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv")]
     assert {c["name"] for c in wino_t} == {"depth.dec2.0", "depth.dec3"}
     assert all(c["macs"] * 16 == c["ref_macs"] * 9 and c["lds"] <= 160 * 1024 and c["sig"].startswith("t_") for c in wino_t)
     # ... and twelve of the sixteen 3 x 1 / 1 x 3 stride-1 layers of the depth net on the 1-D F(2,3) kernel (csrc/conv1d_wino.hip) at 4/6
     wino_1d = [c for c in plan.conv_log if c.get("winograd") and tuple(c["k"]) in ((1, 3), (3, 1))]
     assert {c["name"] for c in wino_1d} == {f"depth.{s}.conv_{a}" for s in ("enc0.1", "enc1.1", "enc2.1", "dec1.1", "dec2.1", "dec4.0") for a in "yx"}
     assert all(c["macs"] * 3 == c["ref_macs"] * 2 and c["lds"] <= 64 * 1024 and c["sig"][:2] in ("x_", "y_") for c in wino_1d)
-    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t + wino_1d)
-    assert abs((plan.conv_macs() + aux + wino_saved) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
+    # ... and the two large layers.Upconv of the mask decoder on the 4-multiply kernel (csrc/conv1d_wino.hip) at 4/16; the other two stay
+    # phase-decomposed at 9/16
+    wino_u = [c for c in plan.conv_log if c.get("upconv")]
+    assert {c["name"] for c in wino_u} == {"mask.dec2.0", "mask.dec3.0"} and all(c["macs"] * 4 == c["ref_macs"] and c["sig"].startswith("u_") for c in wino_u)
+    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t + wino_1d + wino_u)
+    upconv_phased = sum(c["ref_macs"] for c in plan.conv_log if c["name"] in ("mask.dec0.0", "mask.dec1.0")) / 1e9       # 0.579 of the 3.934 GMAC
+    assert abs((plan.conv_macs() + aux + wino_saved) / 1e9 - (61.07 - upconv_phased * 7 / 16)) < 0.01
     direct = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)               # A/B aid: every 3x3 layer on the direct kernel
     assert not any(c.get("winograd") for c in direct.conv_log) and abs((direct.conv_macs() + aux) / 1e9 - (61.07 - 3.934 * 7 / 16)) < 0.01
     assert [n for n, _ in plan.stages["main"]][-1] == "depth.heads" and "apply_mask" not in [n for n, _ in plan.stages["main"]]
@@ -285,7 +290,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log if not c.get("winograd"))
-    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 12
+    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 12 + 2
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 

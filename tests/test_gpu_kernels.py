@@ -908,3 +908,58 @@ def test_plan_routes_3tap_layers_to_the_1d_winograd_kernel(hip_lib, monkeypatch)
             plan.run_stage("main", _stream())
             torch.cuda.synchronize()
             assert float((out.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (axis, code)
+
+
+@pytest.mark.parametrize("case", [((32,), 32, (16, 32), 1, 2), ((96, 128), 96, (8, 36), 2, 2), ((5, 11), 40, (13, 20), 3, 1), ((3,), 7, (5, 4), 1, 1),
+                                  ((64,), 64, (24, 64), 1, 2)])
+def test_upconv_4_multiply_kernel_matches_torch_fp32(hip_lib, case):
+    """mr_upconv2x2_winograd_f32 against layers.Upconv on the CPU (model/layers.py:349-356): nearest x2, pad (0, 1, 0, 1), conv 2x2, bias."""
+    srcs_c, cout, (h, w), batch, mbw = case
+    lib = hip_lib
+    g = torch.Generator().manual_seed(500 + cout + h)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    wt = torch.randn(cout, cin, 2, 2, generator=g) * (1.0 / math.sqrt(4.0 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(F.pad(F.interpolate(torch.cat(srcs, 1), scale_factor=2), [0, 1, 0, 1]), wt, bias)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_wino1d_packed_weight_floats(cout, sc, len(srcs_c), mbw)
+    packed = torch.empty(n)
+    _lib.check(lib.mr_upconv_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s.to(DEV) for s in srcs]
+    for i, s in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, 2 * h, 2 * w), float("nan"), device=DEV)
+    pk, bs = packed.to(DEV), bias.to(DEV)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), None
+    d.activation, d.act_p0, d.cout_blocks_per_wave = ACT_NONE, 0.0, mbw
+    _lib.check(lib.mr_upconv2x2_winograd_f32(ctypes.byref(d), _stream()), "mr_upconv2x2_winograd_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+    d.cout_blocks_per_wave = 3
+    assert lib.mr_upconv2x2_winograd_f32(ctypes.byref(d), _stream()) == -1
+
+
+def test_plan_upconv_on_the_4_multiply_kernel(hip_lib, monkeypatch):
+    """Plan.upconv routes a layers.Upconv to mr_upconv2x2_winograd_f32 when the measured table names it (keys `u_`)."""
+    g = torch.Generator().manual_seed(79)
+    x = torch.randn(1, 40, 16, 32, generator=g)
+    wt = torch.randn(48, 40, 2, 2, generator=g) * (1.0 / math.sqrt(160.0))
+    bias = torch.randn(48, generator=g) * 0.1
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2), [0, 1, 0, 1]), wt, bias)
+    for code in (0, 2):
+        monkeypatch.setitem(engine.WINOGRAD, "u_" + engine.winograd_signature(48, [40], 16, 32, 1), code)
+        plan = engine.Plan.bare(DEV, state={"x.weight": wt, "x.bias": bias})
+        plan.winograd = True
+        out = torch.full((1, 48, 32, 64), float("nan"), device=DEV)
+        plan.upconv("main", "t", [x.to(DEV)], "x.weight", "x.bias", out)
+        plan.finalize()
+        assert bool(plan.conv_log[0].get("winograd")) == bool(code) and plan.conv_log[0]["ref_macs"] == 4 * 16 * 32 * 48 * 40 * 4
+        plan.run_stage("main", _stream())
+        torch.cuda.synchronize()
+        assert float((out.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), code

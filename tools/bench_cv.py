@@ -3,7 +3,7 @@
 the round-1 LDS-tiled kernels (mr_cost_volume_tiled_f32), HIP events on the launch stream.
 
     python tools/bench_cv.py --batch 1 --height 256 --width 512 --frames 2 --depths 32 [--iters 200]
-    MR_CV_MARCH_TY=32 python tools/bench_cv.py ...      # force the row-segment length of the marching kernel (read once per process)
+    MR_HIP_LIBRARY=monorec_amd/libmonorec_hip_timeline.so MR_CV_MARCH_TY=32 python tools/bench_cv.py ...      # force the row-segment length of the marching kernel (read once per process)
 """
 import argparse
 import ctypes

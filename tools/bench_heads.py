@@ -3,7 +3,7 @@
 on its own and all four together.
 
     python tools/bench_heads.py [--batch 1] [--height 256] [--width 512] [--depths 32]
-    MR_HEADS_QUAD_MIN=1 python tools/bench_heads.py       # every head in quad mode;  MR_HEADS_QUAD_MIN=1000000000: all in pixel mode
+    MR_HIP_LIBRARY=monorec_amd/libmonorec_hip_timeline.so MR_HEADS_QUAD_MIN=1 python tools/bench_heads.py       # every head in quad mode;  MR_HEADS_QUAD_MIN=1000000000: all in pixel mode
 """
 import argparse
 import json

@@ -75,6 +75,46 @@ def main():
         tot_b += min(row["direct_us"], tb if best else 1e9)
         print(json.dumps(row), flush=True)
     print(json.dumps({"direct_total_us": round(tot_d, 1), "best_of_both_total_us": round(tot_b, 1)}))
+    # ---- layers.Upconv: the four parity phases on the direct kernel (9 multiplies per 2x2 block) vs the 4-multiply kernel -------------
+    tot_d = tot_b = 0.0
+    for c in ref_plan.conv_log:
+        sp = c["spec"]
+        if c["phases"] != 4 or not c["name"].startswith("mask.dec") or not c["name"].endswith(".0"):
+            continue
+        srcs = [torch.randn(*s_, generator=g).to(DEV) for s_ in sp["src_shapes"]]
+        cout, cin = sp["w_shape"][0], sp["w_shape"][1]
+        w = torch.randn(cout, cin, 2, 2, generator=g) * (1.0 / (4.0 * cin) ** 0.5)
+        bias = torch.randn(cout, generator=g) * 0.1
+        sc = [int(s_.shape[1]) for s_ in srcs]
+        hs, ws, n = srcs[0].shape[2], srcs[0].shape[3], srcs[0].shape[0]
+        sig = "u_" + engine.winograd_signature(cout, sc, hs, ws, n)
+        row = {"name": c["name"], "sig": sig, "cin": cin, "cout": cout, "hw": [hs, ws], "n": n}
+        outs = {}
+        for code in (0, 1, 2):
+            engine.WINOGRAD[sig] = code
+            plan = engine.Plan.bare(DEV, state={"x.weight": w, "x.bias": bias})
+            plan.winograd = True
+            out = torch.full((n, cout, 2 * hs, 2 * ws), float("nan"), device=DEV)
+            plan.upconv("main", c["name"], srcs, "x.weight", "x.bias", out)
+            plan.finalize()
+            assert bool(plan.conv_log[0].get("winograd")) == bool(code)
+            fn = plan.stages["main"][0][1]
+            fn(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs[code] = out
+            row["direct_us" if code == 0 else f"wino{code}_us"] = round(timed(fn), 1)
+            if code:
+                row[f"wino{code}_maxdiff"] = float((out - outs[0]).abs().max())
+        best, tb = 0, 0.97 * row["direct_us"]
+        for code in (1, 2):
+            if row[f"wino{code}_us"] < tb:
+                best, tb = code, row[f"wino{code}_us"]
+        row["best"] = best
+        table[sig] = best
+        tot_d += row["direct_us"]
+        tot_b += min(row["direct_us"], tb if best else 1e9)
+        print(json.dumps(row), flush=True)
+    print(json.dumps({"upconv_direct_total_us": round(tot_d, 1), "upconv_best_total_us": round(tot_b, 1)}))
     if a.emit:
         old = json.load(open(a.emit)) if os.path.exists(a.emit) else {}
         old.update(table)

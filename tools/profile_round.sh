@@ -15,7 +15,7 @@ timeout 600 python bench.py --steps 200 $SHAPE --dump-layers $OUT/layers.json > 
 tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --steps $STEPS --no-cpu-baseline --no-primer --no-forward-api $SHAPE > $OUT/trace.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_seq -o t -- python $REPO/bench.py --steps $STEPS --in-flight 1 --no-cpu-baseline --no-primer --no-forward-api $SHAPE > $OUT/trace_seq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_seq -o t -- python $REPO/bench.py --steps $STEPS --in-flight 1 --single-stream --no-cpu-baseline --no-primer --no-forward-api $SHAPE > $OUT/trace_seq.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES"; do

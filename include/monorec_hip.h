@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 12
+#define MR_ABI_VERSION 13
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -343,6 +343,22 @@ int mr_exact_const_division(float divisor);
  * torch.inverse / matmul, which this implementation runs with the reference's CPU operators) into device-writable pinned host memory. */
 #define MR_MAX_GATHER (2 + 2 * MR_MAX_FRAMES)
 int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_each, float* dst, void* stream);
+
+/* A run of consecutive convolution launches behind ONE host call: item i names an entry point above (MR_LAUNCH_*) and its descriptor
+ * (mr_conv_desc for MR_LAUNCH_CONV2D, mr_wino_desc otherwise; `arg` = the axis of mr_conv1d3_winograd_f32).  Launched in order on
+ * `stream`; stops at the first failure, returns its code and - if `failed_index` is given - its position.  (No reference equivalent:
+ * the reference issues one ATen call per layer from Python; this is the launch-overhead side of MonoRecModel.forward.) */
+#define MR_LAUNCH_CONV2D  0
+#define MR_LAUNCH_WINO3X3 1
+#define MR_LAUNCH_WINO_T  2
+#define MR_LAUNCH_WINO_1D 3
+#define MR_LAUNCH_UPCONV  4
+typedef struct mr_launch_item {
+    int32_t kind;
+    int32_t arg;
+    const void* desc;
+} mr_launch_item;
+int mr_run_launches(const mr_launch_item* items, int32_t num, void* stream, int32_t* failed_index);
 
 /* ResnetEncoder input normalisation ((x + 0.5) - 0.45) / 0.225, elementwise (monorec_model.py:691 + :120);
  * count % 4 == 0.  (MR_TF_RESNET_NORM does the same while staging inside mr_conv2d_f32.) */

@@ -68,12 +68,20 @@ class WinoDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 12            # include/monorec_hip.h
+MR_ABI_VERSION = 13            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
     """mirror of `mr_copy_segment` (include/monorec_hip.h)."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_int64)]
+
+
+class LaunchItem(ctypes.Structure):
+    """mirror of `mr_launch_item` (include/monorec_hip.h)."""
+    _fields_ = [("kind", ctypes.c_int32), ("arg", ctypes.c_int32), ("desc", ctypes.c_void_p)]
+
+
+LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV = 0, 1, 2, 3, 4
 
 
 class HeadDesc(ctypes.Structure):
@@ -139,6 +147,7 @@ ABI = {
                                          ctypes.c_int32, ctypes.c_void_p]),
     "mr_resnet_normalize_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "mr_exact_const_division": (ctypes.c_int, [ctypes.c_float]),
+    "mr_run_launches": (ctypes.c_int, [ctypes.POINTER(LaunchItem), ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "mr_upconv_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_upconv2x2_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_wino1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32]),

@@ -325,6 +325,29 @@ extern "C" int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_
     return (int)hipGetLastError();
 }
 
+// One host call for a run of consecutive convolution launches of a plan (engine.Plan.run_stage): the ~90 convolution-type launches of a
+// keyframe cost the Python host ~4.5 us each as separate ctypes calls, ~2 us as entries of a list walked here.  An item only names an
+// entry point of this ABI and its descriptor; descriptors are read at launch time (the plan re-binds input pointers between forwards).
+extern "C" int mr_run_launches(const mr_launch_item* items, int32_t num, void* stream, int32_t* failed_index) {
+    if (!items || num < 0) return MR_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < num; ++i) {
+        int rc;
+        switch (items[i].kind) {
+            case MR_LAUNCH_CONV2D: rc = mr_conv2d_f32((const mr_conv_desc*)items[i].desc, stream); break;
+            case MR_LAUNCH_WINO3X3: rc = mr_conv3x3_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
+            case MR_LAUNCH_WINO_T: rc = mr_convt4x4s2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
+            case MR_LAUNCH_WINO_1D: rc = mr_conv1d3_winograd_f32((const mr_wino_desc*)items[i].desc, items[i].arg, stream); break;
+            case MR_LAUNCH_UPCONV: rc = mr_upconv2x2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
+            default: rc = MR_ERR_BAD_ARGUMENT;
+        }
+        if (rc != 0) {
+            if (failed_index) *failed_index = i;
+            return rc;
+        }
+    }
+    return 0;
+}
+
 extern "C" int mr_abi_version(void) { return MR_ABI_VERSION; }
 
 extern "C" const char* mr_error_string(int code) {

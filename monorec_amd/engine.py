@@ -337,6 +337,7 @@ class Plan:
         self.input_ptr = {}       # "keyframe" -> device pointer the launches read the keyframe from (resident copy or the caller's tensor)
         self._input_srcs = []     # (ConvDesc, source index, "keyframe"): descriptor slots that follow input_ptr
         self._frame_ptrs = None   # ctypes array of the F source-frame pointers handed to the cost-volume launch
+        self._compiled = {}       # stage -> (launches compiled, [closure | (mr_launch_item array, count, names)]): see run_stage
         self._ws_floats = {}      # stage -> floats: stages may run concurrently on different streams,
         self._pending_ws = []     # so every stage gets its own split-K workspace
         if build:
@@ -374,6 +375,7 @@ class Plan:
 
         def run(stream):
             _lib.check(lib.mr_conv2d_f32(ctypes.byref(desc), stream), name)
+        run.native = (_lib.LAUNCH_CONV2D, desc, 0)          # run_stage walks runs of such launches in one host call (mr_run_launches)
         return run
 
     def conv(self, stage, name, srcs, weight, bias, out, *, stride=(1, 1), pad=(0, 0), grid=None,
@@ -518,6 +520,7 @@ class Plan:
 
         def run(stream):
             _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), name)
+        run.native = (_lib.LAUNCH_WINO3X3, d, 0)
         self.stages[stage].append((name, run))
         return out
 
@@ -561,6 +564,7 @@ class Plan:
 
         def run(stream):
             _lib.check(lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, stream), name)
+        run.native = (_lib.LAUNCH_WINO_1D, d, axis)
         self.stages[stage].append((name, run))
         return out
 
@@ -647,6 +651,7 @@ class Plan:
 
         def run(stream):
             _lib.check(lib.mr_convt4x4s2_winograd_f32(ctypes.byref(d), stream), name)
+        run.native = (_lib.LAUNCH_WINO_T, d, 0)
         self.stages[stage].append((name, run))
         return out
 
@@ -702,6 +707,7 @@ class Plan:
 
         def run(stream):
             _lib.check(lib.mr_upconv2x2_winograd_f32(ctypes.byref(d), stream), name)
+        run.native = (_lib.LAUNCH_UPCONV, d, 0)
         self.stages[stage].append((name, run))
         return out
 
@@ -991,9 +997,47 @@ class Plan:
         return ok
 
     # ------------------------------------------------------------------ execution
+    def _compile_stage(self, stage):
+        """The launch list of a stage as the host executes it: consecutive convolution-type launches (every closure that carries a
+        `.native` = (MR_LAUNCH_* kind, descriptor, arg)) are folded into ONE mr_run_launches call each - ~90 of the ~105 C-ABI calls of
+        a keyframe; everything else stays a Python closure.  The descriptors are referenced, not copied (input pointers are re-bound
+        between forwards)."""
+        out, run, names = [], [], []
+
+        def flush():
+            if not run:
+                return
+            items = (_lib.LaunchItem * len(run))()
+            for i, (kind, desc, arg) in enumerate(run):
+                items[i].kind, items[i].arg, items[i].desc = kind, arg, ctypes.addressof(desc)
+            out.append((items, len(run), tuple(names)))
+            self.keep.append(items)
+            run.clear()
+            names.clear()
+        for name, fn in self.stages[stage]:
+            nat = getattr(fn, "native", None)
+            if nat is None:
+                flush()
+                out.append(fn)
+            else:
+                run.append(nat)
+                names.append(name)
+        flush()
+        self._compiled[stage] = (len(self.stages[stage]), out)
+        return out
+
     def run_stage(self, stage, stream):
-        for _, fn in self.stages[stage]:
-            fn(stream)
+        comp = self._compiled.get(stage)
+        steps = comp[1] if comp is not None and comp[0] == len(self.stages[stage]) else self._compile_stage(stage)
+        for st in steps:
+            if isinstance(st, tuple):
+                items, n, names = st
+                failed = ctypes.c_int32(-1)
+                rc = self.lib.mr_run_launches(items, n, stream, ctypes.byref(failed))
+                if rc != 0:
+                    _lib.check(rc, names[failed.value] if 0 <= failed.value < n else "mr_run_launches")
+            else:
+                st(stream)
 
     def conv_macs(self):
         """Multiply-adds the launches execute."""

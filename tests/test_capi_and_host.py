@@ -295,6 +295,35 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
 
+def test_stage_launch_lists_fold_convolution_runs(hip_lib):
+    """Plan.run_stage walks consecutive convolution-type launches through ONE mr_run_launches call each: at c2 the ~105 C-ABI calls
+    of a keyframe become ~25 host calls; every launch is still there, in order, and the items point at the plan's own descriptors."""
+    m = MonoRecModel(cv_depth_steps=32)
+    plan = engine.Plan(synth.seeded_state_dict(m.state_dict()), 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    calls = launches = 0
+    for stage, ops in plan.stages.items():
+        steps = plan._compile_stage(stage)
+        names = []
+        for st in steps:
+            calls += 1
+            if isinstance(st, tuple):
+                items, n, nm = st
+                assert n == len(nm) >= 1 and all(items[i].desc for i in range(n)) and all(0 <= items[i].kind <= 4 for i in range(n))
+                names += list(nm)
+            else:
+                names.append(None)
+        launches += len(ops)
+        assert [n for n in names if n] == [n for n, fn in ops if getattr(fn, "native", None)] and len(names) == len(ops)
+    assert launches == 83 and calls <= 30, (launches, calls)
+    d = _lib.ConvDesc()
+    bad = (_lib.LaunchItem * 2)()
+    bad[0].kind, bad[0].desc = 9, ctypes.addressof(d)
+    failed = ctypes.c_int32(-1)
+    assert hip_lib.mr_run_launches(bad, 1, None, ctypes.byref(failed)) == -1 and failed.value == 0
+    bad[0].kind = _lib.LAUNCH_CONV2D                       # an empty descriptor: the entry point's own argument check answers
+    assert hip_lib.mr_run_launches(bad, 1, None, ctypes.byref(failed)) == -1 and hip_lib.mr_run_launches(bad, 0, None, None) == 0
+
+
 def test_bf16_weight_packing_layout(hip_lib):
     """mr_conv_pack_weights_bf16: lane (cout l&15, group g = l>>4), element j = channel 16*c16 + 4*j + g of the chunk, rounded
     to bf16 (nearest even), sources padded to 16 channels (csrc/conv_layout.h)."""

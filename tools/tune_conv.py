@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--bf16x3", action="store_true", help="tune the MR_COMPUTE_BF16X3 launches (hip_bf16x3=True plans)")
     ap.add_argument("--only", default=None, help="tune only the layers whose name contains one of these comma-separated strings")
     ap.add_argument("--missing", action="store_true", help="tune only the layer signatures the table has no entry for")
+    ap.add_argument("--prefer-nosplit", type=float, default=None,
+                    help="take the fastest schedule WITHOUT split_k (K split across the waves included) when it is within this many per cent of "
+                         "the overall fastest: one launch less per layer (no finishing kernel, no workspace round trip)")
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
@@ -164,11 +167,30 @@ def main():
             scored = sorted((sorted(ts)[1], sched) for sched, p, fn, ts in built)      # median of three rounds
             best = scored[0]
             del built
+        nosplit = None
+        if args.prefer_nosplit is not None and best[1][2] > 1:
+            # the leaders without split_k, re-timed next to the overall best in the same interleaved way
+            ns = [r for r in sorted((r for r in rows if r[1] and r[0][2] == 1), key=lambda r: r[1])[:3]]
+            if ns:
+                built = []
+                for sched in [best[1]] + [r[0] for r in ns]:
+                    p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w), c.get("bf16", False))
+                    built.append((sched, p, fn, []))
+                for _ in range(3):
+                    for sched, p, fn, ts in built:
+                        ts.append(time_op(fn, reps=max(args.final_reps, 20), warm=1))
+                t_best = sorted(built[0][3])[1]
+                t_ns, s_ns = min((sorted(ts)[1], sched) for sched, p, fn, ts in built[1:])
+                nosplit = (t_ns, s_ns, t_best)
+                if t_ns <= t_best * (1.0 + args.prefer_nosplit / 100.0):
+                    best = (t_ns, s_ns)
+                del built
         table[c["sig"]] = list(best[1])
         tf = 2 * c["macs"] / best[0] / 1e12
         report.append(dict(name=c["name"], sig=c["sig"], best=best[1], us=best[0] * 1e6, tflops=tf,
                            tried=[(list(s), (t * 1e6 if t else None), w) for s, t, w in sorted(rows, key=lambda r: r[1] or 1e9)[:8]]))
-        print(f"{c['name']:26s} best={best[1]} {best[0]*1e6:8.1f} us {tf:6.1f} TF  ({len(keep)} tried)", flush=True)
+        print(f"{c['name']:26s} best={best[1]} {best[0]*1e6:8.1f} us {tf:6.1f} TF  ({len(keep)} tried)"
+              + (f"  [no split_k: {nosplit[1]} {nosplit[0]*1e6:.1f} us vs {nosplit[2]*1e6:.1f} us]" if nosplit else ""), flush=True)
     with open(args.out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
     total = sum(r["us"] for r in report)

@@ -164,7 +164,7 @@ def committed_kernel_stats(cfg):
         forwards = 0
         for r in list(csv.reader(open(path)))[1:]:
             name, calls, total = r[0], int(r[1]), float(r[2])
-            if "conv_mfma_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name or "conv1d3_wino" in name or "upconv2x2_wino" in name:
+            if "conv_mfma_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name or "conv1d3_wino" in name or "conv1d_ct_kernel" in name or "upconv2x2_wino" in name:
                 conv_us += total
                 conv_n += calls
             elif "splitk_epilogue_kernel" in name:
@@ -553,13 +553,16 @@ def main():
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
         n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3))
-        n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and tuple(c["k"]) in ((1, 3), (3, 1)))
+        n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and c.get("wino_m", 2) == 2 and max(c["k"]) == 3)
+        ct_forms = sorted({f"F({c['wino_m']},{max(c['k'])})" for c in model._plans[plan_key].conv_log
+                           if c.get("winograd") and min(c["k"]) == 1 and (c.get("wino_m", 2), max(c["k"])) != (2, 3)})
+        n_ct = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and (c.get("wino_m", 2), max(c["k"])) != (2, 3))
         n_wino_u = sum(1 for c in model._plans[plan_key].conv_log if c.get("upconv"))
         n_wino_t = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv"))
         roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
                  f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches) + convt4x4_wino[_rb]_kernel "
-                 f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d}) + upconv2x2_wino_kernel (4-multiply Upconv, {n_wino_u}); all fp32 v_mfma_f32_16x16x4_f32"),
+                 f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d})" + (f" + conv1d_ct_kernel ({' / '.join(ct_forms)} for k x 1 / 1 x k, {n_ct})" if n_ct else "") + f" + upconv2x2_wino_kernel (4-multiply Upconv, {n_wino_u}); all fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "frac_executed": conv_flops_executed / conv_s / 1e12 / peak,
                 "frac_note": "frac counts the reference's multiply-adds (SURVEY 8d) over the measured conv time; frac_executed counts what the "

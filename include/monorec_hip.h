@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 13
+#define MR_ABI_VERSION 14
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -230,6 +230,24 @@ int64_t mr_conv1d3_winograd_lds_bytes(const mr_wino_desc* desc);
 int mr_conv1d3_winograd_f32(const mr_wino_desc* desc, int32_t axis, void* stream);
 
 /*
+ * The larger Cook-Toom forms of the same layers: F(m, r) = m outputs along the filter axis from m + r - 1 inputs with m + r - 1
+ * multiplies per (input channel, output channel).  (m, r) = (4, 3): 6 instead of 12 multiplies per 4 outputs of the 3-tap layers;
+ * (2, 7) / (4, 7): 8 / 10 instead of 14 / 28 for the 7 x 1 and 1 x 7 stride-1 layers of DepthModule.enc.0.0
+ * (model/monorec/monorec_model.py:487-500, layers.ConvReLU2 model/layers.py:289-314).  Interpolation points 0, +-1, +-2, +-1/2, +-4,
+ * infinity; transform coefficients are dyadic rationals, the transformed weights are formed in double and rounded once.  Effect on the
+ * path's outputs measured before the kernel was written (oracle/numerics_study_winograd.py: depth moves by <= 4e-7).  Descriptor and
+ * conventions as mr_conv1d3_winograd_f32 (zero padding (r - 1) / 2 either side, width % 4 == 0, no residual); weight (out, in, 1, r) for
+ * axis 0, (out, in, r, 1) for axis 1; cout_blocks_per_wave 1..4 (1..3 for (4, 7)).  A workgroup (8 waves) produces 8 rows x 16 m
+ * columns (axis 0) or 4 m rows x 32 columns (axis 1).  MR_ERR_BAD_ARGUMENT for any other (m, r).
+ */
+size_t mr_cooktoom1d_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave,
+                                          int32_t m, int32_t r);
+int mr_cooktoom1d_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                   int32_t cout_blocks_per_wave, int32_t m, int32_t r, float* dst);
+int64_t mr_conv1d_cooktoom_lds_bytes(const mr_wino_desc* desc, int32_t axis, int32_t m, int32_t r);
+int mr_conv1d_cooktoom_f32(const mr_wino_desc* desc, int32_t axis, int32_t m, int32_t r, void* stream);
+
+/*
  * layers.Upconv (model/layers.py:349-356: nn.Upsample(2, nearest) -> pad (0,1,0,1) -> nn.Conv2d(2); the first layer of every MaskModule
  * decoder stage, model/monorec/monorec_model.py:318-338) with 4 multiplies per (input channel, output channel) and 2x2 output block
  * instead of 16 (9 as four parity phases of mr_conv2d_f32): the block of input position (y, x) is a bilinear form of the 2x2 input patch
@@ -345,7 +363,8 @@ int mr_exact_const_division(float divisor);
 int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_each, float* dst, void* stream);
 
 /* A run of consecutive convolution launches behind ONE host call: item i names an entry point above (MR_LAUNCH_*) and its descriptor
- * (mr_conv_desc for MR_LAUNCH_CONV2D, mr_wino_desc otherwise; `arg` = the axis of mr_conv1d3_winograd_f32).  Launched in order on
+ * (mr_conv_desc for MR_LAUNCH_CONV2D, mr_wino_desc otherwise; `arg` = the axis of mr_conv1d3_winograd_f32, or
+ * axis | m << 4 | r << 8 for MR_LAUNCH_COOKTOOM_1D = mr_conv1d_cooktoom_f32).  Launched in order on
  * `stream`; stops at the first failure, returns its code and - if `failed_index` is given - its position.  (No reference equivalent:
  * the reference issues one ATen call per layer from Python; this is the launch-overhead side of MonoRecModel.forward.) */
 #define MR_LAUNCH_CONV2D  0
@@ -353,6 +372,7 @@ int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_ea
 #define MR_LAUNCH_WINO_T  2
 #define MR_LAUNCH_WINO_1D 3
 #define MR_LAUNCH_UPCONV  4
+#define MR_LAUNCH_COOKTOOM_1D 5
 typedef struct mr_launch_item {
     int32_t kind;
     int32_t arg;

@@ -46,11 +46,11 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and not _stale(
-            LIB_PATH, [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "conv_layout.h"), __file__,
+            LIB_PATH, [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "conv_layout.h"), os.path.join(CSRC, "cooktoom_1d.h"), __file__,
                                                                        os.path.join(HERE, "..", "include", "monorec_hip.h")]):
         return LIB_PATH                     # prebuilt library travels with the snapshot; nothing to do
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "conv_layout.h"), os.path.join(HERE, "..", "include", "monorec_hip.h"), __file__]
+    headers = [os.path.join(CSRC, "conv_layout.h"), os.path.join(CSRC, "cooktoom_1d.h"), os.path.join(HERE, "..", "include", "monorec_hip.h"), __file__]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []

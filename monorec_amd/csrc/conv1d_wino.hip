@@ -23,6 +23,7 @@
 #include <atomic>
 
 #include "../../include/monorec_hip.h"
+#include "cooktoom_1d.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -184,6 +185,180 @@ __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
             } else {
                 o[0] = y0;
                 if (oy + 1 < H) o[W] = y1;
+            }
+        }
+}
+
+// ---- the larger Cook-Toom forms F(4, 3), F(2, 7), F(4, 7) (round 3, numerics checked first: oracle/numerics_study_winograd.py) -----------------
+// Same skeleton as conv1d3_wino_kernel; what changes with (M outputs per tile, R taps), N = M + R - 1 positions:
+//   AXIS 0 (1 x R): wave = output row, lane & 15 = tile of M columns -> workgroup = 8 rows x 16 M columns, no vertical halo;
+//   AXIS 1 (R x 1): wave = (tile of M rows, half of the 32 columns) -> workgroup = 4 M rows x 32 columns, R - 1 halo rows;
+//   4 halo columns either side (16-byte groups; >= (R - 1) / 2), channel-plane pitch == 16 mod 32 banks; the transforms are the generated
+//   straight-line chains of cooktoom_1d.h (dyadic coefficients), N accumulator sets per output-channel block.
+template <int M, int R> struct CtForm;
+template <> struct CtForm<4, 3> {
+    static __device__ __forceinline__ void in(const float (&d)[6], float (&v)[6]) { ct_input_4_3(d, v); }
+    static __device__ __forceinline__ void out(const float (&mm)[6], float (&y)[4]) { ct_output_4_3(mm, y); }
+    static const double* g() { return &CT_G_4_3[0][0]; }
+};
+template <> struct CtForm<2, 7> {
+    static __device__ __forceinline__ void in(const float (&d)[8], float (&v)[8]) { ct_input_2_7(d, v); }
+    static __device__ __forceinline__ void out(const float (&mm)[8], float (&y)[2]) { ct_output_2_7(mm, y); }
+    static const double* g() { return &CT_G_2_7[0][0]; }
+};
+template <> struct CtForm<4, 7> {
+    static __device__ __forceinline__ void in(const float (&d)[10], float (&v)[10]) { ct_input_4_7(d, v); }
+    static __device__ __forceinline__ void out(const float (&mm)[10], float (&y)[4]) { ct_output_4_7(mm, y); }
+    static const double* g() { return &CT_G_4_7[0][0]; }
+};
+
+template <int AXIS, int M, int R>
+struct CtGeom {
+    static constexpr int N = M + R - 1;
+    static constexpr int PL = (R - 1) / 2;                       // 'same' padding of an odd filter at stride 1: (R - 1) / 2 either side
+    static constexpr int RH = AXIS == 0 ? 8 : 4 * M;             // output rows / columns per workgroup
+    static constexpr int RW = AXIS == 0 ? 16 * M : 32;
+    static constexpr int ROWS = RH + (AXIS == 1 ? R - 1 : 0);    // raw region: rows oy0 - PL (axis 1) or oy0 (axis 0) ..., columns ox0 - 4 ...
+    static constexpr int PITCH = RW + 8;
+    static constexpr int G4 = PITCH / 4;
+    static constexpr int NG = ROWS * G4;                         // 16-byte groups of one channel plane
+    static constexpr int NI = (NG + 63) / 64;                    // DMA instructions per plane (1 KiB each)
+    static constexpr int PLANE0 = ROWS * PITCH;
+    static constexpr int PLANE = PLANE0 + ((16 - PLANE0 % 32) + 32) % 32;      // == 16 mod 32: the four channels of a B read on distinct banks
+    static_assert(PL <= 4 && PITCH % 4 == 0 && PLANE % 4 == 0 && PLANE % 32 == 16, "raw region layout");
+};
+
+template <int AXIS, int MBW, int M, int R>
+__global__ __launch_bounds__(512) void conv1d_ct_kernel(const W1KArgs a) {
+    using Gm = CtGeom<AXIS, M, R>;
+    constexpr int N = Gm::N, PITCH = Gm::PITCH, PLANE = Gm::PLANE, PL = Gm::PL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int U_FLOATS = N * 2 * MBW * 64;               // U fragments of one chunk: [p][c4][cout block][64 lanes]
+    constexpr int U_PIECES = U_FLOATS / 256;                 // 1 KiB pieces (N even)
+    constexpr int BUF = WCK * PLANE + U_FLOATS;
+    static_assert(U_FLOATS % 256 == 0, "U pieces");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    const int oy0 = ty_wg * Gm::RH, ox0 = tx_wg * Gm::RW;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[Gm::NI];                                        // lane l owns the 16-byte groups r = l + 64 i of a plane: row r / G4, group r % G4
+#pragma unroll
+    for (int i = 0; i < Gm::NI; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / Gm::G4, g4 = r - row * Gm::G4;
+        const int gy = oy0 - (AXIS == 1 ? PL : 0) + row, gx = ox0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < Gm::NG ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)grp * a.wgroup_stride;
+
+    f32x4 acc[N][MBW];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF * 4;
+        const unsigned u_addr = buf_addr + WCK * PLANE * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS;
+#pragma unroll
+        for (int pc = 0; pc < (U_PIECES + 7) / 8; ++pc)
+            if (wave + 8 * pc < U_PIECES) dma_global_x4(u_addr + (wave + 8 * pc) * 1024, wsrc + (wave + 8 * pc) * 256 + lane * 4);
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];            // padded channels read as zero
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < Gm::NI; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int t = lane & 15;
+    // AXIS 0: the N inputs of tile t start at raw column 4 + M t - PL; they are read as aligned vectors from column M t on.
+    // AXIS 1: input i of the tile is raw row M (wave >> 1) + i at column 4 + 16 (wave & 1) + t.
+    const int patch0 = (lane >> 4) * PLANE + (AXIS == 0 ? wave * PITCH + M * t : (M * (wave >> 1)) * PITCH + 4 + (wave & 1) * 16 + t);
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF;
+        const float* ub = raw + WCK * PLANE + lane;
+        dma_wait_all();
+        __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        float v[2][N];                                        // B operands of this lane: (B^T d)[p] of channels 4 c4 + (lane >> 4)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * PLANE;
+            float d[N];
+            if constexpr (AXIS == 1) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[i] = rp[i * PITCH];
+            } else if constexpr (M == 4) {                     // columns 4 t .. 4 t + 11 as three 16-byte reads, inputs from 4 - PL on
+                float x[12];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 g = *(const f32x4*)(rp + 4 * j);
+                    x[4 * j] = g.x; x[4 * j + 1] = g.y; x[4 * j + 2] = g.z; x[4 * j + 3] = g.w;
+                }
+                static_assert(4 - PL + N <= 12, "three groups cover the patch");
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[i] = x[4 - PL + i];
+            } else {                                           // M == 2: columns 2 t .. as 8-byte reads
+                constexpr int NV = (4 - PL + N + 1) / 2;
+                float x[2 * NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const float2 g = *(const float2*)(rp + 2 * j);
+                    x[2 * j] = g.x; x[2 * j + 1] = g.y;
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[i] = x[4 - PL + i];
+            }
+            CtForm<M, R>::in(d, v[c4]);
+        }
+#pragma unroll
+        for (int p = 0; p < N; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    const float av = ub[((p * 2 + c4) * MBW + m) * 64];
+                    acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c4][p], acc[p][m], 0, 0, 0);
+                }
+    }
+    // ---- output transform y = A^T m per (cout, tile) in registers, epilogue ------------------------------------------------------
+    const int ox = ox0 + (AXIS == 0 ? M * t : (wave & 1) * 16 + t);
+    const int oy = oy0 + (AXIS == 0 ? wave : M * (wave >> 1));
+    if (ox >= W || oy >= H) return;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cout = (grp * MBW + m) * 16 + (lane >> 4) * 4 + r;
+            if (cout >= a.Cout) continue;
+            const float bs = a.bias ? a.bias[cout] : 0.f;
+            float mm[N], y[M];
+#pragma unroll
+            for (int p = 0; p < N; ++p) mm[p] = acc[p][m][r];
+            CtForm<M, R>::out(mm, y);
+#pragma unroll
+            for (int k = 0; k < M; ++k) y[k] = act1(y[k] + bs, a.act, a.p0);
+            float* o = a.dst + ((long long)(b * a.Cout + cout) * H + oy) * W + ox;
+            if constexpr (AXIS == 0) {                         // W % 4 == 0 and ox a multiple of M: all M columns exist
+                if constexpr (M == 4) *(f32x4*)o = (f32x4){y[0], y[1], y[2], y[3]};
+                else *(float2*)o = make_float2(y[0], y[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+                    if (oy + k < H) o[(long long)k * W] = y[k];
             }
         }
 }
@@ -370,6 +545,69 @@ int launch1_mbw(const W1Derived& dv, hipStream_t stream) {
     }
 }
 
+
+// ---- host side of the larger Cook-Toom forms ---------------------------------------------------------------------------------------
+bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 2 && r == 7) || (m == 4 && r == 7); }
+bool valid_ct_mbw(int m, int r, int mbw) { return mbw >= 1 && mbw <= (m + r - 1 >= 10 ? 3 : 4); }      // N x MBW accumulator sets in 256 VGPRs
+
+template <int AXIS, int M, int R>
+int derive_ct_form(const mr_wino_desc* d, W1Derived* out) {
+    using Gm = CtGeom<AXIS, M, R>;
+    const int rc = derive1(d, out);                           // argument checks, sources, chunk count (geometry of F(2,3) overwritten below)
+    if (rc != 0) return rc;
+    const int mbw = d->cout_blocks_per_wave;
+    const int ufl = Gm::N * 2 * mbw * 64;
+    out->k.tiles_x = (d->width + Gm::RW - 1) / Gm::RW;
+    out->k.wgroup_stride = (long long)out->k.nchunks * ufl;
+    out->grid = dim3((unsigned)(out->k.tiles_x * ((d->height + Gm::RH - 1) / Gm::RH)), out->grid.y, out->grid.z);
+    out->lds_bytes = (size_t)(2 * (WCK * Gm::PLANE + ufl)) * 4;
+    if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
+    return 0;
+}
+
+template <int AXIS, int MBW, int M, int R>
+int launch_ct(const W1Derived& dv, hipStream_t stream) {
+    static std::atomic<unsigned long long> attr_set{0};      // dynamic-LDS ceiling once per instantiation AND device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_ct_kernel<AXIS, MBW, M, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((conv1d_ct_kernel<AXIS, MBW, M, R>), dv.grid, dim3(512), dv.lds_bytes, stream, dv.k);
+    return (int)hipGetLastError();
+}
+
+template <int AXIS, int M, int R>
+int run_ct_form(const mr_wino_desc* d, hipStream_t stream, bool launch, int64_t* lds) {
+    if (!d || !valid_ct_mbw(M, R, d->cout_blocks_per_wave)) return MR_ERR_BAD_ARGUMENT;
+    W1Derived dv;
+    const int rc = derive_ct_form<AXIS, M, R>(d, &dv);
+    if (rc != 0) return rc;
+    if (lds) *lds = (int64_t)dv.lds_bytes;
+    if (!launch) return 0;
+    switch (dv.mbw) {
+        case 1: return launch_ct<AXIS, 1, M, R>(dv, stream);
+        case 2: return launch_ct<AXIS, 2, M, R>(dv, stream);
+        case 3: return launch_ct<AXIS, 3, M, R>(dv, stream);
+        default:
+            if constexpr (M + R - 1 < 10) return launch_ct<AXIS, 4, M, R>(dv, stream);
+            else return MR_ERR_BAD_ARGUMENT;
+    }
+}
+
+int run_ct(const mr_wino_desc* d, int axis, int m, int r, hipStream_t stream, bool launch, int64_t* lds) {
+    if (!valid_form(m, r) || (axis != 0 && axis != 1)) return MR_ERR_BAD_ARGUMENT;
+    if (m == 4 && r == 3) return axis == 0 ? run_ct_form<0, 4, 3>(d, stream, launch, lds) : run_ct_form<1, 4, 3>(d, stream, launch, lds);
+    if (m == 2 && r == 7) return axis == 0 ? run_ct_form<0, 2, 7>(d, stream, launch, lds) : run_ct_form<1, 2, 7>(d, stream, launch, lds);
+    return axis == 0 ? run_ct_form<0, 4, 7>(d, stream, launch, lds) : run_ct_form<1, 4, 7>(d, stream, launch, lds);
+}
+
+const double* form_g(int m, int r) { return m == 4 && r == 3 ? CtForm<4, 3>::g() : m == 2 ? CtForm<2, 7>::g() : CtForm<4, 7>::g(); }
+
 }  // namespace
 
 extern "C" size_t mr_wino1d_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t mbw) {
@@ -430,6 +668,63 @@ extern "C" int mr_conv1d3_winograd_f32(const mr_wino_desc* desc, int32_t axis, v
     if (axis == 0) return launch1_mbw<0>(dv, (hipStream_t)stream);
     if (axis == 1) return launch1_mbw<1>(dv, (hipStream_t)stream);
     return MR_ERR_BAD_ARGUMENT;
+}
+
+// ---- F(4, 3), F(2, 7), F(4, 7): size, packer, launch ------------------------------------------------------------------------------------
+extern "C" size_t mr_cooktoom1d_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t mbw,
+                                                     int32_t m, int32_t r) {
+    if (!src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || !valid_form(m, r) || !valid_ct_mbw(m, r, mbw) || out_channels < 1) return 0;
+    int nchunks = 0;
+    for (int s = 0; s < num_src; ++s) nchunks += pad8(src_channels[s]) / WCK;
+    const int groups = (out_channels + 16 * mbw - 1) / (16 * mbw);
+    return (size_t)groups * nchunks * ((m + r - 1) * 2 * mbw * 64);
+}
+
+// weight: (out_channels, sum(src_channels), r, 1) or (.., 1, r) fp32, nn.Conv2d layout - r taps per (cout, cin) either way.  U = G g in
+// double (G: cooktoom_1d.h), rounded once to fp32; stream order as mr_wino1d_pack_weights_f32 with m + r - 1 positions.
+extern "C" int mr_cooktoom1d_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src,
+                                              int32_t mbw, int32_t m, int32_t r, float* dst) {
+    if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || !valid_form(m, r) || !valid_ct_mbw(m, r, mbw) ||
+        out_channels < 1)
+        return MR_ERR_BAD_ARGUMENT;
+    const double* G = form_g(m, r);
+    const int npos = m + r - 1;
+    int cin_total = 0;
+    for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
+    const int groups = (out_channels + 16 * mbw - 1) / (16 * mbw);
+    size_t o = 0;
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = pad8(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += WCK)
+                for (int p = 0; p < npos; ++p)
+                    for (int c4 = 0; c4 < 2; ++c4)
+                        for (int mb = 0; mb < mbw; ++mb)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int cout = (g * mbw + mb) * 16 + (lane & 15);
+                                const int cl = c0 + c4 * 4 + (lane >> 4);
+                                double u = 0.0;
+                                if (cout < out_channels && cl < src_channels[s]) {
+                                    const float* gw = weight + ((size_t)cout * cin_total + (cin_off + cl)) * r;
+                                    for (int i = 0; i < r; ++i) u += G[p * r + i] * (double)gw[i];
+                                }
+                                dst[o++] = (float)u;
+                            }
+            cin_off += src_channels[s];
+        }
+    }
+    return 0;
+}
+
+extern "C" int64_t mr_conv1d_cooktoom_lds_bytes(const mr_wino_desc* desc, int32_t axis, int32_t m, int32_t r) {
+    int64_t lds = 0;
+    const int rc = run_ct(desc, axis, m, r, nullptr, false, &lds);
+    return rc != 0 ? rc : lds;
+}
+
+extern "C" int mr_conv1d_cooktoom_f32(const mr_wino_desc* desc, int32_t axis, int32_t m, int32_t r, void* stream) {
+    return run_ct(desc, axis, m, r, (hipStream_t)stream, true, nullptr);
 }
 
 // layers.Upconv: weight (out_channels, sum(src_channels), 2, 2) fp32.  U = [sum w, w01 + w11; w10 + w11, w11] in double, rounded once;

@@ -198,13 +198,16 @@ def choose_winograd_t(cout, src_channels, h, w, batch):
     return WINOGRAD.get("t_" + winograd_signature(cout, src_channels, h, w, batch), 0)
 
 
-def choose_winograd_1d(axis, cout, src_channels, h, w, batch):
-    """3-tap stride-1 'same' convolution along x (axis 0: 1 x 3) or y (axis 1: 3 x 1) - the second pair of every layers.ConvReLU2 stage
-    of the DepthModule: 0 = direct MFMA kernel, 1..4 = the 1-D Winograd F(2,3) kernel (csrc/conv1d_wino.hip) with 16 x that many
-    output channels per workgroup.  Only what the measured table says (tools/bench_wino1d.py --emit; keys prefixed `x_` / `y_`)."""
+def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3):
+    """k-tap stride-1 'same' convolution along x (axis 0: 1 x k) or y (axis 1: k x 1) - layers.ConvReLU2 of the DepthModule (3 taps: the
+    second pair of every stage; 7 taps: enc.0.0): 0 = direct MFMA kernel; 1..4 = the 1-D Winograd F(2,3) kernel (csrc/conv1d_wino.hip)
+    with 16 x that many output channels per workgroup; 10 m + mbw = the Cook-Toom form F(m, taps) of the same file (41..44: F(4,3);
+    21..24 / 41..43 on the 7-tap keys: F(2,7) / F(4,7)).  Only what the measured table says (tools/bench_wino1d.py --emit; keys prefixed
+    `x_` / `y_` for 3 taps, `x7_` / `y7_` for 7)."""
     if w % 4:
         return 0
-    return WINOGRAD.get(("x_", "y_")[axis] + winograd_signature(cout, src_channels, h, w, batch), 0)
+    prefix = ("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_"
+    return WINOGRAD.get(prefix + winograd_signature(cout, src_channels, h, w, batch), 0)
 
 
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
@@ -396,14 +399,14 @@ class Plan:
             mbw = choose_winograd(cout, src_channels, hs, ws, n)
             if mbw:
                 return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw % 10, mbw // 10)
-        if (self.winograd and phases is None and (kh, kw) in ((1, 3), (3, 1)) and tuple(stride) == (1, 1) and tuple(pad) == (kh // 2, kw // 2) and
+        if (self.winograd and phases is None and (kh, kw) in ((1, 3), (3, 1), (1, 7), (7, 1)) and tuple(stride) == (1, 1) and tuple(pad) == (kh // 2, kw // 2) and
                 in_mode == IN_DIRECT and tf == TF_NONE and tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0) and out_ch_offset == 0 and
                 out.shape[1] == cout and tuple(grid) == (hs, ws) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY_RELU) and self.bf16 == 0 and
                 residual is None and name not in self.schedule_override):
-            axis = 0 if kw == 3 else 1
-            mbw = choose_winograd_1d(axis, cout, src_channels, hs, ws, n)
-            if mbw:
-                return self._conv_winograd_1d(stage, name, srcs, weight, bias, out, act, p0, axis, mbw)
+            axis = 0 if kh == 1 else 1
+            code = choose_winograd_1d(axis, cout, src_channels, hs, ws, n, max(kh, kw))
+            if code:
+                return self._conv_winograd_1d(stage, name, srcs, weight, bias, out, act, p0, axis, code % 10, code // 10 if code >= 10 else 2)
         if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
             kh, kw = max(p[0].shape[2] for p in phases), max(p[0].shape[3] for p in phases)
         mixed = phases is not None and any(tuple(p[0].shape[2:]) != (kh, kw) for p in phases)
@@ -524,19 +527,29 @@ class Plan:
         self.stages[stage].append((name, run))
         return out
 
-    def _conv_winograd_1d(self, stage, name, srcs, weight, bias, out, act, p0, axis, mbw):
-        """One mr_conv1d3_winograd_f32 launch (csrc/conv1d_wino.hip: F(2,3), 4 instead of 6 multiplies per output pair) in place of a
-        3 x 1 / 1 x 3 stride-1 mr_conv2d_f32 launch."""
+    def _conv_winograd_1d(self, stage, name, srcs, weight, bias, out, act, p0, axis, mbw, m=2):
+        """One mr_conv1d3_winograd_f32 launch (csrc/conv1d_wino.hip: F(2,3), 4 instead of 6 multiplies per output pair) - or, for m = 4 or
+        7 taps, one mr_conv1d_cooktoom_f32 launch (F(m, taps): m + taps - 1 multiplies per m outputs) - in place of a k x 1 / 1 x k
+        stride-1 mr_conv2d_f32 launch."""
         lib = self.lib
         n, _, hs, ws = srcs[0].shape
         src_channels = [int(s_.shape[1]) for s_ in srcs]
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
-        assert tuple(weight.shape[2:]) == ((1, 3) if axis == 0 else (3, 1)) and cin == sum(src_channels), (name, weight.shape)
+        taps = int(weight.shape[3] if axis == 0 else weight.shape[2])
+        assert tuple(weight.shape[2:]) == ((1, taps) if axis == 0 else (taps, 1)) and cin == sum(src_channels), (name, weight.shape)
+        general = (m, taps) != (2, 3)
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = weight.detach().to(torch.float32).contiguous().cpu()
-        nfl = lib.mr_wino1d_packed_weight_floats(cout, sc, len(src_channels), mbw)
-        packed = torch.empty(nfl, dtype=torch.float32)
-        _lib.check(lib.mr_wino1d_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino1d_pack_weights_f32")
+        if general:
+            nfl = lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(src_channels), mbw, m, taps)
+            assert nfl > 0, (name, m, taps, mbw)
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_cooktoom1d_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, m, taps, packed.data_ptr()),
+                       "mr_cooktoom1d_pack_weights_f32")
+        else:
+            nfl = lib.mr_wino1d_packed_weight_floats(cout, sc, len(src_channels), mbw)
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino1d_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino1d_pack_weights_f32")
         d = WinoDesc()
         for i, s_ in enumerate(srcs):
             d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
@@ -548,23 +561,30 @@ class Plan:
         d.packed_weights = self._dev(packed).data_ptr()
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         d.activation, d.act_p0, d.cout_blocks_per_wave = act, p0, mbw
-        lds = lib.mr_conv1d3_winograd_lds_bytes(ctypes.byref(d))
+        lds = lib.mr_conv1d_cooktoom_lds_bytes(ctypes.byref(d), axis, m, taps) if general else lib.mr_conv1d3_winograd_lds_bytes(ctypes.byref(d))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} winograd-1d")
-        ref = n * hs * ws * cout * cin * 3
-        wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (16 * mbw))
-        kk = (1, 3) if axis == 0 else (3, 1)
-        self.conv_log.append(dict(name=name, macs=ref * 2 // 3, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
-                                  cout=cout, cin=cin, k=kk, out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=0, wino_axis=axis, bf16=0,
-                                  sig=("x_", "y_")[axis] + winograd_signature(cout, src_channels, hs, ws, n),
+        ref = n * hs * ws * cout * cin * taps
+        rh, rw = ((8, 16 * m) if axis == 0 else (4 * m, 32)) if general else (8, 32)
+        wgs = math.ceil(hs / rh) * math.ceil(ws / rw) * n * math.ceil(cout / (16 * mbw))
+        kk = (1, taps) if axis == 0 else (taps, 1)
+        self.conv_log.append(dict(name=name, macs=ref * (m + taps - 1) // (m * taps), ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs,
+                                  lds=int(lds), cout=cout, cin=cin, k=kk, out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=0, wino_axis=axis,
+                                  wino_m=m, bf16=0,
+                                  sig=("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_" + winograd_signature(cout, src_channels, hs, ws, n),
                                   spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin) + kk, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2),
                                             grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=act, p0=p0, p1=0.0, residual=False,
                                             out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
         self.keep += [d, out] + list(srcs)
 
-        def run(stream):
-            _lib.check(lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, stream), name)
-        run.native = (_lib.LAUNCH_WINO_1D, d, axis)
+        if general:
+            def run(stream):
+                _lib.check(lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, m, taps, stream), name)
+            run.native = (_lib.LAUNCH_COOKTOOM_1D, d, axis | (m << 4) | (taps << 8))
+        else:
+            def run(stream):
+                _lib.check(lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, stream), name)
+            run.native = (_lib.LAUNCH_WINO_1D, d, axis)
         self.stages[stage].append((name, run))
         return out
 

@@ -1,0 +1,231 @@
+"""TEST INFRASTRUCTURE (CPU only, never imported by the product): what larger Winograd / Cook-Toom tiles would do to the parity bar.
+
+The product runs the 3x3 stride-1 layers on F(2x2,3x3) and the 3x1 / 1x3 layers on F(2,3): transform
+coefficients 0, +-1, +-1/2, depth within 1.3e-6 of the CPU output.  The next step in multiplies would be F(4x4,3x3) (36 instead of 64
+multiplies per 4x4 outputs), F(4,3) along one axis (6 instead of 8 per 4 outputs) and F(2,7) / F(4,7) for the 7-tap layers of
+DepthModule.enc.0.0 (model/monorec/monorec_model.py:487-500, model/layers.py:289-314) - with interpolation points +-2, +-1/2 and
+constants up to 8 and 1/24.  Before any kernel is written this script answers, in emulated fp32 on the oracle's own activations:
+how far does `result` move when those layers are evaluated that way?  (bar: 1e-4 on the depth)
+
+    python -m oracle.numerics_study_winograd [--height 256 --width 512] [--json out.json]
+
+The emulation follows the kernels' structure: transformed weights formed in double and rounded once, input transform in fp32,
+channel sum in fp32 (torch matmul; the MFMA's exact k-ordered chain differs from it by summation order only), output transform in fp32.
+"""
+import argparse
+import json
+import sys
+from fractions import Fraction
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from monorec_amd import synth
+from oracle import monorec_oracle as oracle
+
+
+# ---------------------------------------------------------------------------------------------------------------- Cook-Toom matrices
+def cook_toom(m, r, points):
+    """F(m, r) for correlation y_k = sum_j g_j d_{k+j}: returns (AT m x n, G n x r, BT n x n) as Fractions, n = m + r - 1, the
+    last interpolation point at infinity.  BT is solved from the bilinear identity, so the triple is exact by construction."""
+    n = m + r - 1
+    assert len(points) == n - 1
+    pts = [Fraction(p) for p in points]
+    AT = [[(pts[i] ** k if i < n - 1 else (Fraction(1) if k == m - 1 else Fraction(0))) for i in range(n)] for k in range(m)]
+    G = []
+    for i in range(n - 1):
+        norm = Fraction(1)
+        for j in range(n - 1):
+            if j != i:
+                norm *= pts[i] - pts[j]
+        G.append([pts[i] ** j / norm for j in range(r)])
+    G.append([Fraction(0)] * (r - 1) + [Fraction(1)])
+    # sum_i AT[k][i] G[i][j] BT[i][l] = [l == k + j]  for all k < m, j < r, l < n: n unknowns per column l, m r equations
+    BT = [[Fraction(0)] * n for _ in range(n)]
+    rows = [[AT[k][i] * G[i][j] for i in range(n)] for k in range(m) for j in range(r)]
+    for l in range(n):
+        rhs = [Fraction(1) if l == k + j else Fraction(0) for k in range(m) for j in range(r)]
+        sol = _solve(rows, rhs, n)
+        for i in range(n):
+            BT[i][l] = sol[i]
+    return AT, G, BT
+
+
+def _solve(rows, rhs, n):
+    a = [list(r_) + [b] for r_, b in zip(rows, rhs)]
+    piv_cols, row = [], 0
+    for col in range(n):
+        p = next((i for i in range(row, len(a)) if a[i][col] != 0), None)
+        if p is None:
+            continue
+        a[row], a[p] = a[p], a[row]
+        inv = 1 / a[row][col]
+        a[row] = [v * inv for v in a[row]]
+        for i in range(len(a)):
+            if i != row and a[i][col] != 0:
+                f = a[i][col]
+                a[i] = [vi - f * vr for vi, vr in zip(a[i], a[row])]
+        piv_cols.append(col)
+        row += 1
+    assert len(piv_cols) == n, "under-determined"
+    assert all(all(v == 0 for v in r_) for r_ in a[row:]), "inconsistent"
+    return [a[i][n] for i in range(n)]
+
+
+def as_np(mat):
+    return np.array([[float(v) for v in r_] for r_ in mat], dtype=np.float64)
+
+
+# finite interpolation points by tile size n = m + r - 1 (the usual choice: small integers and their reciprocals)
+POINTS = {4: [0, 1, -1], 6: [0, 1, -1, 2, -2], 8: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2)],
+          10: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2), 4, -4]}
+_CACHE = {}
+
+
+def matrices(m, r):
+    if (m, r) not in _CACHE:
+        at, g, bt = cook_toom(m, r, POINTS[m + r - 1])
+        _CACHE[(m, r)] = (as_np(at), as_np(g), as_np(bt))
+    return _CACHE[(m, r)]
+
+
+# ---------------------------------------------------------------------------------------------------------------- emulated convolutions
+def winograd_1d(x, w, bias, axis, m):
+    """stride-1 'same' correlation with a (r x 1) [axis 2] or (1 x r) [axis 3] filter as F(m, r) in emulated fp32."""
+    r = w.shape[axis]
+    at, g, bt = matrices(m, r)
+    n = m + r - 1
+    if axis == 2:
+        return winograd_1d(x.transpose(2, 3), w.transpose(2, 3), bias, 3, m).transpose(2, 3)
+    pl, pr = oracle.same_pad(x.shape[3], r, 1)
+    width = x.shape[3]
+    tiles = -(-width // m)
+    xp = F.pad(x, [pl, tiles * m + r - 1 - width - pl, 0, 0])
+    d = xp.unfold(3, n, m)                                                    # N C H T n
+    u = torch.einsum("ij,ocj->oci", torch.from_numpy(g), w[:, :, 0, :].double()).float()          # O C n (rounded once)
+    v = torch.einsum("ij,nchtj->nchti", torch.from_numpy(bt).float(), d)     # fp32 input transform
+    mm = torch.einsum("oci,nchti->nohti", u, v)                                 # fp32 channel sum per position
+    y = torch.einsum("ki,nohti->nohtk", torch.from_numpy(at).float(), mm)     # fp32 output transform
+    y = y.reshape(y.shape[0], y.shape[1], y.shape[2], tiles * m)[..., :width]
+    return y + bias.view(1, -1, 1, 1) if bias is not None else y
+
+
+def winograd_2d(x, w, bias, m):
+    """3x3 stride-1 'same' convolution as F(m x m, 3 x 3) in emulated fp32."""
+    r = 3
+    at, g, bt = matrices(m, r)
+    n = m + r - 1
+    h, wd = x.shape[2], x.shape[3]
+    th, tw = -(-h // m), -(-wd // m)
+    xp = F.pad(x, [1, tw * m + 2 - wd - 1, 1, th * m + 2 - h - 1])
+    d = xp.unfold(2, n, m).unfold(3, n, m)                                      # N C TH TW n n
+    g64 = torch.from_numpy(g)
+    u = torch.einsum("ij,ocjk,lk->ocil", g64, w.double(), g64).float()          # O C n n
+    btf, atf = torch.from_numpy(bt).float(), torch.from_numpy(at).float()
+    v = torch.einsum("ij,ncabjk->ncabik", btf, d)
+    v = torch.einsum("ncabik,lk->ncabil", v, btf)
+    out = x.new_empty(x.shape[0], w.shape[0], th, tw, m, m)
+    for a0 in range(0, th, 8):                                                   # bounded temporaries
+        mm = torch.einsum("ocil,ncabil->noabil", u, v[:, :, a0:a0 + 8])
+        y = torch.einsum("pi,noabil->noabpl", atf, mm)
+        out[:, :, a0:a0 + 8] = torch.einsum("noabpl,ql->noabpq", y, atf)
+    y = out.permute(0, 1, 2, 4, 3, 5).reshape(x.shape[0], w.shape[0], th * m, tw * m)[:, :, :h, :wd]
+    return y + bias.view(1, -1, 1, 1) if bias is not None else y
+
+
+# ---------------------------------------------------------------------------------------------------------------- the experiment
+class Patched:
+    """oracle.conv_same replaced for the layers `rule(weight_shape, stride, input_shape)` selects (returns None or m)."""
+
+    def __init__(self, rule):
+        self.rule, self.hits, self.layer_err = rule, 0, []
+
+    def __enter__(self):
+        self.orig = oracle.conv_same
+        outer = self
+
+        def conv_same(x, w, b, stride=(1, 1)):
+            m = outer.rule(tuple(w.shape), tuple(stride), tuple(x.shape))
+            if m is None:
+                return outer.orig(x, w, b, stride)
+            kh, kw = w.shape[2], w.shape[3]
+            y = winograd_2d(x, w, b, m) if (kh, kw) == (3, 3) else winograd_1d(x, w, b, 2 if kw == 1 else 3, m)
+            ref = outer.orig(x.double(), w.double(), None if b is None else b.double(), stride)
+            direct = outer.orig(x, w, b, stride)
+            outer.hits += 1
+            outer.layer_err.append(dict(shape=list(w.shape), m=m, scale=float(ref.abs().max()),
+                                        winograd_vs_fp64=float((y.double() - ref).abs().max()),
+                                        direct_vs_fp64=float((direct.double() - ref).abs().max())))
+            return y
+        oracle.conv_same = conv_same
+        return self
+
+    def __exit__(self, *exc):
+        oracle.conv_same = self.orig
+
+
+def rules():
+    def only(kh, kw, m, min_pixels=0):
+        def rule(ws, stride, xs):
+            if (ws[2], ws[3]) == (kh, kw) and stride == (1, 1) and ws[0] > 1 and xs[2] * xs[3] >= min_pixels:   # (one-channel heads: csrc/heads.hip)
+                return m
+            return None
+        return rule
+
+    def both(*rs):
+        def rule(ws, stride, xs):
+            for r_ in rs:
+                m = r_(ws, stride, xs)
+                if m is not None:
+                    return m
+            return None
+        return rule
+    return {
+        "F(2x2,3x3) [what the product runs]": only(3, 3, 2),
+        "F(4x4,3x3) all 3x3 stride-1 layers": only(3, 3, 4),
+        "F(4x4,3x3) layers of >= 64x128 pixels only": only(3, 3, 4, 64 * 128),
+        "F(2,3) 3x1 + 1x3 [what the product runs]": both(only(3, 1, 2), only(1, 3, 2)),
+        "F(4,3) 3x1 + 1x3": both(only(3, 1, 4), only(1, 3, 4)),
+        "F(2,7) 7x1 + 1x7": both(only(7, 1, 2), only(1, 7, 2)),
+        "F(4,7) 7x1 + 1x7": both(only(7, 1, 4), only(1, 7, 4)),
+        "F(4x4,3x3) + F(4,3) + F(2,7) together": both(only(3, 3, 4), only(3, 1, 4), only(1, 3, 4), only(7, 1, 2), only(1, 7, 2)),
+    }
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--depths", type=int, default=32)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="substring of the experiment name")
+    args = ap.parse_args(argv)
+    torch.manual_seed(0)
+    batch = synth.make_batch(1, args.height, args.width, 2, seed=1)
+    from monorec_amd.model import MonoRecModel   # state-dict layout only (CPU construction, no launch)
+    sd = synth.seeded_state_dict(MonoRecModel(cv_depth_steps=args.depths).state_dict(), 0)
+    base = oracle.forward(sd, synth.clone_batch(batch), cv_depth_steps=args.depths)
+    report = {"shape": [args.height, args.width, args.depths], "bar": 1e-4, "experiments": {}}
+    for name, rule in rules().items():
+        if args.only and args.only not in name:
+            continue
+        with Patched(rule) as p:
+            out = oracle.forward(sd, synth.clone_batch(batch), cv_depth_steps=args.depths)
+        err = float((out["result"] - base["result"]).abs().max())
+        mask_err = float((out["cv_mask"] - base["cv_mask"]).abs().max())
+        worst = max(p.layer_err, key=lambda e: e["winograd_vs_fp64"] / max(e["scale"], 1e-30)) if p.layer_err else None
+        report["experiments"][name] = dict(layers=p.hits, result_max_abs_diff=err, cv_mask_max_abs_diff=mask_err, worst_layer=worst,
+                                           median_layer_err=float(np.median([e["winograd_vs_fp64"] for e in p.layer_err])) if p.layer_err else None,
+                                           median_direct_err=float(np.median([e["direct_vs_fp64"] for e in p.layer_err])) if p.layer_err else None)
+        print(f"{name:48s} layers {p.hits:2d}  result {err:.2e}  cv_mask {mask_err:.2e}  "
+              f"layer err (median) {report['experiments'][name]['median_layer_err']:.2e} vs direct {report['experiments'][name]['median_direct_err']:.2e}",
+              flush=True)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(report, f, indent=1)
+    return report
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() else 1)

@@ -763,6 +763,78 @@ def test_winograd_1d_weight_packing_and_algebra(hip_lib):
         assert np.abs(out - ref).max() <= 1e-5, axis
 
 
+def test_cooktoom_header_is_what_its_generator_writes_and_the_forms_are_exact(tmp_path):
+    """csrc/cooktoom_1d.h (transform chains + G tables of F(4,3), F(2,7), F(4,7)) == monorec_amd.cooktoom.generate_header(); the forms
+    satisfy the bilinear identity in exact rational arithmetic with dyadic A^T / B^T; and the GENERATED code itself, compiled for the host
+    (tests/c_abi/cooktoom_host.cpp), reproduces the r-tap correlation in fp32 to the rounding the numerics study expects."""
+    from fractions import Fraction
+    from monorec_amd import cooktoom
+    with open(os.path.join(ROOT, "monorec_amd", "csrc", "cooktoom_1d.h")) as f:
+        assert f.read().rstrip("\n") == cooktoom.generate_header().rstrip("\n"), "run python tools/gen_cooktoom.py"
+    for m, r in cooktoom.FORMS + ((2, 3),):
+        at, g, bt = cooktoom.cook_toom(m, r)
+        assert cooktoom.identity_holds(m, r, at, g, bt)
+        assert all(v.denominator & (v.denominator - 1) == 0 for row in at + bt for v in row)          # exact fp32 literals
+    at, g, bt = cooktoom.cook_toom(2, 3)                        # F(2,3) up to the scaling conv1d_wino.hip writes out (G rows x -1 / B^T rows x -1)
+    assert [[abs(v) for v in row] for row in g] == [[1, 0, 0], [Fraction(1, 2)] * 3, [Fraction(1, 2)] * 3, [0, 0, 1]]
+    exe = str(tmp_path / "cooktoom_host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "c_abi", "cooktoom_host.cpp")], check=True)
+    rows = [ln.split() for ln in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()]
+    assert [(int(a), int(b)) for a, b, _, _ in rows] == list(cooktoom.FORMS)
+    bars = {(4, 3): 5e-6, (2, 7): 1e-5, (4, 7): 2e-4}          # single products of O(1) values; sums over channels average it down
+    for a, b, err, scale in rows:
+        assert float(err) <= bars[(int(a), int(b))] and float(scale) > 1.0, (a, b, err)
+
+
+def test_cooktoom_weight_packing_and_plan_routing(hip_lib, monkeypatch):
+    """mr_cooktoom1d_pack_weights_f32: U = G g (double, rounded once) in the stream order of mr_wino1d_pack_weights_f32 with m + r - 1
+    positions; and the plan sends the 7-tap layers of DepthModule.enc.0.0 (monorec_model.py:487-500) to the form the table names, with the
+    executed multiply-adds (m + r - 1) / (m r) of the reference's and an LDS request the library accepts."""
+    from monorec_amd import cooktoom
+    g = torch.Generator().manual_seed(12)
+    srcs_c, cout, mbw = [5, 11], 40, 2
+    cin = sum(srcs_c)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    cpads = [(c + 7) // 8 * 8 for c in srcs_c]
+    groups = (cout + 16 * mbw - 1) // (16 * mbw)
+    for m, r in cooktoom.FORMS:
+        npos = m + r - 1
+        G = np.array([[float(v) for v in row] for row in cooktoom.cook_toom(m, r)[1]])
+        w = torch.randn(cout, cin, 1, r, generator=g)
+        n = hip_lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(srcs_c), mbw, m, r)
+        assert n == groups * sum(cpads) // 8 * (npos * 2 * mbw * 64)
+        packed = torch.empty(n)
+        _lib.check(hip_lib.mr_cooktoom1d_pack_weights_f32(w.data_ptr(), cout, sc, len(srcs_c), mbw, m, r, packed.data_ptr()))
+        st = packed.numpy().reshape(groups, sum(cpads) // 8, npos, 2, mbw, 64)
+        want = np.einsum("pj,ocj->poc", G, w[:, :, 0, :].double().numpy())          # [p][cout][cin]
+        off, cin_off = 0, 0
+        for c, cp in zip(srcs_c, cpads):
+            for cl in range(cp):
+                q, c4, hi = (off + cl) // 8, ((off + cl) % 8) // 4, (off + cl) % 4
+                for co in range(groups * mbw * 16):
+                    got = st[co // (16 * mbw), q, :, c4, (co // 16) % mbw, hi * 16 + co % 16]
+                    exp = want[:, co, cin_off + cl] if (co < cout and cl < c) else np.zeros(npos)
+                    assert np.allclose(got, exp, rtol=2e-7, atol=1e-9), (m, r, co, cl)      # one fp32 ulp: order of the double sum over the taps
+            off, cin_off = off + cp, cin_off + c
+    assert hip_lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(srcs_c), mbw, 2, 3) == 0                # F(2,3): the other entry point
+    assert hip_lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(srcs_c), 4, 4, 7) == 0                  # F(4,7): at most 3 blocks per wave
+    mdl = MonoRecModel(cv_depth_steps=32)
+    sd = synth.seeded_state_dict(mdl.state_dict())
+    base = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    seven = [c for c in base.conv_log if max(c["k"]) == 7 and tuple(c["spec"]["stride"]) == (1, 1)]
+    assert [c["name"] for c in seven] == ["depth.enc0.0.conv_y", "depth.enc0.0.conv_x"] and not any(c.get("winograd") for c in seven)
+    for c, code in zip(seven, (43, 22)):
+        axis = 0 if c["k"][0] == 1 else 1
+        monkeypatch.setitem(engine.WINOGRAD, ("x7_", "y7_")[axis] + engine.winograd_signature(c["cout"], [s_[1] for s_ in c["spec"]["src_shapes"]], 256, 512, 1), code)
+    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    routed = {c["name"]: c for c in plan.conv_log if max(c["k"]) == 7 and c.get("winograd")}
+    assert set(routed) == {"depth.enc0.0.conv_y", "depth.enc0.0.conv_x"}
+    cy, cx = routed["depth.enc0.0.conv_y"], routed["depth.enc0.0.conv_x"]
+    assert cy["wino_m"] == 4 and cy["macs"] * 28 == cy["ref_macs"] * 10 and cy["sig"].startswith("y7_") and 0 < cy["lds"] <= 160 * 1024
+    assert cx["wino_m"] == 2 and cx["macs"] * 14 == cx["ref_macs"] * 8 and cx["sig"].startswith("x7_") and 0 < cx["lds"] <= 160 * 1024
+    assert abs(plan.conv_ref_macs() - base.conv_ref_macs()) == 0
+
+
 def _check_host_geometry_against_the_reference_form():
     from monorec_amd.model import host_geometry_reference_form
     import monorec_amd.model as mm

@@ -910,6 +910,95 @@ def test_plan_routes_3tap_layers_to_the_1d_winograd_kernel(hip_lib, monkeypatch)
             assert float((out.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (axis, code)
 
 
+# ---- the larger Cook-Toom forms F(4,3) / F(2,7) / F(4,7) of the same file ---------------------------------------------------------------
+COOKTOOM_CASES = [
+    # (srcs_c, cout, (H, W), batch, act, mbw)
+    ((35,), 48, (24, 128), 1, ACT_LEAKY_RELU, 3),                     # depth.enc0.0.conv_y: D + 3 input channels, 48 = 3 blocks
+    ((48,), 48, (40, 96), 2, ACT_LEAKY_RELU, 3),
+    ((64,), 64, (24, 64), 1, ACT_LEAKY_RELU, 2),
+    ((32, 64), 32, (16, 32), 2, ACT_LEAKY_RELU, 2),                   # two concatenated sources
+    ((5, 11), 40, (13, 20), 3, ACT_NONE, 2),                          # ragged: C % 8, H % tile, W % tile, cout % 32
+    ((3,), 7, (9, 4), 1, ACT_RELU, 1),
+    ((128,), 128, (18, 68), 1, ACT_LEAKY_RELU, 1),                    # eight cout groups of 16, a ragged second tile column / row
+]
+COOKTOOM_TOL = {(4, 3): 1e-5, (2, 7): 1e-5, (4, 7): 1.5e-4}          # x max(1, |ref|); the fp32 emulation of the forms (oracle/numerics_study_winograd.py)
+                                                                      # measures 2e-6 / 2e-6 / 3e-5 on these cases
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("form", [(4, 3), (2, 7), (4, 7)])
+@pytest.mark.parametrize("case", range(len(COOKTOOM_CASES)))
+def test_cooktoom_1d_conv_matches_torch_fp32(hip_lib, case, form, axis):
+    """mr_conv1d_cooktoom_f32 against F.conv2d with a 1 x r (axis 0) / r x 1 (axis 1) filter, zero padding (r - 1) / 2 along the filter
+    axis (layers.ConvReLU2, model/layers.py:289-314), + bias + activation on the CPU."""
+    srcs_c, cout, (h, w), batch, act, mbw = COOKTOOM_CASES[case]
+    m, r = form
+    lib = hip_lib
+    g = torch.Generator().manual_seed(900 + case)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    kk = (1, r) if axis == 0 else (r, 1)
+    wt = torch.randn(cout, cin, *kk, generator=g) * (1.0 / math.sqrt(float(r) * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = _act_ref(F.conv2d(torch.cat(srcs, 1), wt, bias, padding=(kk[0] // 2, kk[1] // 2)), act, 0.1, 0.0)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(srcs_c), mbw, m, r)
+    assert n > 0
+    packed = torch.empty(n)
+    _lib.check(lib.mr_cooktoom1d_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, m, r, packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s.to(DEV) for s in srcs]
+    for i, s in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, h, w), float("nan"), device=DEV)
+    pk, bs = packed.to(DEV), bias.to(DEV)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), None
+    d.activation, d.act_p0, d.cout_blocks_per_wave = act, 0.1, mbw
+    assert 0 < lib.mr_conv1d_cooktoom_lds_bytes(ctypes.byref(d), axis, m, r) <= 160 * 1024
+    _lib.check(lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, m, r, _stream()), "mr_conv1d_cooktoom_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= COOKTOOM_TOL[form] * max(1.0, float(ref.abs().max())), err
+    if case == 0:
+        assert lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), 2, m, r, _stream()) == -1          # unknown axis
+        assert lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, 2, 3, _stream()) == -1        # F(2,3) lives in mr_conv1d3_winograd_f32
+        d.cout_blocks_per_wave = 5
+        assert lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, m, r, _stream()) == -1
+
+
+def test_plan_routes_layers_to_the_cooktoom_forms(hip_lib, monkeypatch):
+    """Plan.conv sends a k x 1 / 1 x k stride-1 'same' convolution to mr_conv1d_cooktoom_f32 when the measured table names a form
+    (codes 10 m + mbw; 7-tap layers under the keys `x7_` / `y7_`), through the native launch list as well."""
+    g = torch.Generator().manual_seed(79)
+    x = torch.randn(1, 24, 24, 64, generator=g)
+    for taps, codes in ((3, (0, 2, 42)), (7, (0, 22, 43))):
+        for axis in (0, 1):
+            kk = (1, taps) if axis == 0 else (taps, 1)
+            wt = torch.randn(48, 24, *kk, generator=g) * (1.0 / math.sqrt(24.0 * taps))
+            bias = torch.randn(48, generator=g) * 0.1
+            ref = F.leaky_relu(F.conv2d(x, wt, bias, padding=(kk[0] // 2, kk[1] // 2)), 0.1)
+            sig = ("x", "y")[axis] + ("" if taps == 3 else "7") + "_" + engine.winograd_signature(48, [24], 24, 64, 1)
+            for code in codes:
+                monkeypatch.setitem(engine.WINOGRAD, sig, code)
+                plan = engine.Plan.bare(DEV)
+                plan.winograd = True
+                out = torch.full((1, 48, 24, 64), float("nan"), device=DEV)
+                plan.conv("main", "t", [x.to(DEV)], wt, bias, out, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2), grid=(24, 64), act=ACT_LEAKY_RELU, p0=0.1)
+                plan.finalize()
+                log = plan.conv_log[0]
+                assert bool(log.get("winograd")) == bool(code) and log["ref_macs"] == 24 * 64 * 48 * 24 * taps
+                if code >= 10:
+                    m_ = code // 10
+                    assert log["wino_m"] == m_ and log["macs"] == log["ref_macs"] * (m_ + taps - 1) // (m_ * taps)
+                plan.run_stage("main", _stream())
+                torch.cuda.synchronize()
+                tol = 1.5e-4 if code == 43 else 2e-5
+                assert float((out.cpu() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max())), (taps, axis, code)
+
+
 @pytest.mark.parametrize("case", [((32,), 32, (16, 32), 1, 2), ((96, 128), 96, (8, 36), 2, 2), ((5, 11), 40, (13, 20), 3, 1), ((3,), 7, (5, 4), 1, 1),
                                   ((64,), 64, (24, 64), 1, 2)])
 def test_upconv_4_multiply_kernel_matches_torch_fp32(hip_lib, case):

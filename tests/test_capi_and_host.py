@@ -271,10 +271,16 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv")]
     assert {c["name"] for c in wino_t} == {"depth.dec2.0", "depth.dec3"}
     assert all(c["macs"] * 16 == c["ref_macs"] * 9 and c["lds"] <= 160 * 1024 and c["sig"].startswith("t_") for c in wino_t)
-    # ... and twelve of the sixteen 3 x 1 / 1 x 3 stride-1 layers of the depth net on the 1-D F(2,3) kernel (csrc/conv1d_wino.hip) at 4/6
-    wino_1d = [c for c in plan.conv_log if c.get("winograd") and tuple(c["k"]) in ((1, 3), (3, 1))]
-    assert {c["name"] for c in wino_1d} == {f"depth.{s}.conv_{a}" for s in ("enc0.1", "enc1.1", "enc2.1", "dec1.1", "dec2.1", "dec4.0") for a in "yx"}
-    assert all(c["macs"] * 3 == c["ref_macs"] * 2 and c["lds"] <= 64 * 1024 and c["sig"][:2] in ("x_", "y_") for c in wino_1d)
+    # ... and twelve of the sixteen 3 x 1 / 1 x 3 stride-1 layers of the depth net plus the two 7-tap layers of enc.0.0 on the 1-D kernels
+    # (csrc/conv1d_wino.hip): F(2,3) at 4/6, or the Cook-Toom form F(m, r) the table names at (m + r - 1) / (m r)
+    wino_1d = [c for c in plan.conv_log if c.get("winograd") and min(c["k"]) == 1]
+    assert {c["name"] for c in wino_1d} == ({f"depth.{s}.conv_{a}" for s in ("enc0.1", "enc1.1", "enc2.1", "dec1.1", "dec2.1", "dec4.0") for a in "yx"} |
+                                            {"depth.enc0.0.conv_y", "depth.enc0.0.conv_x"})
+    for c in wino_1d:
+        m_, r_ = c.get("wino_m", 2), max(c["k"])
+        assert (m_, r_) in ((2, 3), (4, 3), (2, 7), (4, 7)) and c["macs"] == c["ref_macs"] * (m_ + r_ - 1) // (m_ * r_) and c["lds"] <= 160 * 1024
+        assert c["sig"].startswith(("x", "y")[c["wino_axis"]] + ("_" if r_ == 3 else "7_"))
+    assert {max(c["k"]) for c in wino_1d if c.get("wino_m", 2) == 4} == {3, 7}          # both kinds of form are in the measured table
     # ... and the two large layers.Upconv of the mask decoder on the 4-multiply kernel (csrc/conv1d_wino.hip) at 4/16; the other two stay
     # phase-decomposed at 9/16
     wino_u = [c for c in plan.conv_log if c.get("upconv")]
@@ -290,7 +296,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log if not c.get("winograd"))
-    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 12 + 2
+    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 14 + 2
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
@@ -308,7 +314,7 @@ def test_stage_launch_lists_fold_convolution_runs(hip_lib):
             calls += 1
             if isinstance(st, tuple):
                 items, n, nm = st
-                assert n == len(nm) >= 1 and all(items[i].desc for i in range(n)) and all(0 <= items[i].kind <= 4 for i in range(n))
+                assert n == len(nm) >= 1 and all(items[i].desc for i in range(n)) and all(0 <= items[i].kind <= 5 for i in range(n))
                 names += list(nm)
             else:
                 names.append(None)
@@ -702,8 +708,12 @@ def test_winograd_choice_table_and_rule():
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 11, 12, 14, 21}   # + 10: input transform in registers, + 20: ... with 16-channel tail workgroups
-    assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1) == 3 and engine.choose_winograd_1d(1, 256, [256], 16, 32, 1) == 0 and engine.choose_winograd_1d(0, 48, [48], 256, 510, 1) == 0
+    # 3x3 / transposed keys: + 10 = input transform in registers, + 20 = ... with 16-channel tail workgroups; 1-D keys: 10 m + blocks = F(m, taps)
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 11, 12, 14, 21, 22, 23, 24, 41, 42, 43, 44}
+    assert all(v in (0, 21, 22, 23, 24, 41, 42, 43) for k, v in engine.WINOGRAD.items() if k[:3] in ("x7_", "y7_"))
+    assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1) in (3, 41, 42, 43) and engine.choose_winograd_1d(1, 256, [256], 16, 32, 1) == 0 and engine.choose_winograd_1d(0, 48, [48], 256, 510, 1) == 0
+    assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1, 7) == 43 and engine.choose_winograd_1d(1, 48, [32, 3], 256, 512, 1, 7) == 43      # depth.enc0.0 @ c2: F(4,7)
+    assert engine.choose_winograd_1d(0, 48, [48], 128, 256, 1, 7) == 0                                                                            # unknown 7-tap shape: direct
     assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
     assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
     assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) in (2, 12, 21)  # mask.enc0.*, mask.dec3.1 @ c2
@@ -820,6 +830,8 @@ def test_cooktoom_weight_packing_and_plan_routing(hip_lib, monkeypatch):
     assert hip_lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(srcs_c), 4, 4, 7) == 0                  # F(4,7): at most 3 blocks per wave
     mdl = MonoRecModel(cv_depth_steps=32)
     sd = synth.seeded_state_dict(mdl.state_dict())
+    for key in [k for k in engine.WINOGRAD if k[:3] in ("x7_", "y7_")]:
+        monkeypatch.delitem(engine.WINOGRAD, key)                  # a table without 7-tap entries: those layers stay on the direct kernel
     base = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
     seven = [c for c in base.conv_log if max(c["k"]) == 7 and tuple(c["spec"]["stride"]) == (1, 1)]
     assert [c["name"] for c in seven] == ["depth.enc0.0.conv_y", "depth.enc0.0.conv_x"] and not any(c.get("winograd") for c in seven)

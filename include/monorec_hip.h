@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 14
+#define MR_ABI_VERSION 15
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -215,6 +215,19 @@ int64_t mr_conv3x3_winograd_lds_bytes(const mr_wino_desc* desc);   /* dynamic LD
 int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
 
 /*
+ * The same 3x3 stride-1 convolution as Winograd F(4x4, 3x3): 36 multiplies per (input channel, output channel) and 4x4 outputs instead of
+ * 144 (F(2x2, 3x3): 64) - the F(4, 3) Cook-Toom form of cooktoom_1d.h in both directions (points 0, +-1, +-2, infinity; transform
+ * coefficients up to 8, transformed weights formed in double and rounded once).  Effect on the path's outputs measured before the kernel was
+ * written (oracle/numerics_study_winograd.py: depth moves by 2.4e-7 with every 3x3 stride-1 layer of the mask and depth nets evaluated this
+ * way).  Same descriptor and conventions as mr_conv3x3_winograd_f32 (`cout_blocks_per_wave` and `variant` ignored); a workgroup (8 waves)
+ * produces 16 x 64 output pixels x 32 output channels and uses 153 KB of LDS, so it pays where the layer has >= 256 such workgroups.
+ */
+size_t mr_wino44_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src);
+int mr_wino44_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
+int64_t mr_conv3x3_winograd44_lds_bytes(const mr_wino_desc* desc);
+int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream);
+
+/*
  * 3x1 / 1x3, stride 1, zero padding 1 along the filter axis (PadSameConv2d + nn.Conv2d of layers.ConvReLU2, model/layers.py:289-314: the
  * second pair of every DepthModule encoder stage, dec{1,2}.1, dec4.0 - model/monorec/monorec_model.py:485-513) as 1-D Winograd F(2, 3):
  * 4 multiplies per (input channel, output channel) and 2 outputs instead of 6.  Same descriptor and conventions as
@@ -373,6 +386,7 @@ int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_ea
 #define MR_LAUNCH_WINO_1D 3
 #define MR_LAUNCH_UPCONV  4
 #define MR_LAUNCH_COOKTOOM_1D 5
+#define MR_LAUNCH_WINO44  6
 typedef struct mr_launch_item {
     int32_t kind;
     int32_t arg;

@@ -68,7 +68,7 @@ class WinoDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 14            # include/monorec_hip.h
+MR_ABI_VERSION = 15            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -81,7 +81,7 @@ class LaunchItem(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("arg", ctypes.c_int32), ("desc", ctypes.c_void_p)]
 
 
-LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV, LAUNCH_COOKTOOM_1D = 0, 1, 2, 3, 4, 5
+LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV, LAUNCH_COOKTOOM_1D, LAUNCH_WINO44 = 0, 1, 2, 3, 4, 5, 6
 
 
 class HeadDesc(ctypes.Structure):
@@ -154,6 +154,10 @@ ABI = {
     "mr_wino1d_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv1d3_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
     "mr_conv1d3_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_int32, ctypes.c_void_p]),
+    "mr_wino44_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
+    "mr_wino44_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv3x3_winograd44_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_conv3x3_winograd44_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_cooktoom1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mr_cooktoom1d_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv1d_cooktoom_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),

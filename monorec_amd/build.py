@@ -27,6 +27,7 @@ SOURCES = [
     ("conv_wino.hip", []),
     ("convt_wino.hip", []),
     ("conv1d_wino.hip", []),
+    ("conv_wino44.hip", []),
 ]
 
 

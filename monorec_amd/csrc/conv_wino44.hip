@@ -1,0 +1,333 @@
+// 3x3 stride-1 convolutions as Winograd F(4x4, 3x3) on the fp32 matrix cores of gfx950 (MI355X).
+//
+// Next step after conv_wino.hip (F(2x2, 3x3), 16 multiplies per 2x2 outputs = 4 per output): a 4x4 output tile from a 6x6 input patch with 36
+// multiplies per (cin, cout) = 2.25 per output (direct: 9) - for the layers of the MaskModule (reference model/monorec/monorec_model.py:296-343,
+// layers.ConvReLU model/layers.py:317-335) that fill the chip with 16 x 64-pixel workgroups: the full-resolution stages at batch 1, everything at
+// batch 8.
+//     Y = A^T [ sum_cin (G g G^T) o (B^T d B) ] A         with the F(4, 3) matrices of cooktoom_1d.h (points 0, +-1, +-2, infinity)
+// The transforms have coefficients up to 8 (B^T: 4, 5; A^T: 8) and G has sixths / 24ths, so the effect on the path's outputs was measured BEFORE
+// this kernel was written (oracle/numerics_study_winograd.py: every 3x3 stride-1 layer of the mask and depth nets in emulated fp32 F(4x4, 3x3)
+// arithmetic moves `result` by 2.4e-7, per layer 5e-6 from fp64; bar 1e-4).
+//
+// Skeleton = the in-register-transform kernels (conv3x3_wino_rb_kernel, conv1d_ct_kernel): workgroup = 8 waves = 4 tile rows x 2 blocks of 16
+// output channels: 16 x 64 output pixels x 32 channels; K in chunks of 8 input channels; the haloed region (18 rows x 72 columns per channel, plane
+// pitch 1296 = 16 mod 32 banks, hardware zero fill = padding) and the chunk's U fragments (36 positions; host-packed G g G^T, formed in double and
+// rounded once) arrive by LDS-DMA in one of two pipeline buffers (2 x 76.5 KB: one workgroup per CU - the 36 accumulator sets need 144 of a wave's
+// 256 registers, so two waves per SIMD is what fits anyway); ONE barrier per chunk.  A lane reads the 6x6 patch of its (tile, channel) as 18
+// 16-byte LDS reads, transforms rows then columns with the generated F(4,3) chain (one channel quad at a time: 36 live B operands) and issues
+// 36 MFMAs per quad; it ends up with all 36 positions of its (output channel, tile), so A^T M A, bias, residual, activation run in registers and
+// the 4x4 tile leaves as four 16-byte stores.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <atomic>
+
+#include "../../include/monorec_hip.h"
+#include "cooktoom_1d.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WCK = 8;                                   // input channels per chunk (one per wave in the DMA phase)
+constexpr int NP = 36;                                   // positions p = 6 i + j (i: vertical, j: horizontal transform index)
+constexpr int RH = 16, RW = 64;                          // output pixels per workgroup
+constexpr int ROWS = RH + 2, PITCH = RW + 8;             // raw region: rows oy0 - 1 .. oy0 + 16, columns ox0 - 4 .. ox0 + 67
+constexpr int G4 = PITCH / 4, NG = ROWS * G4;            // 16-byte groups per channel plane (324)
+constexpr int NI = (NG + 63) / 64;                       // DMA instructions per plane (6)
+constexpr int PLANE = ROWS * PITCH;                      // 1296 floats = 16 mod 32 banks
+constexpr int U_FLOATS = NP * 2 * 2 * 64;                // U fragments of one chunk: [p][channel quad][cout block][64 lanes]
+constexpr int BUF = WCK * PLANE + U_FLOATS;              // one pipeline buffer
+static_assert(PLANE % 32 == 16 && PLANE % 4 == 0 && U_FLOATS % 256 == 0, "layout");
+
+struct W44KArgs {
+    const float* src[MR_MAX_SOURCES];
+    int src_bytes[MR_MAX_SOURCES];
+    int src_c[MR_MAX_SOURCES];
+    int src_cpad[MR_MAX_SOURCES];       // padded to a multiple of WCK
+    int nsrc;
+    int H, W;
+    float* dst;
+    const float* bias;
+    const float* res;
+    int act;
+    float p0;
+    int Cout, tiles_x, nchunks;
+    const float* w;
+    long long wgroup_stride;            // packed floats per group of 32 output channels
+};
+
+// LDS-DMA through inline asm (see conv_mfma.hip: the builtins make hipcc drain vmcnt before every sweep)
+__device__ __forceinline__ void dma_buffer_x4(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
+    unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const float* g) {
+    unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ float act44(float v, int act, float p0) {
+    switch (act) {
+        case MR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MR_ACT_LEAKY_RELU: return v > 0.f ? v : v * p0;
+        default: return v;
+    }
+}
+
+__global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
+    const int grp = blockIdx.y, b = blockIdx.z;
+    const int oy0 = ty_wg * RH, ox0 = tx_wg * RW;
+    const int H = a.H, W = a.W, HW = H * W;
+
+    int voff4[NI];                                            // lane l owns the 16-byte groups r = l + 64 i of a plane: row r / 18, group r % 18
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = lane + 64 * i;
+        const int row = r / G4, g4 = r - row * G4;
+        const int gy = oy0 - 1 + row, gx = ox0 - 4 + 4 * g4;
+        const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff4[i] = r < NG ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
+    const float* wgrp = a.w + (long long)grp * a.wgroup_stride;
+
+    f32x4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int cs = 0, cc0 = 0;                                      // chunk cursor: source, first channel
+    auto issue = [&](int q, int pb) {
+        const unsigned buf_addr = lds_base + pb * BUF * 4;
+        const unsigned u_addr = buf_addr + WCK * PLANE * 4;
+        const float* wsrc = wgrp + (long long)q * U_FLOATS;
+        for (int kb = wave; kb < U_FLOATS / 256; kb += 8) dma_global_x4(u_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
+        const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
+        const bool cok = cc0 + wave < a.src_c[cs];            // padded channels read as zero
+        const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+
+    issue(0, 0);
+    const int tb = wave & 3, cb = wave >> 2;                  // tile row of the workgroup, block of 16 output channels of the group
+    const int t = lane & 15;
+    const bool active = (grp * 2 + cb) * 16 < a.Cout;         // a 16-channel tail group: the waves of its empty block only move data
+    // the 6x6 patch of tile (tb, t), channel lane >> 4 of a quad: raw rows 4 tb .. 4 tb + 5, raw columns 4 t + 3 .. 4 t + 8, read as the three
+    // aligned 16-byte groups from column 4 t on
+    const int patch0 = (lane >> 4) * PLANE + (4 * tb) * PITCH + 4 * t;
+    for (int q = 0; q < a.nchunks; ++q) {
+        const int pb = q & 1;
+        const float* raw = lds + pb * BUF;
+        const float* ub = raw + WCK * PLANE + cb * 64 + lane;
+        dma_wait_all();
+        __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
+        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
+        if (!active) continue;
+#pragma nounroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* rp = raw + patch0 + c4 * 4 * PLANE;
+            float v[NP];                                      // h = d B per patch row first, then B^T h per column, in place
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float x[12];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 g = *(const f32x4*)(rp + r * PITCH + 4 * j);
+                    x[4 * j] = g.x; x[4 * j + 1] = g.y; x[4 * j + 2] = g.z; x[4 * j + 3] = g.w;
+                }
+                float d[6], h[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) d[c] = x[3 + c];
+                ct_input_4_3(d, h);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[r * 6 + c] = h[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                float d[6], h[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) d[r] = v[r * 6 + c];
+                ct_input_4_3(d, h);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) v[r * 6 + c] = h[r];
+            }
+            const float* uq = ub + c4 * 128;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[p * 256], v[p], acc[p], 0, 0, 0);
+        }
+    }
+    // ---- output transform Y = A^T M A per (cout, tile) in registers, epilogue --------------------------------------------------------
+    const int ox = ox0 + 4 * t;
+    const int oyb = oy0 + 4 * tb;
+    if (!active || ox >= W || oyb >= H) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cout = (grp * 2 + cb) * 16 + (lane >> 4) * 4 + r;
+        if (cout >= a.Cout) continue;
+        float s[4][6];                                        // A^T M: columns of M through the output transform
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float mm[6], y[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) mm[i] = acc[i * 6 + j][r];
+            ct_output_4_3(mm, y);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k][j] = y[k];
+        }
+        const float bs = a.bias ? a.bias[cout] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oy = oyb + k;
+            if (oy >= H) continue;
+            float y[4];
+            ct_output_4_3(s[k], y);
+            const long long idx = ((long long)(b * a.Cout + cout) * H + oy) * W + ox;      // W % 4 == 0 and ox % 4 == 0: all four columns exist
+            f32x4 o = (f32x4){y[0] + bs, y[1] + bs, y[2] + bs, y[3] + bs};
+            if (a.res) o += *(const f32x4*)(a.res + idx);
+            o.x = act44(o.x, a.act, a.p0); o.y = act44(o.y, a.act, a.p0); o.z = act44(o.z, a.act, a.p0); o.w = act44(o.w, a.act, a.p0);
+            *(f32x4*)(a.dst + idx) = o;
+        }
+    }
+}
+
+int pad8(int c) { return (c + 7) & ~7; }
+
+struct W44Derived {
+    W44KArgs k;
+    dim3 grid;
+    size_t lds_bytes;
+};
+
+int derive44(const mr_wino_desc* d, W44Derived* out) {
+    if (!d || d->num_src < 1 || d->num_src > MR_MAX_SOURCES || d->batch < 1 || d->height < 1 || d->width < 4 || !d->dst ||
+        !d->packed_weights || d->out_channels < 1)
+        return MR_ERR_BAD_ARGUMENT;
+    if (d->width % 4) return MR_ERR_UNSUPPORTED;              // 16-byte groups entirely inside or outside the image
+    if (d->activation != MR_ACT_NONE && d->activation != MR_ACT_RELU && d->activation != MR_ACT_LEAKY_RELU) return MR_ERR_UNSUPPORTED;
+    W44KArgs& k = out->k;
+    memset(&k, 0, sizeof(k));
+    int nchunks = 0;
+    for (int s = 0; s < d->num_src; ++s) {
+        if (!d->src[s] || d->src_channels[s] < 1) return MR_ERR_BAD_ARGUMENT;
+        const long long bytes = (long long)d->batch * d->src_channels[s] * d->height * d->width * 4;
+        if (bytes >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
+        k.src[s] = d->src[s];
+        k.src_bytes[s] = (int)bytes;
+        k.src_c[s] = d->src_channels[s];
+        k.src_cpad[s] = pad8(d->src_channels[s]);
+        nchunks += k.src_cpad[s] / WCK;
+    }
+    if ((long long)d->batch * d->out_channels * d->height * d->width * 4 >= (1ll << 33)) return MR_ERR_UNSUPPORTED;
+    k.nsrc = d->num_src;
+    k.H = d->height; k.W = d->width;
+    k.dst = d->dst; k.bias = d->bias; k.res = d->residual;
+    k.act = d->activation; k.p0 = d->act_p0;
+    k.Cout = d->out_channels;
+    k.tiles_x = (d->width + RW - 1) / RW;
+    k.nchunks = nchunks;
+    k.w = d->packed_weights;
+    k.wgroup_stride = (long long)nchunks * U_FLOATS;
+    const int groups = (d->out_channels + 31) / 32;
+    if (d->batch >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
+    out->grid = dim3((unsigned)(k.tiles_x * ((d->height + RH - 1) / RH)), (unsigned)groups, (unsigned)d->batch);
+    out->lds_bytes = (size_t)(2 * BUF) * 4;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t mr_wino44_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src) {
+    if (!src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || out_channels < 1) return 0;
+    int nchunks = 0;
+    for (int s = 0; s < num_src; ++s) nchunks += pad8(src_channels[s]) / WCK;
+    return (size_t)((out_channels + 31) / 32) * nchunks * U_FLOATS;
+}
+
+// weight: (out_channels, sum(src_channels), 3, 3) fp32, nn.Conv2d layout.  U = G g G^T (6 x 6; G of F(4,3): cooktoom_1d.h) in double, rounded
+// once to fp32; stream order [group of 32 output channels][chunk (source-major, 8 channels)][position p = 6 i + j][channel quad][block of
+// 16 channels of the group][64 lanes], lane l = (cout l & 15 of the block, channel l >> 4 of the quad).
+extern "C" int mr_wino44_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst) {
+    if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || out_channels < 1) return MR_ERR_BAD_ARGUMENT;
+    int cin_total = 0;
+    for (int s = 0; s < num_src; ++s) cin_total += src_channels[s];
+    const int groups = (out_channels + 31) / 32;
+    size_t o = 0;
+    for (int g = 0; g < groups; ++g) {
+        int cin_off = 0;
+        for (int s = 0; s < num_src; ++s) {
+            const int cpad = pad8(src_channels[s]);
+            for (int c0 = 0; c0 < cpad; c0 += WCK)
+                for (int p = 0; p < NP; ++p)
+                    for (int c4 = 0; c4 < 2; ++c4)
+                        for (int mb = 0; mb < 2; ++mb)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int cout = g * 32 + mb * 16 + (lane & 15);
+                                const int cl = c0 + c4 * 4 + (lane >> 4);
+                                double u = 0.0;
+                                if (cout < out_channels && cl < src_channels[s]) {
+                                    const float* gw = weight + ((size_t)cout * cin_total + (cin_off + cl)) * 9;
+                                    const int pi = p / 6, pj = p % 6;
+                                    for (int i = 0; i < 3; ++i) {
+                                        double row = 0.0;
+                                        for (int j = 0; j < 3; ++j) row += (double)gw[i * 3 + j] * CT_G_4_3[pj][j];
+                                        u += CT_G_4_3[pi][i] * row;
+                                    }
+                                }
+                                dst[o++] = (float)u;
+                            }
+            cin_off += src_channels[s];
+        }
+    }
+    return 0;
+}
+
+extern "C" int64_t mr_conv3x3_winograd44_lds_bytes(const mr_wino_desc* desc) {
+    W44Derived dv;
+    const int rc = derive44(desc, &dv);
+    return rc != 0 ? rc : (int64_t)dv.lds_bytes;
+}
+
+extern "C" int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream) {
+    W44Derived dv;
+    const int rc = derive44(desc, &dv);
+    if (rc != 0) return rc;
+    static std::atomic<unsigned long long> attr_set{0};      // dynamic-LDS ceiling once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino44_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(conv3x3_wino44_kernel, dv.grid, dim3(512), dv.lds_bytes, (hipStream_t)stream, dv.k);
+    return (int)hipGetLastError();
+}

@@ -171,7 +171,8 @@ def winograd_signature(cout, src_channels, h, w, batch):
 def choose_winograd(cout, src_channels, h, w, batch):
     """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
     11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), 21 = variant 2 (11 whose 1..16 tail channels
-    come from 16-row workgroups: the 48-channel layers), for a 3x3 stride-1 convolution.  The
+    come from 16-row workgroups: the 48-channel layers), 31 = F(4x4,3x3) (csrc/conv_wino44.hip; only by the table), for a 3x3 stride-1
+    convolution.  The
     measured table (tools/bench_wino.py --emit, MI355X) wins; shapes it does not know go to the Winograd kernel when it has enough
     workgroups (8 x 32 output pixels each) to fill the chip - below that the direct kernel's smaller tiles and split-K win
     (measured: every ResNet layer of a batch-1 keyframe) - with the variant that measured faster at that width on every shape of
@@ -485,7 +486,11 @@ class Plan:
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = weight.detach().to(torch.float32).contiguous().cpu()
-        if variant == 2:       # 32 a + (1..16) output channels: the tail group by 16-row workgroups (csrc/conv_wino.hip: wino_rb_tail)
+        if variant == 3:       # F(4x4,3x3) (csrc/conv_wino44.hip): 36 positions, 16 x 64 pixels x 32 channels per workgroup
+            nfl = lib.mr_wino44_packed_weight_floats(cout, sc, len(src_channels))
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44_pack_weights_f32")
+        elif variant == 2:     # 32 a + (1..16) output channels: the tail group by 16-row workgroups (csrc/conv_wino.hip: wino_rb_tail)
             assert mbw == 1 and 0 < cout % 32 <= 16, (name, cout)
             nfl = lib.mr_wino_packed_weight_floats_tail(cout, sc, len(src_channels))
             packed = torch.empty(nfl, dtype=torch.float32)
@@ -508,12 +513,15 @@ class Plan:
             assert residual.shape == out.shape
             d.residual = residual.data_ptr()
         d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
-        lds = lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d))
+        lds = lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) if variant == 3 else lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} winograd")
         ref = n * hs * ws * cout * cin * 9
-        wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (32 * mbw))
-        self.conv_log.append(dict(name=name, macs=ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+        if variant == 3:
+            wgs = math.ceil(hs / 16) * math.ceil(ws / 64) * n * math.ceil(cout / 32)
+        else:
+            wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (32 * mbw))
+        self.conv_log.append(dict(name=name, macs=ref // 4 if variant == 3 else ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(3, 3), out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=variant, bf16=0,
                                   sig=winograd_signature(cout, src_channels, hs, ws, n),
                                   spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 3, 3), stride=(1, 1), pad=(1, 1),
@@ -521,9 +529,14 @@ class Plan:
                                             out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
         self.keep += [d, out, residual] + list(srcs)
 
-        def run(stream):
-            _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), name)
-        run.native = (_lib.LAUNCH_WINO3X3, d, 0)
+        if variant == 3:
+            def run(stream):
+                _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), stream), name)
+            run.native = (_lib.LAUNCH_WINO44, d, 0)
+        else:
+            def run(stream):
+                _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), name)
+            run.native = (_lib.LAUNCH_WINO3X3, d, 0)
         self.stages[stage].append((name, run))
         return out
 

@@ -314,7 +314,7 @@ def test_stage_launch_lists_fold_convolution_runs(hip_lib):
             calls += 1
             if isinstance(st, tuple):
                 items, n, nm = st
-                assert n == len(nm) >= 1 and all(items[i].desc for i in range(n)) and all(0 <= items[i].kind <= 5 for i in range(n))
+                assert n == len(nm) >= 1 and all(items[i].desc for i in range(n)) and all(0 <= items[i].kind <= 6 for i in range(n))
                 names += list(nm)
             else:
                 names.append(None)
@@ -709,7 +709,7 @@ def test_winograd_choice_table_and_rule():
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
     # 3x3 / transposed keys: + 10 = input transform in registers, + 20 = ... with 16-channel tail workgroups; 1-D keys: 10 m + blocks = F(m, taps)
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 11, 12, 14, 21, 22, 23, 24, 41, 42, 43, 44}
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 11, 12, 14, 21, 22, 23, 24, 31, 41, 42, 43, 44}          # 31: F(4x4,3x3)
     assert all(v in (0, 21, 22, 23, 24, 41, 42, 43) for k, v in engine.WINOGRAD.items() if k[:3] in ("x7_", "y7_"))
     assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1) in (3, 41, 42, 43) and engine.choose_winograd_1d(1, 256, [256], 16, 32, 1) == 0 and engine.choose_winograd_1d(0, 48, [48], 256, 510, 1) == 0
     assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1, 7) == 43 and engine.choose_winograd_1d(1, 48, [32, 3], 256, 512, 1, 7) == 43      # depth.enc0.0 @ c2: F(4,7)
@@ -845,6 +845,38 @@ def test_cooktoom_weight_packing_and_plan_routing(hip_lib, monkeypatch):
     assert cy["wino_m"] == 4 and cy["macs"] * 28 == cy["ref_macs"] * 10 and cy["sig"].startswith("y7_") and 0 < cy["lds"] <= 160 * 1024
     assert cx["wino_m"] == 2 and cx["macs"] * 14 == cx["ref_macs"] * 8 and cx["sig"].startswith("x7_") and 0 < cx["lds"] <= 160 * 1024
     assert abs(plan.conv_ref_macs() - base.conv_ref_macs()) == 0
+
+
+def test_winograd44_weight_packing(hip_lib):
+    """mr_wino44_pack_weights_f32: U = G g G^T (6 x 6, G of F(4,3): cooktoom.py) in double, rounded once, in the stream order conv_wino44.hip
+    reads - [group of 32 couts][chunk of 8 channels, source-major][position 6 i + j][channel quad][block of 16][64 lanes]."""
+    from monorec_amd import cooktoom
+    G = np.array([[float(v) for v in row] for row in cooktoom.cook_toom(4, 3)[1]])
+    g = torch.Generator().manual_seed(13)
+    srcs_c, cout = [5, 11], 40
+    cin = sum(srcs_c)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    cpads = [(c + 7) // 8 * 8 for c in srcs_c]
+    groups = (cout + 31) // 32
+    n = hip_lib.mr_wino44_packed_weight_floats(cout, sc, len(srcs_c))
+    assert n == groups * sum(cpads) // 8 * (36 * 2 * 2 * 64)
+    packed = torch.empty(n)
+    _lib.check(hip_lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
+    st = packed.numpy().reshape(groups, sum(cpads) // 8, 36, 2, 2, 64)
+    want = np.einsum("ia,ocab,jb->ijoc", G, w.double().numpy(), G).reshape(36, cout, cin)
+    off, cin_off = 0, 0
+    for c, cp in zip(srcs_c, cpads):
+        for cl in range(cp):
+            q, c4, hi = (off + cl) // 8, ((off + cl) % 8) // 4, (off + cl) % 4
+            for co in range(groups * 32):
+                got = st[co // 32, q, :, c4, (co // 16) % 2, hi * 16 + co % 16]
+                exp = want[:, co, cin_off + cl] if (co < cout and cl < c) else np.zeros(36)
+                assert np.allclose(got, exp, rtol=3e-7, atol=1e-9), (co, cl)
+        off, cin_off = off + cp, cin_off + c
+    assert hip_lib.mr_wino44_packed_weight_floats(0, sc, len(srcs_c)) == 0
+    d = _lib.WinoDesc()
+    assert hip_lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) == -1            # empty descriptor: bad argument, nothing launched
 
 
 def _check_host_geometry_against_the_reference_form():

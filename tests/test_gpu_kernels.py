@@ -834,6 +834,79 @@ def test_gather_small_into_pinned_host_memory(hip_lib):
     assert hip_lib.mr_gather_small_f32(ptrs, 0, 32, host.data_ptr(), None) == -1 and hip_lib.mr_gather_small_f32(ptrs, 19, 32, host.data_ptr(), None) == -1
 
 
+WINO44_EXTRA_CASES = [((32,), 32, (64, 128), 2, ACT_LEAKY_RELU, False, 1),        # 4 x 2 workgroups per image, one group of 32 channels
+                      ((48,), 48, (40, 192), 1, ACT_LEAKY_RELU, False, 1)]        # 48 = 32 + 16: the second group's upper block is empty; H % 16 != 0
+
+
+@pytest.mark.parametrize("case", range(len(WINO_CASES) + len(WINO44_EXTRA_CASES)))
+def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
+    """mr_conv3x3_winograd44_f32 (F(4x4,3x3), csrc/conv_wino44.hip) against F.conv2d(padding=1) on the CPU.  Its transforms have coefficients up
+    to 8, so it rounds more than F(2x2,3x3): the fp32 emulation of the form (oracle/numerics_study_winograd.py) is within 9e-6 of the fp64
+    result on these cases (F(2x2,3x3): 6e-7); bar 4e-5 of the output scale - model level: depth moves by 2.4e-7."""
+    srcs_c, cout, (h, w), batch, act, residual, _ = (WINO_CASES + WINO44_EXTRA_CASES)[case]
+    lib = hip_lib
+    g = torch.Generator().manual_seed(100 + case)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * math.sqrt(cin)))
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(batch, cout, h, w, generator=g) if residual else None
+    ref = F.conv2d(torch.cat(srcs, 1), wt, bias, padding=1)
+    if residual:
+        ref = ref + res
+    ref = _act_ref(ref, act, 0.1, 0.0)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_wino44_packed_weight_floats(cout, sc, len(srcs_c))
+    packed = torch.empty(n)
+    _lib.check(lib.mr_wino44_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s.to(DEV) for s in srcs]
+    for i, s in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, h, w), float("nan"), device=DEV)
+    pk, bs, rs = packed.to(DEV), bias.to(DEV), (res.to(DEV) if residual else None)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), (rs.data_ptr() if residual else None)
+    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, 1, 3
+    assert 0 < lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) <= 160 * 1024
+    _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()), "mr_conv3x3_winograd44_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 4e-5 * max(1.0, float(ref.abs().max())), err
+    if case == 0:
+        d.width = 98
+        assert lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()) == -2            # width % 4: unsupported
+        d.width, d.packed_weights = w, None
+        assert lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()) == -1
+
+
+def test_plan_routes_3x3_layers_to_the_f44_kernel(hip_lib, monkeypatch):
+    """Table code 31 sends a 3x3 stride-1 layer to mr_conv3x3_winograd44_f32 (through the native launch list as well); the executed
+    multiply-adds are a quarter of the reference's."""
+    g = torch.Generator().manual_seed(80)
+    xs = [torch.randn(2, 16, 32, 128, generator=g), torch.randn(2, 24, 32, 128, generator=g)]
+    wt = torch.randn(48, 40, 3, 3, generator=g) * (1.0 / (3.0 * math.sqrt(40.0)))
+    bias = torch.randn(48, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(torch.cat(xs, 1), wt, bias, padding=1), 0.1)
+    sig = engine.winograd_signature(48, [16, 24], 32, 128, 2)
+    for code in (0, 21, 31):
+        monkeypatch.setitem(engine.WINOGRAD, sig, code)
+        plan = engine.Plan.bare(DEV)
+        plan.winograd = True
+        out = torch.full((2, 48, 32, 128), float("nan"), device=DEV)
+        plan.conv("main", "t", [x.to(DEV) for x in xs], wt, bias, out, stride=(1, 1), pad=(1, 1), grid=(32, 128), act=ACT_LEAKY_RELU, p0=0.1)
+        plan.finalize()
+        log = plan.conv_log[0]
+        assert bool(log.get("winograd")) == bool(code) and log["ref_macs"] == 2 * 32 * 128 * 48 * 40 * 9
+        if code == 31:
+            assert log["wino_variant"] == 3 and log["macs"] * 4 == log["ref_macs"] and log["wgs"] == 2 * 2 * 2 * 2
+        plan.run_stage("main", _stream())
+        torch.cuda.synchronize()
+        assert float((out.cpu() - ref).abs().max()) <= 4e-5 * max(1.0, float(ref.abs().max())), code
+
+
 # ---- 1-D Winograd F(2,3) kernel (csrc/conv1d_wino.hip) ---------------------------------------------------------------------------
 WINO_1D_CASES = [
     # (srcs_c, cout, (H, W), batch, act, mbw)

@@ -40,7 +40,11 @@ def timed(fn, iters=50):
 def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, variant=0):
     sc = [int(s.shape[1]) for s in srcs]
     arr = (ctypes.c_int32 * len(sc))(*sc)
-    if variant == 2:
+    if variant == 3:                                   # F(4x4,3x3): csrc/conv_wino44.hip
+        n = lib.mr_wino44_packed_weight_floats(weight.shape[0], arr, len(sc))
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(lib.mr_wino44_pack_weights_f32(weight.contiguous().data_ptr(), weight.shape[0], arr, len(sc), packed.data_ptr()), "pack")
+    elif variant == 2:
         n = lib.mr_wino_packed_weight_floats_tail(weight.shape[0], arr, len(sc))
         packed = torch.empty(n, dtype=torch.float32)
         _lib.check(lib.mr_wino_pack_weights_tail_f32(weight.contiguous().data_ptr(), weight.shape[0], arr, len(sc), packed.data_ptr()), "pack")
@@ -58,7 +62,12 @@ def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, varia
     d.residual = residual.data_ptr() if residual is not None else None
     d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
     keep = (pk, bs, d)
+    if variant == 3:
+        return (lambda stream: _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), stream), "wino44")), keep
     return (lambda stream: _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), "wino")), keep
+
+
+CODES = (1, 2, 11, 12, 21, 31)
 
 
 def main():
@@ -69,6 +78,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--min-pixels", type=int, default=0, help="skip layers with fewer output pixels per image (a quick pass over the big layers)")
     ap.add_argument("--emit", default=None, help="write {signature: 0 | 1 | 2 | 11 | 12} (fastest kernel per layer; Winograd must win by 3 %%; + 10 = input "
                                                  "transform in registers) to this JSON file; entries already in the file for other shapes are kept")
     a = ap.parse_args()
@@ -84,6 +94,8 @@ def main():
             continue
         if a.only and a.only not in c["name"]:
             continue
+        if sp["grid"][0] * sp["grid"][1] < a.min_pixels:
+            continue
         srcs = [torch.randn(*s, generator=g).to(DEV) for s in sp["src_shapes"]]
         cout, cin = sp["w_shape"][0], sp["w_shape"][1]
         w = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3.0 * cin ** 0.5))
@@ -97,7 +109,7 @@ def main():
         direct = plan.stages["main"][0][1]
         row = {"name": c["name"], "cin": cin, "cout": cout, "hw": list(sp["grid"]), "n": sp["out_shape"][0], "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"]],
                "direct_us": round(timed(direct), 1)}
-        for code in (1, 2, 11, 12, 21):                   # cout blocks per wave, + 10: input transform in registers, + 20: ... with tail workgroups
+        for code in CODES:                   # cout blocks per wave, + 10: input transform in registers, + 20: ... with tail workgroups, 31: F(4x4,3x3)
             mbw, variant = code % 10, code // 10
             if mbw == 2 and cout <= 32:
                 continue
@@ -111,7 +123,7 @@ def main():
             row[f"wino{code}_maxdiff"] = float((out_w - out_d).abs().max())
             row[f"wino{code}_us"] = round(timed(fn), 1)
         best, tb = 0, 0.97 * row["direct_us"]                # Winograd must win by 3 %
-        for code in (1, 2, 11, 12, 21):
+        for code in CODES:
             if f"wino{code}_us" in row and row[f"wino{code}_us"] < tb:
                 best, tb = code, row[f"wino{code}_us"]
         row["sig"] = engine.winograd_signature(cout, [s_[1] for s_ in sp["src_shapes"]], sp["grid"][0], sp["grid"][1], sp["out_shape"][0])
@@ -125,7 +137,7 @@ def main():
         with open(a.emit, "w") as f:
             json.dump(table, f, indent=0, sort_keys=True)
     tot_d = sum(r["direct_us"] for r in rows)
-    tot_w = sum(min([r["direct_us"]] + [r.get(f"wino{c}_us", 1e9) for c in (1, 2, 11, 12, 21)]) for r in rows)
+    tot_w = sum(min([r["direct_us"]] + [r.get(f"wino{c}_us", 1e9) for c in CODES]) for r in rows)
     print(json.dumps({"layers": len(rows), "direct_total_us": round(tot_d, 1), "best_of_both_total_us": round(tot_w, 1)}))
 
 

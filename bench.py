@@ -552,7 +552,8 @@ def main():
                              "valu_frac_note": "SQ_INSTS_VALU x 64 lanes / sad-kernel time / 78.6e12 lane-instr/s", "counters_source": pmc_src})
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
-        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3))
+        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") != 3)
+        n_wino44 = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") == 3)
         n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and c.get("wino_m", 2) == 2 and max(c["k"]) == 3)
         ct_forms = sorted({f"F({c['wino_m']},{max(c['k'])})" for c in model._plans[plan_key].conv_log
                            if c.get("winograd") and min(c["k"]) == 1 and (c.get("wino_m", 2), max(c["k"])) != (2, 3)})
@@ -561,7 +562,7 @@ def main():
         n_wino_t = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv"))
         roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
-                 f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches) + convt4x4_wino[_rb]_kernel "
+                 f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches)" + (f" + conv3x3_wino44_kernel (F(4x4,3x3), {n_wino44})" if n_wino44 else "") + " + convt4x4_wino[_rb]_kernel "
                  f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d})" + (f" + conv1d_ct_kernel ({' / '.join(ct_forms)} for k x 1 / 1 x k, {n_ct})" if n_ct else "") + f" + upconv2x2_wino_kernel (4-multiply Upconv, {n_wino_u}); all fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "frac_executed": conv_flops_executed / conv_s / 1e12 / peak,
@@ -573,8 +574,8 @@ def main():
                 "algorithmic_gflop_per_step": conv_flops / 1e9, "executed_gflop_per_step": conv_flops_executed / 1e9,
                 "algorithmic_note": "the reference's Conv2d / ConvTranspose2d MACs x 2 (SURVEY 8d); executed is lower where Upconv runs "
                                     "phase-decomposed on the low-resolution input (9 of 16 taps), where a 3x3 convolution runs as Winograd "
-                                    "F(2x2,3x3) (16 of 36 multiplies), where a ConvTranspose2d(4,2) runs as F(2x2,2x2) (9 of 16) and where a 3x1 / 1x3 convolution "
-                                    "runs as F(2,3) (4 of 6); the two large Upconv layers run on 4 of 16",
+                                    "F(2x2,3x3) (16 of 36 multiplies) or F(4x4,3x3) (36 of 144), where a ConvTranspose2d(4,2) runs as F(2x2,2x2) (9 of 16) and where a k x 1 / 1 x k "
+                                    "convolution runs as F(2,3) (4 of 6), F(4,3) (6 of 12) or F(4,7) (10 of 28); the two large Upconv layers run on 4 of 16",
                 "conv_ms_per_step": conv_s * 1e3,
                 "splitk_finishing_launches_per_step": sum(1 for c in model._plans[plan_key].conv_log if c["split_k"] > 1),
                 "all_kernel_launches_per_step": len(rows) + sum(1 for c in model._plans[plan_key].conv_log if c["split_k"] > 1) + 2,

@@ -265,7 +265,10 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     wino = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3)]
     assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
                                          "mask.dec3.2", "depth.dec4.2"}
-    assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
+    # (F(2x2,3x3): 16 of 36 multiplies; the two 32-channel full-resolution layers on F(4x4,3x3), csrc/conv_wino44.hip: 36 of 144)
+    assert all(c["macs"] * (4 if c.get("wino_variant") == 3 else 9) == c["ref_macs"] * (1 if c.get("wino_variant") == 3 else 4) and c["lds"] <= 160 * 1024
+               for c in wino)
+    assert {c["name"] for c in wino if c.get("wino_variant") == 3} == {"mask.enc0.0", "mask.enc0.1"}
     assert {c["name"] for c in wino if c.get("wino_variant") == 2} == {"mask.dec3.1", "mask.dec3.2"}     # 48 channels: 32 + a 16-channel tail
     # ... and the two large Refine layers (ConvTranspose2d(4, 2)) on the F(2x2,2x2) kernel (csrc/convt_wino.hip) at 9/16
     wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv")]

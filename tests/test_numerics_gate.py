@@ -1,0 +1,39 @@
+"""CPU: the numerics gate of the reduced-multiply kernels.  The larger Cook-Toom / Winograd forms (F(4,3), F(2,7), F(4,7), F(4x4,3x3):
+csrc/conv1d_wino.hip, csrc/conv_wino44.hip) have transform coefficients up to 89 and thirds / 2835ths in G; before any of those kernels was
+written, oracle/numerics_study_winograd.py measured on the oracle's own forward what evaluating the affected layers that way does to `result`
+(emulated fp32, transformed weights rounded once from double).  This test keeps that measurement alive at a small shape: every form the
+product's table may select must leave the depth far inside the 1e-4 parity bar."""
+import pytest
+
+from oracle import numerics_study_winograd as study
+
+
+def test_every_form_the_table_may_select_keeps_the_depth_far_inside_the_parity_bar():
+    report = study.main(["--height", "64", "--width", "128", "--depths", "32"])
+    exps = report["experiments"]
+    assert len(exps) == 8 and report["bar"] == 1e-4
+    for name, e in exps.items():
+        assert e["layers"] > 0, name
+        assert e["result_max_abs_diff"] <= 2e-6, (name, e["result_max_abs_diff"])          # measured 1.5e-7 .. 2.8e-7: 1/50 of this bound, 1/350 of the bar
+        assert e["cv_mask_max_abs_diff"] <= 1e-5, (name, e["cv_mask_max_abs_diff"])
+    # per layer the larger forms do round more than the direct sum - the reason the gate exists
+    assert exps["F(4,7) 7x1 + 1x7"]["median_layer_err"] > 5 * exps["F(4,7) 7x1 + 1x7"]["median_direct_err"]
+    assert exps["F(4x4,3x3) all 3x3 stride-1 layers"]["median_layer_err"] > 2 * exps["F(4x4,3x3) all 3x3 stride-1 layers"]["median_direct_err"]
+
+
+def test_cook_toom_emulation_equals_the_direct_convolution_up_to_rounding():
+    import math
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 9, 13, 22, generator=g)
+    for m, r, tol in ((2, 3, 1e-5), (4, 3, 2e-5), (2, 7, 3e-5), (4, 7, 3e-4)):
+        for axis in (2, 3):
+            kk = (r, 1) if axis == 2 else (1, r)
+            w = torch.randn(5, 9, *kk, generator=g) / math.sqrt(9.0 * r)
+            b = torch.randn(5, generator=g)
+            ref = F.conv2d(x, w, b, padding=(kk[0] // 2, kk[1] // 2))
+            assert float((study.winograd_1d(x, w, b, axis, m) - ref).abs().max()) <= tol, (m, r, axis)
+    w = torch.randn(5, 9, 3, 3, generator=g) / 9.0
+    for m, tol in ((2, 1e-5), (4, 5e-5)):
+        assert float((study.winograd_2d(x, w, None, m) - F.conv2d(x, w, None, padding=1)).abs().max()) <= tol, m

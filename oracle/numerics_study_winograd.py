@@ -1,11 +1,12 @@
 """TEST INFRASTRUCTURE (CPU only, never imported by the product): what larger Winograd / Cook-Toom tiles would do to the parity bar.
 
-The product runs the 3x3 stride-1 layers on F(2x2,3x3) and the 3x1 / 1x3 layers on F(2,3): transform
-coefficients 0, +-1, +-1/2, depth within 1.3e-6 of the CPU output.  The next step in multiplies would be F(4x4,3x3) (36 instead of 64
+The product first ran the 3x3 stride-1 layers on F(2x2,3x3) and the 3x1 / 1x3 layers on F(2,3): transform
+coefficients 0, +-1, +-1/2, depth within 1.3e-6 of the CPU output.  The next step in multiplies is F(4x4,3x3) (36 instead of 64
 multiplies per 4x4 outputs), F(4,3) along one axis (6 instead of 8 per 4 outputs) and F(2,7) / F(4,7) for the 7-tap layers of
-DepthModule.enc.0.0 (model/monorec/monorec_model.py:487-500, model/layers.py:289-314) - with interpolation points +-2, +-1/2 and
-constants up to 8 and 1/24.  Before any kernel is written this script answers, in emulated fp32 on the oracle's own activations:
-how far does `result` move when those layers are evaluated that way?  (bar: 1e-4 on the depth)
+DepthModule.enc.0.0 (model/monorec/monorec_model.py:487-500, model/layers.py:289-314) - with interpolation points +-2, +-1/2, +-4 and
+constants up to 89 and 1/2835.  BEFORE any of those kernels was written this script answered, in emulated fp32 on the oracle's own
+activations: how far does `result` move when those layers are evaluated that way?  (bar: 1e-4 on the depth; answer: 2-4e-7,
+profiles/r03_numerics_study_winograd.json; kept alive by tests/test_numerics_gate.py)
 
     python -m oracle.numerics_study_winograd [--height 256 --width 512] [--json out.json]
 
@@ -15,78 +16,24 @@ channel sum in fp32 (torch matmul; the MFMA's exact k-ordered chain differs from
 import argparse
 import json
 import sys
-from fractions import Fraction
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from monorec_amd import synth
+from monorec_amd import cooktoom, synth
 from oracle import monorec_oracle as oracle
 
 
 # ---------------------------------------------------------------------------------------------------------------- Cook-Toom matrices
-def cook_toom(m, r, points):
-    """F(m, r) for correlation y_k = sum_j g_j d_{k+j}: returns (AT m x n, G n x r, BT n x n) as Fractions, n = m + r - 1, the
-    last interpolation point at infinity.  BT is solved from the bilinear identity, so the triple is exact by construction."""
-    n = m + r - 1
-    assert len(points) == n - 1
-    pts = [Fraction(p) for p in points]
-    AT = [[(pts[i] ** k if i < n - 1 else (Fraction(1) if k == m - 1 else Fraction(0))) for i in range(n)] for k in range(m)]
-    G = []
-    for i in range(n - 1):
-        norm = Fraction(1)
-        for j in range(n - 1):
-            if j != i:
-                norm *= pts[i] - pts[j]
-        G.append([pts[i] ** j / norm for j in range(r)])
-    G.append([Fraction(0)] * (r - 1) + [Fraction(1)])
-    # sum_i AT[k][i] G[i][j] BT[i][l] = [l == k + j]  for all k < m, j < r, l < n: n unknowns per column l, m r equations
-    BT = [[Fraction(0)] * n for _ in range(n)]
-    rows = [[AT[k][i] * G[i][j] for i in range(n)] for k in range(m) for j in range(r)]
-    for l in range(n):
-        rhs = [Fraction(1) if l == k + j else Fraction(0) for k in range(m) for j in range(r)]
-        sol = _solve(rows, rhs, n)
-        for i in range(n):
-            BT[i][l] = sol[i]
-    return AT, G, BT
-
-
-def _solve(rows, rhs, n):
-    a = [list(r_) + [b] for r_, b in zip(rows, rhs)]
-    piv_cols, row = [], 0
-    for col in range(n):
-        p = next((i for i in range(row, len(a)) if a[i][col] != 0), None)
-        if p is None:
-            continue
-        a[row], a[p] = a[p], a[row]
-        inv = 1 / a[row][col]
-        a[row] = [v * inv for v in a[row]]
-        for i in range(len(a)):
-            if i != row and a[i][col] != 0:
-                f = a[i][col]
-                a[i] = [vi - f * vr for vi, vr in zip(a[i], a[row])]
-        piv_cols.append(col)
-        row += 1
-    assert len(piv_cols) == n, "under-determined"
-    assert all(all(v == 0 for v in r_) for r_ in a[row:]), "inconsistent"
-    return [a[i][n] for i in range(n)]
-
-
-def as_np(mat):
-    return np.array([[float(v) for v in r_] for r_ in mat], dtype=np.float64)
-
-
-# finite interpolation points by tile size n = m + r - 1 (the usual choice: small integers and their reciprocals)
-POINTS = {4: [0, 1, -1], 6: [0, 1, -1, 2, -2], 8: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2)],
-          10: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2), 4, -4]}
+# (ONE derivation for the study, the generated kernel header and the tests: monorec_amd/cooktoom.py, exact rational arithmetic)
 _CACHE = {}
 
 
 def matrices(m, r):
+    """(A^T, G, B^T) of F(m, r) as float64 arrays."""
     if (m, r) not in _CACHE:
-        at, g, bt = cook_toom(m, r, POINTS[m + r - 1])
-        _CACHE[(m, r)] = (as_np(at), as_np(g), as_np(bt))
+        _CACHE[(m, r)] = tuple(np.array([[float(v) for v in row] for row in mat], dtype=np.float64) for mat in cooktoom.cook_toom(m, r))
     return _CACHE[(m, r)]
 
 

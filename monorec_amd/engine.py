@@ -134,6 +134,23 @@ def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False, reduce_bytes=0):
     return max(nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if int(bf16) == 1 else 16)), reduce_bytes)    # bf16x3 blocks: hi + lo = fp32 size
 
 
+# Buffers of a plan that the model hands out as outputs (monorec_model.py:256-279,690,713-727).  `Plan.rebind_outputs` can point every
+# launch that writes or reads them at caller-owned memory instead (MonoRecModel.forward: the outputs are produced where the caller
+# keeps them - no copy), and back at the resident buffers (submit()).
+OUTPUT_BUFFERS = ("cost_volume", "sfcv", "feat0", "feat1", "feat2", "feat3", "feat4", "cv_mask", "pred0", "pred1", "pred2", "pred3")
+
+
+class _Ref:
+    """Run-time pointer of a tensor captured by a launch closure: fixed, or `offset` bytes into an output buffer's CURRENT binding."""
+    __slots__ = ("plan", "name", "offset", "fixed")
+
+    def __init__(self, plan, name, offset, fixed):
+        self.plan, self.name, self.offset, self.fixed = plan, name, offset, fixed
+
+    def ptr(self):
+        return self.fixed if self.name is None else self.plan.bound[self.name] + self.offset
+
+
 TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
 
 
@@ -162,6 +179,23 @@ def _load_winograd():
 
 
 _load_winograd()
+
+
+def plan_stamp():
+    """What decides which kernels a plan launches: sha256 over the two measured tables (tuned_schedules.json, tuned_winograd.json) and
+    the library's ABI version.  tools/summarize_prof.py stamps every committed profile with it; bench.py quotes a committed rocprof
+    figure on its line only when the stamp of that profile equals the stamp of the running plan (the round-3 driver line
+    quoted profiles that were one table behind HEAD)."""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("tuned_schedules.json", "tuned_winograd.json"):
+        path = os.path.join(here, name)
+        h.update(name.encode())
+        h.update(open(path, "rb").read() if os.path.exists(path) else b"-")
+    h.update(f"abi{_lib.MR_ABI_VERSION}".encode())
+    return h.hexdigest()[:16]
 
 
 def winograd_signature(cout, src_channels, h, w, batch):
@@ -305,7 +339,7 @@ class Plan:
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
                  pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3,
-                 one_channel_kernels=None, winograd=None):
+                 one_channel_kernels=None, winograd=None, conv_forms="table"):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps % 4:
@@ -338,12 +372,25 @@ class Plan:
         import os as _os
         # 3x3 stride-1 convolutions on the Winograd F(2x2,3x3) kernel where it is faster (choose_winograd); MR_WINOGRAD=0: A/B aid
         self.winograd = _os.environ.get("MR_WINOGRAD", "1") != "0" if winograd is None else bool(winograd)
+        # which reduced-multiply forms the measured table may select (MonoRecModel(hip_exact_convs=...)):
+        #   "table"  everything it holds, F(4,3) / F(4,7) / F(4x4,3x3) included (transform constants up to 89 and 1/2835);
+        #   "f2"     the F(2,.) forms only (constants 0, +-1, +-1/2: rounding like the direct sum) - a larger form is mapped to the
+        #            F(2,.) kernel of the same layer;
+        #   "direct" none: every convolution on the direct MFMA kernel, an exact fmaf chain per output like the reference's.
+        if conv_forms not in ("table", "f2", "direct"):
+            raise ValueError(f"conv_forms must be 'table', 'f2' or 'direct', got {conv_forms!r}")
+        self.conv_forms = conv_forms
+        if conv_forms == "direct":
+            self.winograd = False
         self.input_ptr = {}       # "keyframe" -> device pointer the launches read the keyframe from (resident copy or the caller's tensor)
         self._input_srcs = []     # (ConvDesc, source index, "keyframe"): descriptor slots that follow input_ptr
         self._frame_ptrs = None   # ctypes array of the F source-frame pointers handed to the cost-volume launch
         self._compiled = {}       # stage -> (launches compiled, [closure | (mr_launch_item array, count, names)]): see run_stage
         self._ws_floats = {}      # stage -> floats: stages may run concurrently on different streams,
         self._pending_ws = []     # so every stage gets its own split-K workspace
+        self.bound = {}           # output buffer name -> base pointer its launches currently use (rebind_outputs)
+        self._relocs = []         # (ctypes object, field name, index or None, output buffer name, byte offset): see _index_outputs
+        self._ptr_arrays = []     # ctypes pointer arrays handed to launches (scanned by _index_outputs)
         if build:
             self._build()
             self.finalize()
@@ -361,6 +408,80 @@ class Plan:
             desc.workspace = self.buf[f"splitk_workspace.{stage}"].data_ptr()
         self._pending_ws = []
         self._ws_floats = {}
+        self._index_outputs()
+
+    # ------------------------------------------------------------------ output binding
+    def _out_range(self, ptr):
+        """(name, byte offset) of the output buffer `ptr` points into, or (None, 0)."""
+        for name in OUTPUT_BUFFERS:
+            t = self.buf.get(name)
+            if t is not None:
+                lo = t.data_ptr()
+                if lo <= ptr < lo + t.numel() * t.element_size():
+                    return name, ptr - lo
+        return None, 0
+
+    def ref(self, t):
+        """Pointer of `t` as a launch closure should read it at run time (follows rebind_outputs when `t` lies in an output buffer)."""
+        name, off = self._out_range(t.data_ptr())
+        return _Ref(self, name, off, t.data_ptr())
+
+    def _index_outputs(self):
+        """Relocation table of the output buffers: every pointer slot of a descriptor (or of a pointer array handed to a launch) that
+        points into one of OUTPUT_BUFFERS, found by address.  Descriptors are referenced by the native launch lists, so patching
+        them in place re-targets the launches."""
+        self.bound = {n: self.buf[n].data_ptr() for n in OUTPUT_BUFFERS if n in self.buf}
+        self._resident = dict(self.bound)
+        self._relocs = []
+        seen = set()
+
+        def slot(obj, field, idx, ptr):
+            if not ptr:
+                return
+            name, off = self._out_range(int(ptr))
+            if name is not None:
+                self._relocs.append((obj, field, idx, name, off))
+        for obj in self.keep:
+            if id(obj) in seen:
+                continue
+            seen.add(id(obj))
+            if isinstance(obj, (ConvDesc, WinoDesc)):
+                for i in range(obj.num_src):
+                    slot(obj, "src", i, obj.src[i])
+                slot(obj, "dst", None, obj.dst)
+                slot(obj, "residual", None, obj.residual)
+            elif isinstance(obj, ctypes.Array) and getattr(obj, "_type_", None) is HeadDesc:
+                for i in range(len(obj)):
+                    slot(obj[i], "src", None, obj[i].src)
+                    slot(obj[i], "dst", None, obj[i].dst)
+        for arr in self._ptr_arrays:
+            for i in range(len(arr)):
+                slot(arr, None, i, arr[i])
+
+    def rebind_outputs(self, bases=None):
+        """Point every launch at `bases[name]` (device pointers of caller-owned memory, one per output buffer, same layout) - or, with
+        None, back at the plan's resident buffers.  Only what changes is patched."""
+        target = self._resident if bases is None else {n: bases.get(n, self._resident[n]) for n in self._resident}
+        if target == self.bound:
+            return
+        changed = {n for n in target if target[n] != self.bound[n]}
+        for obj, field, idx, name, off in self._relocs:
+            if name in changed:
+                p = target[name] + off
+                if field is None:
+                    obj[idx] = p
+                elif idx is None:
+                    setattr(obj, field, p)
+                else:
+                    getattr(obj, field)[idx] = p
+        self.bound = dict(target)
+
+    @property
+    def outputs_rebindable(self):
+        """Plans whose output buffers are written by every forward (the full model): the variants that keep constant content in
+        them (no_cv zero volumes, pretrain_mode 1 / 3 masks, mask-only mode) hand out copies of the resident buffers instead."""
+        preds = getattr(self, "preds", None)
+        return self.pretrain_mode == 0 and not self.no_cv and preds is not None and all(p is not None for p in preds)
 
     # ------------------------------------------------------------------ buffers / parameters
     def alloc(self, name, *shape):
@@ -398,6 +519,8 @@ class Plan:
                 out.shape[1] == cout and tuple(grid) == (hs, ws) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY_RELU) and self.bf16 == 0 and
                 name not in self.schedule_override):
             mbw = choose_winograd(cout, src_channels, hs, ws, n)
+            if mbw // 10 == 3 and self.conv_forms == "f2":
+                mbw = 11                       # F(4x4,3x3) -> F(2x2,3x3), input transform in registers, 32 output channels per workgroup
             if mbw:
                 return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw % 10, mbw // 10)
         if (self.winograd and phases is None and (kh, kw) in ((1, 3), (3, 1), (1, 7), (7, 1)) and tuple(stride) == (1, 1) and tuple(pad) == (kh // 2, kw // 2) and
@@ -406,6 +529,8 @@ class Plan:
                 residual is None and name not in self.schedule_override):
             axis = 0 if kh == 1 else 1
             code = choose_winograd_1d(axis, cout, src_channels, hs, ws, n, max(kh, kw))
+            if code >= 40 and self.conv_forms == "f2":
+                code = code % 10 if max(kh, kw) == 3 else 20 + code % 10     # F(4,3) -> F(2,3), F(4,7) -> F(2,7), same channels per workgroup
             if code:
                 return self._conv_winograd_1d(stage, name, srcs, weight, bias, out, act, p0, axis, code % 10, code // 10 if code >= 10 else 2)
         if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
@@ -775,8 +900,8 @@ class Plan:
         self.conv(st, "resnet.conv1", [kfn], w, b, f0, stride=(2, 2), pad=(3, 3), grid=(H // 2, W // 2), act=ACT_RELU)
         pool = self.alloc("resnet.pool", B, 64, H // 4, W // 4)
 
-        def run_pool(stream, src=f0, dst=pool):
-            _lib.check(lib.mr_maxpool3x3s2_f32(src.data_ptr(), dst.data_ptr(), B * 64, H // 2, W // 2, stream),
+        def run_pool(stream, src=self.ref(f0), dst=pool):
+            _lib.check(lib.mr_maxpool3x3s2_f32(src.ptr(), dst.data_ptr(), B * 64, H // 2, W // 2, stream),
                        "mr_maxpool3x3s2_f32")
         self.add(st, "resnet.maxpool", run_pool)
         feats = [f0]
@@ -813,8 +938,10 @@ class Plan:
         frame_ptrs = (ctypes.c_void_p * F)(*[frames[f].data_ptr() for f in range(F)])
         sfcv_ptrs = (ctypes.c_void_p * F)(*[sfcv[f].data_ptr() for f in range(F)])
         self.keep += [frame_ptrs, sfcv_ptrs]
+        self._ptr_arrays.append(sfcv_ptrs)
         self._frame_ptrs = frame_ptrs
         kinv, proj, depths = self.buf["kinv"], self.buf["proj"], self.buf["depths"]
+        cv_ref = self.ref(cv)
 
         def run_cv(stream):
             pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
@@ -822,12 +949,12 @@ class Plan:
                 _lib.check(lib.mr_cost_volume_mode_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                        depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                        1 if self.sfcv_mult_mask else 0,
-                                                       cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
+                                                       cv_ref.ptr(), sfcv_ptrs, stream), "mr_cost_volume_mode_f32")
             else:
                 _lib.check(lib.mr_cost_volume_patch_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                         depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                         1 if self.sfcv_mult_mask else 0, self.cv_patch_size,
-                                                        cv.data_ptr(), sfcv_ptrs, stream), "mr_cost_volume_patch_f32")
+                                                        cv_ref.ptr(), sfcv_ptrs, stream), "mr_cost_volume_patch_f32")
         if self.no_cv:                     # :682-686: zero volumes, never written (the in-place mask multiply keeps 0)
             sfcv.zero_()
             cv.zero_()
@@ -847,8 +974,8 @@ class Plan:
             mean = self.alloc("mask.sfcv_mean", B, D, H, W)
             prev = self.alloc("prev_depth", B, 1, H, W)      # data_dict["predicted_inverse_depths"][0], copied in by the model
 
-            def run_mean(stream, src=sfcv, dst=mean):
-                _lib.check(lib.mr_nonzero_mean_over_frames_f32(src.data_ptr(), dst.data_ptr(), self.F, B * D * H * W, stream),
+            def run_mean(stream, src=self.ref(sfcv), dst=mean):
+                _lib.check(lib.mr_nonzero_mean_over_frames_f32(src.ptr(), dst.data_ptr(), self.F, B * D * H * W, stream),
                            "mr_nonzero_mean_over_frames_f32")
             self.add(st, "mask.sfcv_mean", run_mean)
             first_srcs, FM = [mean, kf, prev], 1
@@ -905,11 +1032,12 @@ class Plan:
             cw_ = self._dev(sd[f"{am}.classifier.0.weight"].reshape(-1))
             cb_ = self._dev(sd[f"{am}.classifier.0.bias"].reshape(-1))
             mask_applied = with_depth and self.pretrain_mode == 0
-            cvp = cv if mask_applied else None
+            cvp = cv_ref if mask_applied else None
+            mask_ref = self.ref(cv_mask)
 
             def run_classifier(stream, feat=feat, cw_=cw_, cb_=cb_, cvp=cvp):
                 _lib.check(lib.mr_mask_classifier_f32(feat.data_ptr(), cw_.data_ptr(), cb_.data_ptr(), B, int(feat.shape[1]), H * W,
-                                                      cv_mask.data_ptr(), cvp.data_ptr() if cvp is not None else None, D, stream),
+                                                      mask_ref.ptr(), cvp.ptr() if cvp is not None else None, D, stream),
                            "mr_mask_classifier_f32")
             self.add(st, "mask.classifier", run_classifier)
             self.aux_log.append(dict(name="mask.classifier", ref_macs=B * H * W * int(feat.shape[1])))
@@ -923,8 +1051,10 @@ class Plan:
         if not with_depth:                 # pretrain_mode 2 (:693, :712, :723-724): mask only
             return
 
+        mask_ref2 = self.ref(cv_mask)
+
         def run_mask(stream):                                                        # :713 (in place)
-            _lib.check(lib.mr_apply_mask_f32(cv.data_ptr(), cv_mask.data_ptr(), cv.data_ptr(), B, D, H * W, stream),
+            _lib.check(lib.mr_apply_mask_f32(cv_ref.ptr(), mask_ref2.ptr(), cv_ref.ptr(), B, D, H * W, stream),
                        "mr_apply_mask_f32")
         if self.pretrain_mode != 1 and not mask_applied:        # (1 - 0) * cv == cv exactly
             self.add(st, "apply_mask", run_mask)

@@ -103,7 +103,9 @@ class Evaluater:
                     continue
                 data = self._to(data, device)
                 data["target"] = self._to(target, device)
-                token = self.model.prepare(data) if hasattr(self.model, "prepare") else None    # pose algebra while the device is busy
+                # pose algebra while the device is busy (not with dynamic batching: a coalesced launch forms the matrices of its group)
+                batching = getattr(self.model, "_batch_keyframes", 1) > 1
+                token = self.model.prepare(data) if (hasattr(self.model, "prepare") and not batching) else None
                 if len(pending) >= self.in_flight:                  # the slot the next submit reuses: reduce its result first
                     collect()
                 handle = self.model.submit(data, token) if token is not None else self.model.submit(data)

@@ -13,6 +13,7 @@ import ctypes
 import threading
 import time
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -232,12 +233,23 @@ def host_geometry_reference_form(keyframe_intrinsics, keyframe_pose, intrinsics,
     return kinv, proj
 
 
+HOST_SPIN_SECONDS = 0.004       # longest busy-poll of _host_wait before it falls back to a sleeping wait
+
+
 def _host_wait(event):
-    """Block the host until `event` has happened - by polling.  hipEventSynchronize polls only for a while and then sleeps, and a
-    sleeping wait wakes up late (measured on MI355X / ROCm 7: sequential forwards of 2 ms each went to 3.2 ms once the wait inside
-    submit() crossed ~2 ms).  These waits are short or end with work for the host, so it keeps polling; the GIL is released between
-    polls (nn.DataParallel drives replicas from threads)."""
+    """Block the host until `event` has happened - by polling, for a bounded time.  hipEventSynchronize polls only for a while and
+    then sleeps, and a sleeping wait wakes up late (measured on MI355X / ROCm 7: sequential forwards of 2 ms each went to 3.2 ms
+    once the wait inside submit() crossed ~2 ms).  The waits of a keyframe stream are short (a c2 keyframe takes ~1.5 ms) and end
+    with work for the host, so the host polls - the GIL is released between polls (nn.DataParallel drives replicas from threads) -
+    but only for HOST_SPIN_SECONDS: behind that (batched workloads, a stalled device, eight ranks of a node each spinning a core
+    for nothing) it hands the wait to hipEventSynchronize, whose late wake-up no longer matters at that length."""
+    if event.query():
+        return
+    deadline = time.perf_counter() + HOST_SPIN_SECONDS
     while not event.query():
+        if time.perf_counter() > deadline:
+            event.synchronize()
+            return
         time.sleep(0)
 
 
@@ -257,7 +269,7 @@ class MonoRecModel(nn.Module):
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False):
+                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -307,11 +319,18 @@ class MonoRecModel(nn.Module):
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
         # hi/lo bf16 pairs, three bf16 MFMAs per product - fp32-class accuracy, 4e-6 in CPU emulation)
         self._bf16 = 2 if hip_bf16x3 else (1 if hip_bf16 else 0)
+        # which reduced-multiply convolution forms the measured table may select (engine.Plan conv_forms; INTEGRATION.md "trained
+        # checkpoints"): False = all of it; "f2" = F(2,.) forms only; True = none - every convolution is the direct MFMA kernel's
+        # exact fmaf chain (the reference's arithmetic up to summation order)
+        if hip_exact_convs not in (False, True, "f2"):
+            raise ValueError("hip_exact_convs must be False, True or 'f2'")
+        self._conv_forms = {False: "table", True: "direct", "f2": "f2"}[hip_exact_convs]
         self._slot_counter = [0]         # mutable on purpose: nn.DataParallel replicas (shallow copies made per forward) share it
         self._plans = {}
         self._graphs = {}
         self._streams = {}
         self._consts = {}
+        self._const_slab = {}
         self._packed_state = None
         self._prep_pinned = {}           # (device, matrices, batch) -> (pinned host buffer, stream) of prepare()'s gather launch
         self._lock = threading.RLock()   # one enqueue at a time per model object (nn.DataParallel calls replicas from threads)
@@ -369,6 +388,7 @@ class MonoRecModel(nn.Module):
         self._plans = {}
         self._graphs = {}
         self._consts = {}
+        self._const_slab = {}
         self._packed_state = None
 
     def _weights_snapshot(self):
@@ -391,7 +411,7 @@ class MonoRecModel(nn.Module):
 
     def __getstate__(self):          # copy.deepcopy / pickle: device plans, streams, graphs and the lock are rebuilt on demand
         state = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
-        for k in ("_plans", "_graphs", "_streams", "_consts", "_prep_pinned"):
+        for k in ("_plans", "_graphs", "_streams", "_consts", "_const_slab", "_prep_pinned"):
             state[k] = {}
         state["_packed_state"] = None
         state["_open_group"] = None
@@ -420,7 +440,7 @@ class MonoRecModel(nn.Module):
                         use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
                         no_cv=self.no_cv, mask_use_cv=self.mask_use_cv or self.simple_mask,
                         mask_use_feats=self.mask_use_feats or self.simple_mask, simple_mask=self.simple_mask,
-                        cv_patch_size=self.cv_patch_size)
+                        cv_patch_size=self.cv_patch_size, conv_forms=self._conv_forms)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
@@ -429,6 +449,8 @@ class MonoRecModel(nn.Module):
             plan.host_time_at = 0
             plan.enqueued = collections.deque()   # completion events of this slot's forwards the host has not waited for yet
             plan.consumers = []                   # streams that were handed results of this slot since its last enqueue
+            plan.handles = []                     # weak references to the submit() handles whose outputs are views of this slot
+            plan.own_layout = None                # forward(): arena layout of the caller-owned outputs (see _bind_owned_outputs)
             self._plans[key] = plan
         return key, plan
 
@@ -449,15 +471,26 @@ class MonoRecModel(nn.Module):
             # stream order makes consecutive forward() calls sequential whatever the number of slots, so they all use slot 0: one
             # set of resident buffers and packed weights stays hot (alternating two slots measured 2.1 -> 2.8 ms per forward)
             self._flush_open_group()
-            out = self._submit_one(data_dict, slot=0).result()
-            with torch.cuda.device(out["keyframe"].device):
-                self._own_outputs(out)
+            handle = self._forward_handle(data_dict)
+            out = handle.result()
+            if not handle.owned:                              # plan variants with constant content in their output buffers, hipGraph
+                with torch.cuda.device(out["keyframe"].device):
+                    self._own_outputs(out)
         if self.pretrain_mode == 2:                           # :723-727, same aliasing as the reference
             out["result"] = out["cv_mask"]
         else:
             out["result"] = out["predicted_inverse_depths"][0]
             out["mask"] = out["cv_mask"]
         return out
+
+    def _forward_handle(self, data_dict):
+        """Enqueue forward()'s keyframe: checks, host wait for the inputs, then the launches - with the outputs bound to memory the
+        caller will own where the plan allows it (`handle.owned`)."""
+        data_dict.pop(_METRIC_CACHE_KEY, None)
+        prep = self._parse(data_dict)                         # checks only; the pose algebra runs behind the encoder's launches
+        with torch.cuda.device(prep.device):
+            self._wait_inputs(prep.device)
+            return self._submit_locked(data_dict, prep, slot=self._forward_slot(prep), own=True)
 
     def _own_outputs(self, out):
         """Replace the output views of `out` (resident slot buffers) by tensors the caller owns: one allocation, ONE copy launch
@@ -524,6 +557,14 @@ class MonoRecModel(nn.Module):
 
         so that ~0.1-0.2 ms of host work per keyframe overlap the device instead of preceding the first launch of the keyframe.
         Returns a token for `submit(data_dict, token)`; the inputs must not change in between."""
+        prep = self._parse(data_dict)
+        with self._lock, torch.cuda.device(prep.device):
+            self._wait_inputs(prep.device)
+            self._geometry(prep)
+        return prep
+
+    def _parse(self, data_dict):
+        """The checks of a request and its tensors, without touching the device: a `_Prepared` whose matrices are still to be formed."""
         if self.training:
             raise NotImplementedError("monorec_amd.MonoRecModel is inference-only: call .eval() first")
         keyframe = data_dict["keyframe"]                      # missing keys -> KeyError, like the reference
@@ -554,45 +595,69 @@ class MonoRecModel(nn.Module):
             raise NotImplementedError("cv_depths with hip_graph=True: the captured launch has no per-pixel depth pointer")
         b, c, h, w = keyframe.shape
         nf = len(frames)
-        device = keyframe.device
         mat_list = [kf_intrinsics, kf_pose] + intrinsics + poses
-        with self._lock, torch.cuda.device(device):
-            caller = torch.cuda.current_stream(device)
-            # The HOST waits for the caller's stream to reach this point: the inputs exist now, and nothing below (here or in submit)
-            # is enqueued behind an unsatisfied stream dependency - a launch parked in its hardware queue as a blocked barrier packet
-            # slows the OTHER queues down (measured, round 3: sequential forwards 2.1 -> 3.2 ms with the next forward's encoder
-            # pre-enqueued behind such a wait; a request stream enqueued one forward ahead 5-7 % slower).
-            inputs_ready = torch.cuda.Event()
-            inputs_ready.record(caller)
-            _host_wait(inputs_ready)
-            if all(not m.is_cuda for m in mat_list):
-                # matrices on the host (a loader that keeps the 4x4s on the CPU, kitti.KittiOdometryDataset): used where they are
-                hm = [m.detach().float() for m in mat_list]
-            else:
-                # matrices on the device: one gather launch into device-writable pinned host memory, awaited at once
-                dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
-                      m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
-                if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
-                    ev = torch.cuda.Event()
-                    ev.record(caller)
-                    _host_wait(ev)
-                pk = (str(device), len(dm), b)
-                pinned = self._prep_pinned.get(pk)
-                if pinned is None:
-                    pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), torch.cuda.Stream(device))
-                hm, gs = pinned
-                ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
-                _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")
-                done = torch.cuda.Event()
-                done.record(gs)
-                for m in dm:
-                    m.record_stream(gs)
-                _host_wait(done)
-            # host 4x4 algebra with the same ATen CPU operators as the reference: bit-identical matrices (~0.1 ms)
-            kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
-            if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
-                kinv, proj = self._geometry_override
-        return _Prepared(data_dict, keyframe, frames, cv_depths, (b, h, w, nf), device, kinv.reshape(-1).clone(), proj.reshape(-1).clone())
+        for m in mat_list:                                    # the gather launch below reads 16 * b floats per matrix: no silent overrun
+            if tuple(m.shape) != (b, 4, 4):
+                raise ValueError(f"pose / intrinsics matrices must be ({b}, 4, 4) like the keyframe batch, got {tuple(m.shape)}")
+        return _Prepared(data_dict, keyframe, frames, cv_depths, (b, h, w, nf), keyframe.device, None, None, mat_list)
+
+    def _wait_inputs(self, device):
+        """The HOST waits for the caller's stream to reach this point: the inputs exist now, and nothing afterwards (here or in
+        submit) is enqueued behind an unsatisfied stream dependency - a launch parked in its hardware queue as a blocked barrier
+        packet slows the OTHER queues down (measured, round 3: sequential forwards 2.1 -> 3.2 ms with the next forward's encoder
+        pre-enqueued behind such a wait; a request stream enqueued one forward ahead 5-7 % slower)."""
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(torch.cuda.current_stream(device))
+        _host_wait(inputs_ready)
+
+    def _geometry(self, prep):
+        """kinv / proj of a parsed request (monorec_model.py:171,198,207; layers.py:65) into the token.  Inputs must be ready."""
+        device, mat_list = prep.device, prep.mats
+        b, _, _, nf = prep.shape
+        caller = torch.cuda.current_stream(device)
+        if all(not m.is_cuda for m in mat_list):
+            # matrices on the host (a loader that keeps the 4x4s on the CPU, kitti.KittiOdometryDataset): used where they are
+            hm = [m.detach().float() for m in mat_list]
+        else:
+            # matrices on the device: one gather launch into device-writable pinned host memory, awaited at once
+            dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
+                  m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
+            if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
+                ev = torch.cuda.Event()
+                ev.record(caller)
+                _host_wait(ev)
+            pk = (str(device), len(dm), b)
+            pinned = self._prep_pinned.get(pk)
+            if pinned is None:
+                pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), torch.cuda.Stream(device))
+            hm, gs = pinned
+            ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
+            _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")
+            done = torch.cuda.Event()
+            done.record(gs)
+            for m in dm:
+                m.record_stream(gs)
+            _host_wait(done)
+        # host 4x4 algebra with the same ATen CPU operators as the reference: bit-identical matrices (~0.1 ms)
+        kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
+        if self._geometry_override is not None:           # test seam: matrices formed on another host (tests/golden geom.*)
+            kinv, proj = self._geometry_override
+        prep.kinv, prep.proj = kinv.reshape(-1).clone(), proj.reshape(-1).clone()
+        return prep
+
+    def _forward_slot(self, prep):
+        """Slot of a forward() call: 0 - one set of resident buffers and packed weights stays hot -, unless its plan hands out copies of
+        its resident output buffers (no rebinding) and a submit() handle of that slot has not been collected yet: the copies' source
+        would be that handle's outputs.  Then the next slot without one."""
+        b, h, w, nf = prep.shape
+        for slot in range(self._in_flight):
+            plan = self._plans.get((slot, b, h, w, nf, self.cv_depth_steps, str(prep.device)))
+            if plan is None or (plan.outputs_rebindable and not self._hip_graph):
+                return slot
+            if not any(hd() is not None and not hd().collected for hd in plan.handles):
+                return slot
+        raise RuntimeError("forward(): every in-flight slot holds a submit() whose result has not been taken; collect one "
+                           "(handle.result() / .synchronize()) first, or construct the model with a larger hip_in_flight")
 
     def _submit_one(self, data_dict, prepared=None, slot=None):
         """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
@@ -700,10 +765,13 @@ class MonoRecModel(nn.Module):
                 m["result"] = m["predicted_inverse_depths"][0]
                 m["mask"] = m["cv_mask"]
 
-    def _submit_locked(self, data_dict, prepared, slot=None):
+    def _submit_locked(self, data_dict, prepared, slot=None, own=False):
+        """`own`: forward() - the outputs are produced in memory the caller owns (two arenas allocated here, every launch that writes
+        or reads an output buffer re-targeted by Plan.rebind_outputs) instead of the slot's resident buffers; a token without
+        matrices gets them formed behind the encoder's launches (the device starts on the pose-independent stage while the host
+        does the pose algebra - the caller of forward() has nothing else to overlap it with)."""
         keyframe, frames, cv_depths, device = prepared.keyframe, prepared.frames, prepared.cv_depths, prepared.device
         b, h, w, nf = prepared.shape
-        geo = (prepared.kinv, prepared.proj)
         # the three constants of :675-677: built once per device (a `new_tensor` from a Python list is a blocking pageable H2D copy on
         # the caller's stream, three of them per keyframe); forward() hands out copies like every other output
         consts = self._consts.get(str(device))
@@ -713,6 +781,7 @@ class MonoRecModel(nn.Module):
             slab.view(torch.int32)[2] = int(self.cv_depth_steps)
             consts = (slab[0:1], slab[1:2], slab.view(torch.int32)[2:3])
             self._consts[str(device)] = consts
+            self._const_slab[str(device)] = slab
         data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = consts
 
         if slot is None:
@@ -729,11 +798,16 @@ class MonoRecModel(nn.Module):
         # The launches below overwrite the slot's previous outputs: the host waits for whatever the caller's stream - and any other
         # stream that took results of this slot through `.result()` - has been given to do with them so far (host waits, not stream
         # waits: no blocked packets, see prepare(); an idle stream costs a few microseconds).
-        for cs in [caller] + [c for c in plan.consumers if c != caller]:
+        for cs in ([] if own else [caller]) + [c for c in plan.consumers if c != caller]:   # (forward() has just waited for its caller's stream)
             ev = torch.cuda.Event()
             ev.record(cs)
             _host_wait(ev)
         plan.consumers.clear()
+        owned = None
+        if own and plan.outputs_rebindable and not self._hip_graph:
+            owned = self._bind_owned_outputs(plan, device, (main, enc))
+        elif not self._hip_graph:
+            plan.rebind_outputs(None)
         with torch.cuda.stream(main):
             # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
             # captured launches keep their pointers - goes through the slot's resident buffers
@@ -777,8 +851,13 @@ class MonoRecModel(nn.Module):
                     plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
                 self._run_stage(key, plan, "cv", main)
 
-            cv_stage(*geo)                 # head of the longest chain (cost volume -> mask encoder -> mask decoder -> depth): first
-            enc_done, tail_done = encoder_stage()
+            if prepared.kinv is None:      # forward(): encoder launches first, the pose algebra while the device runs them
+                enc_done, tail_done = encoder_stage()
+                self._geometry(prepared)
+                cv_stage(prepared.kinv, prepared.proj)
+            else:
+                cv_stage(prepared.kinv, prepared.proj)   # head of the longest chain (cost volume -> mask encoder -> mask decoder -> depth): first
+                enc_done, tail_done = encoder_stage()
             # join: mask decoder -> depth
             main.wait_event(enc_done)
             self._run_stage(key, plan, "main", main)
@@ -794,6 +873,16 @@ class MonoRecModel(nn.Module):
         plan.host_time[i] = time.time() - start_time
         data_dict["cv_module_time"] = plan.host_time[i:i + 1].to(device, non_blocking=True)
 
+        if owned is not None:
+            data_dict["cost_volume"] = owned["cost_volume"]
+            data_dict["single_frame_cvs"] = [owned["sfcv"][f] for f in range(nf)]
+            data_dict["image_features"] = [owned[f"feat{i}"] for i in range(5)]
+            data_dict["cv_mask"] = owned["cv_mask"]
+            data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = owned["consts"]
+            data_dict["predicted_inverse_depths"] = [owned[f"pred{i}"] for i in range(4)]
+            data_dict["result"] = data_dict["predicted_inverse_depths"][0]
+            data_dict["mask"] = data_dict["cv_mask"]
+            return _Pending(data_dict, done, device, None, owned=True)
         data_dict["cost_volume"] = plan.buf["cost_volume"]
         data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
         data_dict["image_features"] = list(plan.feats)
@@ -804,7 +893,46 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = list(plan.preds)
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-        return _Pending(data_dict, done, device, plan.consumers)
+        handle = _Pending(data_dict, done, device, plan.consumers)
+        if not own:                                           # forward() collects its handle before anyone else can see the slot
+            plan.handles = [hd for hd in plan.handles if hd() is not None and not hd().collected]
+            plan.handles.append(weakref.ref(handle))
+        return handle
+
+    def _bind_owned_outputs(self, plan, device, streams):
+        """forward(): allocate the memory the caller will own and re-target the plan's launches at it.  Two arenas - the maps a caller
+        typically keeps (`cv_mask`, the four depth scales, the three constants of :675-677: ~1.4 MB at c2) and the bulky ones (fused and
+        single-frame volumes, image features: ~62 MB) - so that holding on to `result` does not pin the volumes.  Returns
+        name -> tensor views with the resident buffers' shapes."""
+        lay = plan.own_layout
+        if lay is None:
+            lay = {"small": [], "big": [], "size": {"small": 256, "big": 0}}      # the first 256 bytes of the small arena: the constants
+            for name in plan.bound:
+                t = plan.buf[name]
+                kind = "small" if (name == "cv_mask" or name.startswith("pred")) else "big"
+                lay[kind].append((name, lay["size"][kind], tuple(t.shape)))
+                lay["size"][kind] += (t.numel() * 4 + 255) // 256 * 256
+            plan.own_layout = lay
+        small = torch.empty(lay["size"]["small"], dtype=torch.uint8, device=device)
+        big = torch.empty(lay["size"]["big"], dtype=torch.uint8, device=device)
+        for st in streams:                                    # the arenas are written on the slot's streams, not the allocating one
+            small.record_stream(st)
+            big.record_stream(st)
+        out, bases = {}, {}
+        for kind, arena in (("small", small), ("big", big)):
+            base = arena.data_ptr()
+            for name, off, shape in lay[kind]:
+                n = 4
+                for d in shape:
+                    n *= d
+                out[name] = arena[off:off + n].view(torch.float32).view(shape)
+                bases[name] = base + off
+        plan.rebind_outputs(bases)
+        # the three constants: copied from the per-device slab by the caller's stream (16 bytes; ordered like every other output)
+        head = small[0:16]
+        head.view(torch.float32).copy_(self._const_slab[str(device)], non_blocking=True)
+        out["consts"] = (head[0:4].view(torch.float32), head[4:8].view(torch.float32), head[8:12].view(torch.int32))
+        return out
 
     def _run_stage(self, key, plan, stage, stream):
         """Run one stage of the plan on `stream`: eagerly, or (hip_graph) as a captured hipGraph replay."""
@@ -834,9 +962,9 @@ class MonoRecModel(nn.Module):
 class _Prepared:
     """Token of MonoRecModel.prepare(): the parsed inputs of one forward and its projection matrices."""
 
-    def __init__(self, data, keyframe, frames, cv_depths, shape, device, kinv, proj):
+    def __init__(self, data, keyframe, frames, cv_depths, shape, device, kinv, proj, mats=None):
         self.data, self.keyframe, self.frames, self.cv_depths = data, keyframe, frames, cv_depths
-        self.shape, self.device, self.kinv, self.proj = shape, device, kinv, proj
+        self.shape, self.device, self.kinv, self.proj, self.mats = shape, device, kinv, proj, mats
 
 
 class _Group:
@@ -872,8 +1000,10 @@ class _GroupHandle:
 class _Pending:
     """Handle of an enqueued forward (MonoRecModel.submit)."""
 
-    def __init__(self, data_dict, done, device, consumers=None):
+    def __init__(self, data_dict, done, device, consumers=None, owned=False):
         self._data, self._done, self._device, self._consumers = data_dict, done, device, consumers
+        self.collected = False      # result() / synchronize() taken: forward() may reuse the slot's resident output buffers as a copy source
+        self.owned = owned          # the outputs already live in memory the caller owns (forward())
 
     def result(self):
         """Order the caller's current stream after the forward and return the output dict.  The stream is remembered: the submit
@@ -882,12 +1012,14 @@ class _Pending:
         cs.wait_event(self._done)
         if self._consumers is not None and cs not in self._consumers:
             self._consumers.append(cs)
+        self.collected = True
         return self._data
 
     def synchronize(self):
         """Wait on the HOST for the forward and return the output dict: the caller's stream needs no wait packet then (a blocked
         one slows the other hardware queues down) - the way to collect results in a pipelined loop."""
         _host_wait(self._done)
+        self.collected = True
         return self._data
 
 

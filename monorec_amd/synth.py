@@ -100,7 +100,10 @@ def clone_batch(batch, device=None):
     return {k: cv(v) for k, v in batch.items()}
 
 
-def seeded_state_dict(template_state_dict, seed=0):
+WEIGHT_FAMILIES = ("he", "harsh")
+
+
+def seeded_state_dict(template_state_dict, seed=0, family="he"):
     """Deterministic, key-addressed weights for any state dict with the MonoRec key set.
 
     Independent of module construction order (unlike torch.manual_seed + default init),
@@ -109,9 +112,23 @@ def seeded_state_dict(template_state_dict, seed=0):
     activations O(1) through ~20 layers so parity tolerances stay meaningful - PyTorch's
     default bound shrinks the signal by sqrt(3) per layer); biases ~ U(+-1/sqrt(fan_in));
     BatchNorm gets non-trivial affine/statistics so that BN folding is actually exercised.
+
+    family="harsh" (the reduced-multiply kernels were only ever checked on well-conditioned weights) keeps the
+    layer-average gain of "he" - so the heads stay out of saturation and the 1e-4 bar stays meaningful - but makes every layer
+    ill-conditioned the way a trained checkpoint can be:
+      * output channels scaled log-uniformly over [1/3, 3] (a 9x range inside one layer; RMS 1),
+      * every 8th filter of a layer with >= 3 taps along an axis is NEAR-CANCELLING: alternating-sign taps of 3x the He bound whose
+        sum is ~2 % of their magnitude (on the smooth activations of this net the products cancel - the case in which the larger
+        Cook-Toom / Winograd transforms lose digits, model/layers.py:289-314),
+      * BatchNorm running_var log-uniform down to 1e-3 on every 8th channel (folded scale up to ~30x its neighbours'), gamma rescaled
+        so that the RMS folded scale of the layer is unchanged.
     """
+    if family not in WEIGHT_FAMILIES:
+        raise ValueError(f"unknown weight family {family!r}")
+    harsh = family == "harsh"
     out = {}
-    for idx, key in enumerate(sorted(template_state_dict.keys())):
+    keys = sorted(template_state_dict.keys())
+    for idx, key in enumerate(keys):
         ref = template_state_dict[key]
         gen = torch.Generator().manual_seed(1000003 * (seed + 1) + idx)
         shape = tuple(ref.shape)
@@ -119,7 +136,12 @@ def seeded_state_dict(template_state_dict, seed=0):
             out[key] = torch.zeros(shape, dtype=ref.dtype)
             continue
         if key.endswith("running_var"):
-            out[key] = 0.5 + torch.rand(shape, generator=gen)
+            v = 0.5 + torch.rand(shape, generator=gen)
+            if harsh:
+                tiny = torch.exp(math.log(1e-3) + (math.log(0.5) - math.log(1e-3)) * torch.rand(shape, generator=gen))
+                sel = (torch.arange(shape[0]) % 8) == 5
+                v = torch.where(sel, tiny, v)
+            out[key] = v
             continue
         if key.endswith("running_mean"):
             out[key] = 0.4 * (torch.rand(shape, generator=gen) - 0.5)
@@ -133,7 +155,8 @@ def seeded_state_dict(template_state_dict, seed=0):
             out[key] = 0.4 * (torch.rand(shape, generator=gen) - 0.5)
             continue
         if len(shape) >= 2:
-            if "conv2d_t" in key:  # ConvTranspose2d weight is (Cin, Cout, kh, kw)
+            transposed = "conv2d_t" in key
+            if transposed:  # ConvTranspose2d weight is (Cin, Cout, kh, kw)
                 fan_in = shape[0] * 4  # k4/s2: every output pixel sees 2x2 taps of each input channel
             else:
                 fan_in = 1
@@ -142,10 +165,47 @@ def seeded_state_dict(template_state_dict, seed=0):
             bound = math.sqrt(6.0 / fan_in)
         else:
             bound = 0.05
-        if ".predictors." in key or ".classifier." in key:
+        head = ".predictors." in key or ".classifier." in key
+        if head:
             bound *= 0.5  # keep tanh / sigmoid heads out of saturation
-        out[key] = ((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(torch.float32)
+        w = ((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(torch.float32)
+        if harsh and len(shape) == 4 and not head:
+            w = _harshen(w, bound, 1 if transposed else 0, gen)
+        out[key] = w
+    if harsh:      # gamma rescaled so that the RMS of the folded scale gamma / sqrt(var + eps) is what it would be with the "he" variances
+        for key in keys:
+            if key.endswith("running_var") and key[:-len("running_var")] + "weight" in out:
+                gkey = key[:-len("running_var")] + "weight"
+                gen = torch.Generator().manual_seed(1000003 * (seed + 1) + keys.index(key))
+                v_he = 0.5 + torch.rand(tuple(out[key].shape), generator=gen)
+                g = out[gkey].double()
+                rms = lambda var: float(torch.sqrt(torch.mean((g / torch.sqrt(var.double() + 1e-5)) ** 2)))
+                out[gkey] = (g * (rms(v_he) / rms(out[key]))).float()
     return out
+
+
+def _harshen(w, bound, out_dim, gen):
+    """The ill-conditioned variant of one conv weight (see seeded_state_dict): `out_dim` = dimension of the output channels."""
+    w = w.clone()
+    cout = w.shape[out_dim]
+    kh, kw = w.shape[2], w.shape[3]
+    scale = torch.exp((torch.rand(cout, generator=gen) * 2 - 1) * math.log(3.0))
+    if max(kh, kw) >= 3:
+        sign = (1 - 2 * ((torch.arange(kh).view(kh, 1) + torch.arange(kw).view(1, kw)) % 2)).to(torch.float32)     # checkerboard / alternating
+        cin = w.shape[1 - out_dim]
+        amp = 3.0 * bound * (0.5 + 0.5 * torch.rand(cin, generator=gen)) * (1 - 2 * (torch.rand(cin, generator=gen) < 0.5).float())   # sign per input channel
+        for c in range(3, cout, 8):
+            noise = 1.0 + 0.02 * (torch.rand(cin, kh, kw, generator=gen) * 2 - 1)
+            f = amp.view(cin, 1, 1) * sign.view(1, kh, kw) * noise
+            if out_dim == 0:
+                w[c] = f
+            else:
+                w[:, c] = f
+    view = [1, 1, 1, 1]
+    view[out_dim] = cout
+    w = w * scale.view(view)
+    # layer-average gain of the He family: RMS over the whole tensor back to bound / sqrt(3)
+    return (w * ((bound / math.sqrt(3.0)) / float(torch.sqrt(torch.mean(w.double() ** 2))))).to(torch.float32)
 
 
 def make_pointcloud_case(batch=1, height=64, width=96, seed=3, num_masks=5):

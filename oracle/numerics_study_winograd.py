@@ -147,13 +147,14 @@ def main(argv=None):
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default=None, help="substring of the experiment name")
+    ap.add_argument("--family", default="he", choices=synth.WEIGHT_FAMILIES, help="weight family of synth.seeded_state_dict")
     args = ap.parse_args(argv)
     torch.manual_seed(0)
     batch = synth.make_batch(1, args.height, args.width, 2, seed=1)
     from monorec_amd.model import MonoRecModel   # state-dict layout only (CPU construction, no launch)
-    sd = synth.seeded_state_dict(MonoRecModel(cv_depth_steps=args.depths).state_dict(), 0)
+    sd = synth.seeded_state_dict(MonoRecModel(cv_depth_steps=args.depths).state_dict(), 0, args.family)
     base = oracle.forward(sd, synth.clone_batch(batch), cv_depth_steps=args.depths)
-    report = {"shape": [args.height, args.width, args.depths], "bar": 1e-4, "experiments": {}}
+    report = {"shape": [args.height, args.width, args.depths], "bar": 1e-4, "family": args.family, "experiments": {}}
     for name, rule in rules().items():
         if args.only and args.only not in name:
             continue

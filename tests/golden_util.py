@@ -10,9 +10,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 class Golden:
     def __init__(self, name):
         self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
-        b, h, w, nf, d, seed, hard, full = [int(v) for v in self.z["meta"]]
+        meta = [int(v) for v in self.z["meta"]]
+        b, h, w, nf, d, seed, hard, full = meta[:8]
         self.batch, self.h, self.w, self.frames, self.depths = b, h, w, nf, d
         self.seed, self.hard_pose, self.full_model = seed, bool(hard), bool(full)
+        from monorec_amd import synth
+        self.family = synth.WEIGHT_FAMILIES[meta[8]] if len(meta) > 8 else "he"      # weight family of synth.seeded_state_dict
 
     def names(self):
         return sorted({k.rsplit(".", 1)[0] for k in self.z.files if k not in ("meta", "metrics") and not k.startswith("input.")})

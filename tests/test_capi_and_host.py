@@ -569,6 +569,8 @@ def test_marching_cost_volume_kernel_codegen():
 
 
 class _FakePending:
+    owned = False          # outputs are views of "resident" tensors: forward() copies them
+
     def __init__(self, data):
         self._data = data
 
@@ -649,11 +651,13 @@ def test_dynamic_batching_failed_launch_reaches_every_member_and_bad_requests_fa
 
 
 def test_forward_returns_owned_outputs_with_the_reference_aliasing():
-    """forward() = submit().result() + one copy of every output tensor (monorec_model.py:713-727 allocates its outputs), with
-    `result is predicted_inverse_depths[0]` and `mask is cv_mask` like the reference (:723-727)."""
+    """forward() on a plan whose outputs cannot be bound to caller-owned memory (handle.owned False: hipGraph replay, the option
+    variants with constant buffers) = the enqueued forward + one copy of every output tensor (monorec_model.py:713-727 allocates its
+    outputs), with `result is predicted_inverse_depths[0]` and `mask is cv_mask` like the reference (:723-727)."""
     m = MonoRecModel(cv_depth_steps=8)
     _stub_submit_one(m, [])
     m.submit = lambda d: m._submit_one(d)
+    m._forward_handle = lambda d: m._submit_one(d)
     import contextlib
     orig = torch.cuda.device
     torch.cuda.device = lambda dev: contextlib.nullcontext()    # no HIP device in this test
@@ -917,3 +921,94 @@ def test_host_geometry_shortcuts_are_bit_identical_to_the_reference_form():
 def test_host_geometry_shortcuts_on_the_gpu_box_host(hip_lib):
     """The same statement on the GPU box's host CPU (another LAPACK / MKL code path than the build container's)."""
     _check_host_geometry_against_the_reference_form()
+
+
+def test_output_relocation_table_of_a_plan(hip_lib):
+    """Plan.rebind_outputs (forward(): outputs produced in caller-owned memory): every descriptor pointer into an output buffer
+    moves with its buffer's new base, byte offsets kept (the mask encoder reads frame f of `sfcv` at f * B * D * H * W), closures
+    follow through Plan.ref, and rebinding back restores every pointer.  The plan is built on the CPU: building launches nothing."""
+    from monorec_amd import engine
+    m = MonoRecModel(cv_depth_steps=8)
+    sd = synth.seeded_state_dict(m.state_dict(), 0)
+    plan = engine.Plan(sd, 2, 64, 96, 2, 8, (0.33, 0.0025), "cpu")
+    assert plan.outputs_rebindable and set(plan.bound) == set(engine.OUTPUT_BUFFERS)
+
+    def slots():
+        out = []
+        for obj, field, idx, name, off in plan._relocs:
+            out.append(obj[idx] if field is None else (getattr(obj, field) if idx is None else getattr(obj, field)[idx]))
+        return out
+    names = [r[3] for r in plan._relocs]
+    # writers and readers: conv1 writes feat0, the mask / depth decoders read it; the depth encoder reads the fused volume; the four
+    # heads write the predictions; the cost-volume launch gets one pointer per frame of the single-frame volumes
+    assert names.count("feat0") >= 3 and names.count("cost_volume") >= 1 and all(names.count(f"pred{i}") == 1 for i in range(4))
+    assert names.count("sfcv") == 1 + 2
+    resident = slots()
+    bases = {n: 0x7000000000 + i * 0x10000000 for i, n in enumerate(plan.bound)}
+    ref_cv, ref_kf = plan.ref(plan.buf["cost_volume"][1]), plan.ref(plan.buf["keyframe"])
+    plan.rebind_outputs(bases)
+    for (obj, field, idx, name, off), was, now in zip(plan._relocs, resident, slots()):
+        assert was == plan._resident[name] + off and now == bases[name] + off
+    assert ref_cv.ptr() == bases["cost_volume"] + 8 * 64 * 96 * 4 and ref_kf.ptr() == plan.buf["keyframe"].data_ptr()
+    frame_offsets = sorted(off for _, field, _, name, off in plan._relocs if name == "sfcv" and field is None)
+    assert frame_offsets == [0, 2 * 8 * 64 * 96 * 4]
+    plan.rebind_outputs({"pred0": bases["pred0"]})            # the others fall back to the resident buffers
+    assert plan.bound["pred0"] == bases["pred0"] and plan.bound["cost_volume"] == plan._resident["cost_volume"]
+    plan.rebind_outputs(None)
+    assert slots() == resident and plan.bound == plan._resident
+    # option variants that keep constant content in an output buffer are not rebindable: forward() copies out of them instead
+    m1 = MonoRecModel(cv_depth_steps=8, pretrain_mode=1)
+    p1 = engine.Plan(synth.seeded_state_dict(m1.state_dict(), 0), 1, 64, 96, 2, 8, (0.33, 0.0025), "cpu", pretrain_mode=1)
+    p2 = engine.Plan(sd, 1, 64, 96, 2, 8, (0.33, 0.0025), "cpu", no_cv=True)
+    assert not p1.outputs_rebindable and not p2.outputs_rebindable
+
+
+def test_host_wait_polls_for_a_bounded_time_then_sleeps():
+    from monorec_amd import model as mm
+
+    class Ev:
+        def __init__(self, ready_after):
+            self.n, self.ready_after, self.synced = 0, ready_after, False
+
+        def query(self):
+            self.n += 1
+            return self.n > self.ready_after
+
+        def synchronize(self):
+            self.synced = True
+    e = Ev(0)
+    mm._host_wait(e)
+    assert e.n == 1 and not e.synced                         # already done: one query
+    e = Ev(50)
+    mm._host_wait(e)
+    assert e.n == 51 and not e.synced                        # short wait: polled
+    old = mm.HOST_SPIN_SECONDS
+    mm.HOST_SPIN_SECONDS = 0.0
+    try:
+        e = Ev(10 ** 9)
+        mm._host_wait(e)
+        assert e.synced and e.n <= 3                         # beyond the bound: handed to hipEventSynchronize
+    finally:
+        mm.HOST_SPIN_SECONDS = old
+
+
+def test_forward_slot_avoids_uncollected_handles_of_copying_plans():
+    """forward() keeps slot 0 unless the plan there copies out of its resident buffers AND a submit() handle of that slot is still
+    uncollected."""
+    import types
+    import weakref
+    from monorec_amd.model import _Pending
+    m = MonoRecModel(cv_depth_steps=8, hip_in_flight=2)
+    prep = types.SimpleNamespace(shape=(1, 64, 96, 2), device="cuda:0")
+    assert m._forward_slot(prep) == 0                        # no plan yet
+    key = lambda slot: (slot, 1, 64, 96, 2, 8, "cuda:0")
+    h = _Pending({}, None, "cuda:0")
+    m._plans[key(0)] = types.SimpleNamespace(outputs_rebindable=True, handles=[weakref.ref(h)])
+    assert m._forward_slot(prep) == 0                        # outputs go to caller-owned memory: the handle's views are safe
+    m._plans[key(0)].outputs_rebindable = False
+    assert m._forward_slot(prep) == 1
+    m._plans[key(1)] = types.SimpleNamespace(outputs_rebindable=False, handles=[weakref.ref(h)])
+    with pytest.raises(RuntimeError, match="result has not been taken"):
+        m._forward_slot(prep)
+    h.collected = True
+    assert m._forward_slot(prep) == 0

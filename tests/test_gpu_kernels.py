@@ -994,8 +994,9 @@ COOKTOOM_CASES = [
     ((3,), 7, (9, 4), 1, ACT_RELU, 1),
     ((128,), 128, (18, 68), 1, ACT_LEAKY_RELU, 1),                    # eight cout groups of 16, a ragged second tile column / row
 ]
-COOKTOOM_TOL = {(4, 3): 1e-5, (2, 7): 1e-5, (4, 7): 1.5e-4}          # x max(1, |ref|); the fp32 emulation of the forms (oracle/numerics_study_winograd.py)
-                                                                      # measures 2e-6 / 2e-6 / 3e-5 on these cases
+COOKTOOM_TOL = {(4, 3): 1e-5, (2, 7): 1e-5, (4, 7): 6e-5}            # x max(1, |ref|); the fp32 emulation of the forms (oracle/numerics_study_winograd.py)
+                                                                      # measures 2e-6 / 2e-6 / 3e-5 on these cases: every per-layer bar is
+                                                                      # below the 1e-4 depth bar of the model (1.5e-4 was not)
 
 
 @pytest.mark.parametrize("axis", [0, 1])

@@ -25,11 +25,12 @@ def test_pinning_report_says_oracle_equals_reference():
         assert max(info["oracle_vs_reference_maxabs"].values()) == 0.0, case
 
 
-@pytest.mark.parametrize("case", ["small", "small_hard_pose", "d64_f4"])
+@pytest.mark.parametrize("case", ["small", "small_hard_pose", "d64_f4", "small_harsh"])
 def test_oracle_full_model_matches_reference_fixture(case):
+    """(`small_harsh`: the ill-conditioned weight family of synth.seeded_state_dict, fixture by oracle/make_golden_harsh.py)"""
     g = Golden(case)
     model = MonoRecModel(cv_depth_steps=g.depths)
-    sd = synth.seeded_state_dict(model.state_dict(), seed=0)
+    sd = synth.seeded_state_dict(model.state_dict(), seed=0, family=g.family)
     out = orc.forward(sd, g.make_inputs(), cv_depth_steps=g.depths)
     g.compare("result", out["result"], atol=ATOL)
     g.compare("cv_mask", out["cv_mask"], atol=ATOL)
@@ -180,3 +181,29 @@ def test_conv3d_of_the_box_stage_is_one_fma_chain_position_major():
         exact = exact and bool((acc.permute(1, 0, 2, 3) == sad).all())
     if not exact:
         pytest.skip("this host's conv3d accumulates in another order (the pin holds on the fixture-generating AVX-512 / oneDNN hosts)")
+
+
+def test_harsh_weight_family_is_ill_conditioned_but_keeps_the_layer_gain():
+    """synth.seeded_state_dict(family="harsh") - the second weight family of the numerics gate: a 9x range of output
+    channel scales, near-cancelling alternating-sign filters in every layer with >= 3 taps, BatchNorm variances down to 1e-3 - at the
+    He family's RMS per layer, so that the heads stay out of saturation and the 1e-4 depth bar stays meaningful."""
+    import math
+    tmpl = MonoRecModel(cv_depth_steps=32).state_dict()
+    he, harsh = synth.seeded_state_dict(tmpl, 0), synth.seeded_state_dict(tmpl, 0, family="harsh")
+    assert set(he) == set(harsh)
+    assert all(torch.equal(he[k], synth.seeded_state_dict(tmpl, 0, family="he")[k]) for k in list(he)[:40])
+    k = "depth_module.enc.0.0.conv_y.weight"                     # 7 x 1, the layer the table runs as F(4,7)
+    w = harsh[k]
+    assert abs(float(w.pow(2).mean().sqrt() / he[k].pow(2).mean().sqrt()) - 1.0) < 0.03     # normalised to the uniform law's RMS, bound / sqrt(3)
+    rms = w.pow(2).mean(dim=(1, 2, 3)).sqrt()
+    assert float(rms.max() / rms.min()) > 5.0                    # channel scales spread over most of [1/3, 3] (x the cancelling filters' 3x)
+    f = w[3]                                                     # a near-cancelling filter: alternating taps, sum ~ 2 % of the taps' size
+    assert float(f.sum(dim=1).abs().max()) < 0.05 * float(f.abs().sum(dim=1).min()) * 7 and bool((f[:, 0] * f[:, 1] < 0).all())
+    var = harsh["_feature_extractor.encoder.layer1.0.bn1.running_var"]
+    assert float(var.min()) < 0.05 and float(var.max()) > 0.5
+    # folded BatchNorm scale: same RMS as the He family, far wider range
+    fold = lambda sd_: sd_["_feature_extractor.encoder.layer1.0.bn1.weight"] / torch.sqrt(sd_["_feature_extractor.encoder.layer1.0.bn1.running_var"] + 1e-5)
+    a, b = fold(he), fold(harsh)
+    assert abs(float(b.pow(2).mean().sqrt() / a.pow(2).mean().sqrt()) - 1.0) < 1e-3 and float(b.max() / b.min()) > 3 * float(a.max() / a.min())
+    with pytest.raises(ValueError):
+        synth.seeded_state_dict(tmpl, 0, family="nope")

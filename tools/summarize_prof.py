@@ -83,6 +83,13 @@ def main():
             w = csv.writer(f)
             w.writerow(cols + ["note: durations in us; rocprofv3 --kernel-trace --stats; bench.py --in-flight 1 (one keyframe at a time)"])
             w.writerows(rows)
+    # every profile set carries the stamp of the plan it was taken on (tables + ABI): bench.py refuses to quote a stale one
+    import sys
+    sys.path.insert(0, ROOT)
+    from monorec_amd import engine, _lib
+    with open(os.path.join(out_dir, f"{args.tag}_stamp.json"), "w") as f:
+        json.dump({"plan_stamp": engine.plan_stamp(), "abi": _lib.MR_ABI_VERSION,
+                   "note": "sha256(tuned_schedules.json + tuned_winograd.json + ABI)[:16] at the time the traces / counters of this tag were taken"}, f)
     agg = collections.defaultdict(dict)
     for path in args.pmc:
         c = sqlite3.connect(path)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 15
+#define MR_ABI_VERSION 16
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -221,11 +221,17 @@ int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
  * written (oracle/numerics_study_winograd.py: depth moves by 2.4e-7 with every 3x3 stride-1 layer of the mask and depth nets evaluated this
  * way).  Same descriptor and conventions as mr_conv3x3_winograd_f32 (`cout_blocks_per_wave` and `variant` ignored); a workgroup (8 waves)
  * produces 16 x 64 output pixels x 32 output channels and uses 153 KB of LDS, so it pays where the layer has >= 256 such workgroups.
+ *
+ * DIAGNOSTIC LIBRARY ONLY since ABI 16 (python -m monorec_amd.build --timeline -> libmonorec_hip_timeline.so, selected with MR_HIP_LIBRARY):
+ * measured on the MI355X it runs at a quarter of its matrix-core time (one 153 KB workgroup per CU), is 1.19x ahead of F(2x2,3x3) on one
+ * pair of 37 us layers of c2 and moves keyframes/s by nothing - below the bar for a form with transform constants up to 8 in the product.
  */
+#ifdef MR_DIAGNOSTIC_LIBRARY
 size_t mr_wino44_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src);
 int mr_wino44_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
 int64_t mr_conv3x3_winograd44_lds_bytes(const mr_wino_desc* desc);
 int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream);
+#endif
 
 /*
  * 3x1 / 1x3, stride 1, zero padding 1 along the filter axis (PadSameConv2d + nn.Conv2d of layers.ConvReLU2, model/layers.py:289-314: the

@@ -68,7 +68,7 @@ class WinoDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 15            # include/monorec_hip.h
+MR_ABI_VERSION = 16            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -154,10 +154,6 @@ ABI = {
     "mr_wino1d_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv1d3_winograd_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
     "mr_conv1d3_winograd_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_int32, ctypes.c_void_p]),
-    "mr_wino44_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
-    "mr_wino44_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
-    "mr_conv3x3_winograd44_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
-    "mr_conv3x3_winograd44_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_cooktoom1d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mr_cooktoom1d_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv1d_cooktoom_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -206,6 +202,15 @@ ABI = {
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }
 
+# exported by the diagnostic library only (python -m monorec_amd.build --timeline; include/monorec_hip.h under MR_DIAGNOSTIC_LIBRARY): typed
+# when present, never required
+DIAGNOSTIC_ABI = {
+    "mr_wino44_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
+    "mr_wino44_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv3x3_winograd44_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_conv3x3_winograd44_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
+}
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmonorec_hip.so")
 _lib = None
 
@@ -226,6 +231,14 @@ def load():
             fn = getattr(lib, name)
         except AttributeError as e:
             raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    lib.has_diagnostic_forms = True
+    for name, (restype, argtypes) in DIAGNOSTIC_ABI.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            lib.has_diagnostic_forms = False
+            continue
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.mr_abi_version() != MR_ABI_VERSION:

@@ -27,8 +27,12 @@ SOURCES = [
     ("conv_wino.hip", []),
     ("convt_wino.hip", []),
     ("conv1d_wino.hip", []),
-    ("conv_wino44.hip", []),
 ]
+# conv_wino44.hip (F(4x4,3x3)) is built into the DIAGNOSTIC library only since round 4: it runs at a quarter of its MFMA time, is 1.19x
+# ahead of F(2x2,3x3) on one 37 us layer pair of c2 and moved keyframes/s by nothing (697 -> 698) - below the bar for a kernel with
+# transform constants up to 8 in the product.  The same goes for the F(2,7) instantiations of conv1d_wino.hip,
+# which no table entry ever selected.
+DIAGNOSTIC_ONLY_SOURCES = [("conv_wino44.hip", [])]
 
 
 def _hipcc():
@@ -78,7 +82,9 @@ TIMELINE_LIB_PATH = os.path.join(HERE, "libmonorec_hip_timeline.so")
 # sources whose diagnostic switches are compiled in only for the diagnostic library: (source, define)
 DIAGNOSTIC = {"conv_mfma.hip": "-DMR_CONV_TIMELINE",     # per-workgroup timestamps / ablation bits (MR_CONV_DBG; ~3 % slower even when off)
               "cost_volume.hip": "-DMR_TUNING_ENV",      # MR_CV_MARCH_TY / MR_CV_MARCH_DP / MR_CV_NO_KF_PREPASS (tools/bench_cv.py sweeps)
-              "heads.hip": "-DMR_TUNING_ENV"}            # MR_HEADS_QUAD_MIN (tools/bench_heads.py)
+              "heads.hip": "-DMR_TUNING_ENV",            # MR_HEADS_QUAD_MIN (tools/bench_heads.py)
+              "conv1d_wino.hip": "-DMR_DIAGNOSTIC_FORMS",   # the F(2,7) instantiations
+              "eltwise.hip": "-DMR_DIAGNOSTIC_FORMS"}       # MR_LAUNCH_WINO44 in mr_run_launches
 
 
 def build_timeline(verbose=False):
@@ -96,7 +102,16 @@ def build_timeline(verbose=False):
         o = os.path.join(objdir, src.replace(".hip", "_diag.o"))
         s = os.path.join(CSRC, src)
         if _stale(o, [s, os.path.join(CSRC, "conv_layout.h")]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", DIAGNOSTIC[src], "-c", s, "-o", o] + flags[src]
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", DIAGNOSTIC[src], "-DMR_DIAGNOSTIC_LIBRARY", "-c", s, "-o", o] + flags[src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        objs.append(o)
+    for src, extra in DIAGNOSTIC_ONLY_SOURCES:
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        s = os.path.join(CSRC, src)
+        if _stale(o, [s, os.path.join(CSRC, "conv_layout.h"), os.path.join(CSRC, "cooktoom_1d.h"), os.path.join(HERE, "..", "include", "monorec_hip.h")]):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-DMR_DIAGNOSTIC_LIBRARY", "-c", s, "-o", o] + extra
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

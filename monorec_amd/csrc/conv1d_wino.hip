@@ -547,7 +547,13 @@ int launch1_mbw(const W1Derived& dv, hipStream_t stream) {
 
 
 // ---- host side of the larger Cook-Toom forms ---------------------------------------------------------------------------------------
+// F(2, 7) was never selected by a measured table (F(4, 7) halves the 7-tap layers, the direct kernel beats F(2, 7)): its instantiations
+// are compiled into the diagnostic library only (python -m monorec_amd.build --timeline).
+#ifdef MR_DIAGNOSTIC_FORMS
 bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 2 && r == 7) || (m == 4 && r == 7); }
+#else
+bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 4 && r == 7); }
+#endif
 bool valid_ct_mbw(int m, int r, int mbw) { return mbw >= 1 && mbw <= (m + r - 1 >= 10 ? 3 : 4); }      // N x MBW accumulator sets in 256 VGPRs
 
 template <int AXIS, int M, int R>
@@ -602,7 +608,9 @@ int run_ct_form(const mr_wino_desc* d, hipStream_t stream, bool launch, int64_t*
 int run_ct(const mr_wino_desc* d, int axis, int m, int r, hipStream_t stream, bool launch, int64_t* lds) {
     if (!valid_form(m, r) || (axis != 0 && axis != 1)) return MR_ERR_BAD_ARGUMENT;
     if (m == 4 && r == 3) return axis == 0 ? run_ct_form<0, 4, 3>(d, stream, launch, lds) : run_ct_form<1, 4, 3>(d, stream, launch, lds);
+#ifdef MR_DIAGNOSTIC_FORMS
     if (m == 2 && r == 7) return axis == 0 ? run_ct_form<0, 2, 7>(d, stream, launch, lds) : run_ct_form<1, 2, 7>(d, stream, launch, lds);
+#endif
     return axis == 0 ? run_ct_form<0, 4, 7>(d, stream, launch, lds) : run_ct_form<1, 4, 7>(d, stream, launch, lds);
 }
 

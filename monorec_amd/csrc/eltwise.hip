@@ -338,7 +338,11 @@ extern "C" int mr_run_launches(const mr_launch_item* items, int32_t num, void* s
             case MR_LAUNCH_WINO_T: rc = mr_convt4x4s2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_WINO_1D: rc = mr_conv1d3_winograd_f32((const mr_wino_desc*)items[i].desc, items[i].arg, stream); break;
             case MR_LAUNCH_UPCONV: rc = mr_upconv2x2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
+#ifdef MR_DIAGNOSTIC_FORMS
             case MR_LAUNCH_WINO44: rc = mr_conv3x3_winograd44_f32((const mr_wino_desc*)items[i].desc, stream); break;
+#else
+            case MR_LAUNCH_WINO44: rc = MR_ERR_UNSUPPORTED; break;      // F(4x4,3x3): diagnostic library only
+#endif
             case MR_LAUNCH_COOKTOOM_1D:
                 rc = mr_conv1d_cooktoom_f32((const mr_wino_desc*)items[i].desc, items[i].arg & 15, (items[i].arg >> 4) & 15, (items[i].arg >> 8) & 15, stream);
                 break;

@@ -180,6 +180,21 @@ def _load_winograd():
 
 _load_winograd()
 
+WINOGRAD_F2 = {}    # conv_forms = "f2": for every key whose table entry is a larger form (F(4,.), F(4x4,3x3)), the F(2,.) code that was
+                    # measured best for it before the larger forms existed (0 = direct kernel: the 7-tap layers)
+
+
+def _load_winograd_f2():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_winograd_f2.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            WINOGRAD_F2.update({k: int(v) for k, v in json.load(f).items()})
+
+
+_load_winograd_f2()
+
 
 def plan_stamp():
     """What decides which kernels a plan launches: sha256 over the two measured tables (tuned_schedules.json, tuned_winograd.json) and
@@ -202,7 +217,7 @@ def winograd_signature(cout, src_channels, h, w, batch):
     return f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_o{h}x{w}_b{batch}"
 
 
-def choose_winograd(cout, src_channels, h, w, batch):
+def choose_winograd(cout, src_channels, h, w, batch, f2=False):
     """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
     11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), 21 = variant 2 (11 whose 1..16 tail channels
     come from 16-row workgroups: the 48-channel layers), 31 = F(4x4,3x3) (csrc/conv_wino44.hip; only by the table), for a 3x3 stride-1
@@ -215,7 +230,10 @@ def choose_winograd(cout, src_channels, h, w, batch):
         return 0
     sig = winograd_signature(cout, src_channels, h, w, batch)
     if sig in WINOGRAD:
-        return WINOGRAD[sig]
+        code = WINOGRAD[sig]
+        if f2 and code // 10 == 3:           # F(4x4,3x3) -> the F(2x2,3x3) variant measured before it (else: transform in registers, 32 channels)
+            code = WINOGRAD_F2.get(sig, 11)
+        return code
     tiles = math.ceil(h / 8) * math.ceil(w / 32) * batch
     if tiles * math.ceil(cout / 32) < 256:
         return 0
@@ -233,7 +251,7 @@ def choose_winograd_t(cout, src_channels, h, w, batch):
     return WINOGRAD.get("t_" + winograd_signature(cout, src_channels, h, w, batch), 0)
 
 
-def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3):
+def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3, f2=False):
     """k-tap stride-1 'same' convolution along x (axis 0: 1 x k) or y (axis 1: k x 1) - layers.ConvReLU2 of the DepthModule (3 taps: the
     second pair of every stage; 7 taps: enc.0.0): 0 = direct MFMA kernel; 1..4 = the 1-D Winograd F(2,3) kernel (csrc/conv1d_wino.hip)
     with 16 x that many output channels per workgroup; 10 m + mbw = the Cook-Toom form F(m, taps) of the same file (41..44: F(4,3);
@@ -242,7 +260,11 @@ def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3):
     if w % 4:
         return 0
     prefix = ("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_"
-    return WINOGRAD.get(prefix + winograd_signature(cout, src_channels, h, w, batch), 0)
+    key = prefix + winograd_signature(cout, src_channels, h, w, batch)
+    code = WINOGRAD.get(key, 0)
+    if f2 and code >= 40:                    # F(4,.) -> what was measured best among F(2,.) and the direct kernel before the larger forms
+        code = WINOGRAD_F2.get(key, 0)
+    return code
 
 
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
@@ -374,8 +396,8 @@ class Plan:
         self.winograd = _os.environ.get("MR_WINOGRAD", "1") != "0" if winograd is None else bool(winograd)
         # which reduced-multiply forms the measured table may select (MonoRecModel(hip_exact_convs=...)):
         #   "table"  everything it holds, F(4,3) / F(4,7) / F(4x4,3x3) included (transform constants up to 89 and 1/2835);
-        #   "f2"     the F(2,.) forms only (constants 0, +-1, +-1/2: rounding like the direct sum) - a larger form is mapped to the
-        #            F(2,.) kernel of the same layer;
+        #   "f2"     the F(2,.) forms only (constants 0, +-1, +-1/2: rounding like the direct sum) - a layer the table gives to a larger
+        #            form runs what was measured best for it before those forms existed (tuned_winograd_f2.json);
         #   "direct" none: every convolution on the direct MFMA kernel, an exact fmaf chain per output like the reference's.
         if conv_forms not in ("table", "f2", "direct"):
             raise ValueError(f"conv_forms must be 'table', 'f2' or 'direct', got {conv_forms!r}")
@@ -518,9 +540,7 @@ class Plan:
                 in_mode == IN_DIRECT and tf == TF_NONE and tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0) and out_ch_offset == 0 and
                 out.shape[1] == cout and tuple(grid) == (hs, ws) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY_RELU) and self.bf16 == 0 and
                 name not in self.schedule_override):
-            mbw = choose_winograd(cout, src_channels, hs, ws, n)
-            if mbw // 10 == 3 and self.conv_forms == "f2":
-                mbw = 11                       # F(4x4,3x3) -> F(2x2,3x3), input transform in registers, 32 output channels per workgroup
+            mbw = choose_winograd(cout, src_channels, hs, ws, n, f2=self.conv_forms == "f2")
             if mbw:
                 return self._conv_winograd(stage, name, srcs, weight, bias, out, act, p0, residual, mbw % 10, mbw // 10)
         if (self.winograd and phases is None and (kh, kw) in ((1, 3), (3, 1), (1, 7), (7, 1)) and tuple(stride) == (1, 1) and tuple(pad) == (kh // 2, kw // 2) and
@@ -528,9 +548,7 @@ class Plan:
                 out.shape[1] == cout and tuple(grid) == (hs, ws) and act in (ACT_NONE, ACT_RELU, ACT_LEAKY_RELU) and self.bf16 == 0 and
                 residual is None and name not in self.schedule_override):
             axis = 0 if kh == 1 else 1
-            code = choose_winograd_1d(axis, cout, src_channels, hs, ws, n, max(kh, kw))
-            if code >= 40 and self.conv_forms == "f2":
-                code = code % 10 if max(kh, kw) == 3 else 20 + code % 10     # F(4,3) -> F(2,3), F(4,7) -> F(2,7), same channels per workgroup
+            code = choose_winograd_1d(axis, cout, src_channels, hs, ws, n, max(kh, kw), f2=self.conv_forms == "f2")
             if code:
                 return self._conv_winograd_1d(stage, name, srcs, weight, bias, out, act, p0, axis, code % 10, code // 10 if code >= 10 else 2)
         if phases is not None:                 # the common kh x kw sizes the input tile: the maximum over the phases
@@ -612,6 +630,9 @@ class Plan:
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = weight.detach().to(torch.float32).contiguous().cpu()
         if variant == 3:       # F(4x4,3x3) (csrc/conv_wino44.hip): 36 positions, 16 x 64 pixels x 32 channels per workgroup
+            if not lib.has_diagnostic_forms:
+                raise RuntimeError(f"{name}: table code 31 (F(4x4,3x3)) needs the diagnostic library (python -m monorec_amd.build --timeline, "
+                                   "MR_HIP_LIBRARY); the product library does not carry that kernel")
             nfl = lib.mr_wino44_packed_weight_floats(cout, sc, len(src_channels))
             packed = torch.empty(nfl, dtype=torch.float32)
             _lib.check(lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44_pack_weights_f32")

@@ -179,7 +179,7 @@ def test_reference_example_sample_with_the_fixtures_own_matrices(hip_lib):
     model, sd = _model(g.depths, graph=False)
     model._geometry_override = (torch.from_numpy(g.z["geom.kinv"]), torch.from_numpy(g.z["geom.proj"]))
     with torch.no_grad():
-        out = model(_to_dev(batch))
+        out = model.submit(_to_dev(batch)).synchronize()      # zero-copy interface: step 5 patches the plan's resident volume and re-runs its launches
     torch.cuda.synchronize()
     sf = [t.cpu() for t in out["single_frame_cvs"]]
     nf, h, w = g.frames, g.h, g.w

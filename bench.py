@@ -124,6 +124,29 @@ def time_layers(model, batch_dev, plan_key, reps=5):
     return rows
 
 
+def conv_algorithmic_bytes(c):
+    """HBM bytes a convolution launch must move: every source activation once, the output once, the weights once (conv_log entry)."""
+    sp = c["spec"]
+    lays = sp.get("src_layouts") or [0] * len(sp["src_shapes"])
+    n = 0.0
+    for shp, lay in zip(sp["src_shapes"], lays):
+        e = 1
+        for d in shp:
+            e *= d
+        n += e * (2 if lay == 1 else 4)
+    if c.get("b8"):
+        n += c["batch"] * c["cout"] * c["out"][0] * c["out"][1] * c["phases"] * (2 if sp["out_layout"] == 1 else 4)
+    else:
+        e = 1
+        for d in sp["out_shape"]:
+            e *= d
+        n += e * 4
+    w = 1
+    for d in sp["w_shape"]:
+        w *= d
+    return n + w * (2 if c.get("bf16") == 1 else 4) * (c["phases"] if c["phases"] == 4 and not c.get("b8") else 1)
+
+
 def _latest_profile(cfg, suffix):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{cfg}_{suffix}")))
@@ -184,7 +207,7 @@ def committed_kernel_stats(cfg):
         forwards = 0
         for r in list(csv.reader(open(path)))[1:]:
             name, calls, total = r[0], int(r[1]), float(r[2])
-            if "conv_mfma_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name or "conv1d3_wino" in name or "conv1d_ct_kernel" in name or "upconv2x2_wino" in name:
+            if "conv_mfma_kernel" in name or "conv_b8_kernel" in name or "conv3x3_wino" in name or "convt4x4_wino" in name or "conv1d3_wino" in name or "conv1d_ct_kernel" in name or "upconv2x2_wino" in name:
                 conv_us += total
                 conv_n += calls
             elif "splitk_epilogue_kernel" in name:
@@ -629,7 +652,9 @@ def main():
         n_ct = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and (c.get("wino_m", 2), max(c["k"])) != (2, 3))
         n_wino_u = sum(1 for c in model._plans[plan_key].conv_log if c.get("upconv"))
         n_wino_t = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv"))
-        roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (bf16 v_mfma_f32_16x16x16_bf16)" if args.bf16 else
+        n_b8 = sum(1 for c in model._plans[plan_key].conv_log if c.get("b8"))
+        roof = {"bound": "mfma", "kernel": (f"conv_b8_kernel (v_mfma_f32_16x16x32_bf16, channel-blocked bf16 activation storage; {n_b8} of the launches) + "
+                                            "conv_mfma_kernel (bf16 operands, fp32 storage: the ResNet encoder)") if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
                  f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches)" + (f" + conv3x3_wino44_kernel (F(4x4,3x3), {n_wino44})" if n_wino44 else "") + " + convt4x4_wino[_rb]_kernel "
                  f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d})" + (f" + conv1d_ct_kernel ({' / '.join(ct_forms)} for k x 1 / 1 x k, {n_ct})" if n_ct else "") + f" + upconv2x2_wino_kernel (4-multiply Upconv, {n_wino_u}); all fp32 v_mfma_f32_16x16x4_f32"),
@@ -650,6 +675,17 @@ def main():
                 "all_kernel_launches_per_step": len(rows) + sum(1 for c in model._plans[plan_key].conv_log if c["split_k"] > 1) + 2,
                 "all_kernel_launches_note": "every launch of a keyframe: convolutions + their split-K finishing kernels + pooling / max / normalise / "
                                             "classifier / heads + the three cost-volume kernels (statistics prepass, sad, fusion)"}
+        if args.bf16:
+            # configs[4]: the bf16 path is HBM-bound (0.27 ms of bf16 MFMA time against ~0.5 ms of activation traffic): the roofline
+            # of the line is bytes, the flops stay as secondary keys
+            cbytes = sum(conv_algorithmic_bytes(c) for c in model._plans[plan_key].conv_log)
+            roof.update({"bound": "hbm", "achieved": cbytes / conv_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cbytes / conv_s / 8e12,
+                         "algorithmic_MB_per_step": cbytes / 1e6,
+                         "algorithmic_bytes_note": "per convolution launch: every source activation once (2 B per element where it is stored channel-blocked "
+                                                   "in bf16, 4 B where it is dense fp32), the output once, the weights once; summed over the launches / the "
+                                                   "HIP-event time of the launches / 8 TB/s",
+                         "mfma_frac": achieved / peak, "mfma_achieved_TFLOPs": achieved, "mfma_peak_TFLOPs": peak,
+                         "frac_note": "HBM roofline (see algorithmic_bytes_note); mfma_frac = the reference's conv flops / conv time / bf16 dense peak"})
         if kst:
             roof.update({"rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,
                          "frac_kernel_only": conv_flops / (kst["conv_us_per_forward"] * 1e-6) / 1e12 / peak,
@@ -699,7 +735,7 @@ def main():
             "config": {"workload": f"{cfg_name}: {args.batch} keyframe(s)/step/GPU, {args.height}x{args.width}, "
                                    f"{args.frames} source frames, {args.depths} depth bins, "
                                    + ("bf16x3 split-MFMA convolutions (hi/lo bf16 pairs, fp32-class accuracy; fp32 storage and cost volume), " if args.bf16x3 else
-                                      "bf16 MFMA convolutions (fp32 storage and cost volume), " if args.bf16 else "fp32, ") + "random-init weights",
+                                      "bf16 MFMA convolutions (bf16 channel-blocked activations inside the mask / depth nets; fp32 cost volume, image features and outputs), " if args.bf16 else "fp32, ") + "random-init weights",
                        "batch_per_gpu": args.batch, "hip_graph": args.graph, "keyframes_in_flight": args.in_flight,
                        "host_queue_depth_per_slot": args.queue_depth, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "results_collected_by": "stream wait (handle.result())" if args.stream_collect else "host wait (handle.synchronize())",

@@ -234,6 +234,55 @@ int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream);
 #endif
 
 /*
+ * ---- bf16 MFMA path with channel-blocked bf16 activation storage (BASELINE configs[4]; MonoRecModel(hip_bf16=True)) --------------------
+ * Layout "B8" of an activation: (batch, ceil(C / 8), H, W, 8) bf16 - one 16-byte group holds 8 consecutive channels of one pixel, padded
+ * channels are zero.  mr_conv2d_b8 stands in for the nn.Conv2d / ConvTranspose2d(4,2) / Upconv layers of MaskModule and DepthModule
+ * (model/monorec/monorec_model.py:345-385,526-557; model/layers.py:289-356,380-400): sources concatenated on channels and read in place,
+ * each either B8 or dense fp32 NCHW (rounded to bf16, nearest even, while it is staged); v_mfma_f32_16x16x32_bf16 with fp32 accumulation;
+ * bias and activation (none / ReLU / LeakyReLU(act_p0)) in the epilogue; destination B8 (rounded once) or fp32 NCHW, written at
+ * (oy * out_step_h + phase_out_off_h, ox * out_step_w + phase_out_off_w) of a (dst_plane_h, dst_plane_w) plane.  Taps read input
+ * (oy * stride_h - phase_pad_top + ky, ox * stride_w - phase_pad_left + kx), zero outside.  num_phases = 4 runs the four output parities of
+ * a transposed / upsampling layer in one launch (per-phase filter size <= kh x kw, padding, offset, weights); num_phases <= 1 uses entry 0.
+ * Not within the 1e-4 parity bar (bf16 operands): the accuracy bar of this mode is tests/test_gpu_model.py::test_c5_shape_in_fp32_and_bf16.
+ */
+#define MR_LAYOUT_F32_NCHW 0
+#define MR_LAYOUT_BF16_B8  1
+typedef struct mr_b8_conv_desc {
+    const void* src[MR_MAX_SOURCES];
+    int32_t src_channels[MR_MAX_SOURCES];
+    int32_t src_layout[MR_MAX_SOURCES];      /* MR_LAYOUT_* */
+    int32_t num_src, batch, src_h, src_w;
+    int32_t kh, kw, stride_h, stride_w;      /* kh / kw: the maximum over the phases */
+    int32_t out_h, out_w;                    /* conv grid size (per phase) */
+    void* dst;
+    int32_t dst_layout, out_channels;
+    int32_t dst_plane_h, dst_plane_w, out_step_h, out_step_w;
+    const float* bias;                       /* out_channels floats or NULL */
+    int32_t activation;
+    float act_p0;
+    int32_t cout_blocks_per_wg;              /* MB: 1..4 blocks of 16 output channels per workgroup */
+    int32_t pixel_blocks_per_wave;           /* NB: 1, 2, 4 */
+    int32_t waves_per_wg;                    /* 4 or 8 */
+    int32_t num_phases;
+    const void* phase_weights[4];            /* from mr_b8_pack_weights with that phase's filter size (device copies) */
+    int32_t phase_kh[4], phase_kw[4];        /* 0 = kh / kw */
+    int32_t phase_pad_top[4], phase_pad_left[4], phase_out_off_h[4], phase_out_off_w[4];
+} mr_b8_conv_desc;
+size_t mr_b8_packed_weight_bytes(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t kh, int32_t kw, int32_t mb);
+/* weight: (out_channels, sum(src_channels), kh, kw) fp32 in host memory -> bf16 A-fragment stream in host memory `dst` */
+int mr_b8_pack_weights(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t kh, int32_t kw,
+                       int32_t mb, void* dst);
+int64_t mr_conv2d_b8_lds_bytes(const mr_b8_conv_desc* desc);
+int mr_conv2d_b8(const mr_b8_conv_desc* desc, void* stream);
+/* nn.MaxPool2d(2) of the next MaskModule encoder stage and the maximum over the frames (monorec_model.py:357-365) on B8 tensors:
+ * src (frames, planes, h, w) 16-byte groups, planes = batch * channel blocks -> pooled (frames, planes, h/2, w/2), fmax (planes, h, w) */
+int mr_pool2x2_framemax_b8(const void* src, void* pooled, void* fmax, int32_t frames, int64_t planes, int32_t h, int32_t w, void* stream);
+int mr_max_over_frames_b8(const void* src, void* dst, int32_t frames, int64_t groups16, void* stream);
+/* layout conversions: dense fp32 (n, c, hw) <-> B8 (n, ceil(c/8), hw, 8) bf16 */
+int mr_f32_nchw_to_b8(const float* src, void* dst, int32_t n, int32_t c, int64_t hw, void* stream);
+int mr_b8_to_f32_nchw(const void* src, float* dst, int32_t n, int32_t c, int64_t hw, void* stream);
+
+/*
  * 3x1 / 1x3, stride 1, zero padding 1 along the filter axis (PadSameConv2d + nn.Conv2d of layers.ConvReLU2, model/layers.py:289-314: the
  * second pair of every DepthModule encoder stage, dec{1,2}.1, dec4.0 - model/monorec/monorec_model.py:485-513) as 1-D Winograd F(2, 3):
  * 4 multiplies per (input channel, output channel) and 2 outputs instead of 6.  Same descriptor and conventions as
@@ -393,6 +442,7 @@ int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_ea
 #define MR_LAUNCH_UPCONV  4
 #define MR_LAUNCH_COOKTOOM_1D 5
 #define MR_LAUNCH_WINO44  6
+#define MR_LAUNCH_CONV_B8 7
 typedef struct mr_launch_item {
     int32_t kind;
     int32_t arg;

@@ -67,6 +67,25 @@ class WinoDesc(ctypes.Structure):
                 ("variant", ctypes.c_int32)]
 
 
+LAYOUT_F32_NCHW, LAYOUT_BF16_B8 = 0, 1
+
+
+class B8ConvDesc(ctypes.Structure):
+    """mirror of `mr_b8_conv_desc` (include/monorec_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p * MR_MAX_SOURCES), ("src_channels", ctypes.c_int32 * MR_MAX_SOURCES), ("src_layout", ctypes.c_int32 * MR_MAX_SOURCES),
+                ("num_src", ctypes.c_int32), ("batch", ctypes.c_int32), ("src_h", ctypes.c_int32), ("src_w", ctypes.c_int32),
+                ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride_h", ctypes.c_int32), ("stride_w", ctypes.c_int32),
+                ("out_h", ctypes.c_int32), ("out_w", ctypes.c_int32),
+                ("dst", ctypes.c_void_p), ("dst_layout", ctypes.c_int32), ("out_channels", ctypes.c_int32),
+                ("dst_plane_h", ctypes.c_int32), ("dst_plane_w", ctypes.c_int32), ("out_step_h", ctypes.c_int32), ("out_step_w", ctypes.c_int32),
+                ("bias", ctypes.c_void_p), ("activation", ctypes.c_int32), ("act_p0", ctypes.c_float),
+                ("cout_blocks_per_wg", ctypes.c_int32), ("pixel_blocks_per_wave", ctypes.c_int32), ("waves_per_wg", ctypes.c_int32),
+                ("num_phases", ctypes.c_int32),
+                ("phase_weights", ctypes.c_void_p * 4), ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
+                ("phase_pad_top", ctypes.c_int32 * 4), ("phase_pad_left", ctypes.c_int32 * 4),
+                ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4)]
+
+
 MR_MAX_COPY_SEGMENTS = 24
 MR_ABI_VERSION = 16            # include/monorec_hip.h
 
@@ -81,7 +100,7 @@ class LaunchItem(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("arg", ctypes.c_int32), ("desc", ctypes.c_void_p)]
 
 
-LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV, LAUNCH_COOKTOOM_1D, LAUNCH_WINO44 = 0, 1, 2, 3, 4, 5, 6
+LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV, LAUNCH_COOKTOOM_1D, LAUNCH_WINO44, LAUNCH_CONV_B8 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class HeadDesc(ctypes.Structure):
@@ -162,6 +181,16 @@ ABI = {
     "mr_wino_t_pack_weights_tail_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
     "mr_wino_packed_weight_floats_tail": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
     "mr_wino_pack_weights_tail_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
+    "mr_b8_packed_weight_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mr_b8_pack_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv2d_b8_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(B8ConvDesc)]),
+    "mr_conv2d_b8": (ctypes.c_int, [ctypes.POINTER(B8ConvDesc), ctypes.c_void_p]),
+    "mr_pool2x2_framemax_b8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_void_p]),
+    "mr_max_over_frames_b8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_f32_nchw_to_b8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
+    "mr_b8_to_f32_nchw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]),
     "mr_gather_small_f32": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_copy_segments": (ctypes.c_int, [ctypes.POINTER(CopySegment), ctypes.c_int32, ctypes.c_void_p]),
     "mr_max_over_frames_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,

@@ -27,6 +27,7 @@ SOURCES = [
     ("conv_wino.hip", []),
     ("convt_wino.hip", []),
     ("conv1d_wino.hip", []),
+    ("conv_b8.hip", []),
 ]
 # conv_wino44.hip (F(4x4,3x3)) is built into the DIAGNOSTIC library only since round 4: it runs at a quarter of its MFMA time, is 1.19x
 # ahead of F(2x2,3x3) on one 37 us layer pair of c2 and moved keyframes/s by nothing (697 -> 698) - below the bar for a kernel with

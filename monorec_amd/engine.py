@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_ABS_TANH_AFFINE, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, IN_DIRECT, IN_MAXPOOL2,
-                   IN_UPSAMPLE2, TF_NONE, TF_RESNET_NORM, ConvDesc, HeadDesc, WinoDesc)
+                   IN_UPSAMPLE2, LAYOUT_BF16_B8, LAYOUT_F32_NCHW, TF_NONE, TF_RESNET_NORM, B8ConvDesc, ConvDesc, HeadDesc, WinoDesc)
 
 LEAKY_SLOPE = 0.1   # model/layers.py:290,318,381
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, used by torchvision's ResNet
@@ -381,6 +381,10 @@ class Plan:
         self.cv_patch_size = int(cv_patch_size)                                           # :138-142,247
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = int(bf16)         # convolutions: 0 fp32 MFMA, 1 bf16 MFMA (MR_COMPUTE_BF16), 2 bf16x3 split (MR_COMPUTE_BF16X3); everything else fp32
+        # bf16 MFMA mode: the activations BETWEEN the convolutions of the mask and depth nets are stored channel-blocked in bf16 ("B8",
+        # csrc/conv_b8.hip) - half the HBM bytes, the MFMA operand read from LDS as it is.  MR_B8=0: A/B aid (fp32 storage as in rounds 1-3)
+        import os as _os0
+        self.b8 = self.bf16 == 1 and _os0.environ.get("MR_B8", "1") != "0"
         self.sd = state
         self.buf = {}
         self.keep = []          # packed weights / biases (device tensors kept alive)
@@ -472,6 +476,10 @@ class Plan:
                     slot(obj, "src", i, obj.src[i])
                 slot(obj, "dst", None, obj.dst)
                 slot(obj, "residual", None, obj.residual)
+            elif isinstance(obj, B8ConvDesc):
+                for i in range(obj.num_src):
+                    slot(obj, "src", i, obj.src[i])
+                slot(obj, "dst", None, obj.dst)
             elif isinstance(obj, ctypes.Array) and getattr(obj, "_type_", None) is HeadDesc:
                 for i in range(len(obj)):
                     slot(obj[i], "src", None, obj[i].src)
@@ -890,6 +898,141 @@ class Plan:
         self.stages[stage].append((name, run))
         return out
 
+    # ------------------------------------------------------------------ bf16 MFMA path with B8 activation storage (csrc/conv_b8.hip)
+    def alloc_b8(self, name, n, c, h, w):
+        """Activation in the channel-blocked bf16 layout: (n, ceil(c / 8), h, w, 8) bf16; `.b8_channels` carries c."""
+        t = torch.empty(n, (c + 7) // 8, h, w, 8, dtype=torch.bfloat16, device=self.device)
+        t.b8_channels = c
+        self.buf[name] = t
+        return t
+
+    @staticmethod
+    def _act_info(t):
+        """(layout, batch, channels, h, w) of an activation tensor: B8 (5-D bf16) or dense fp32 NCHW."""
+        if t.dtype == torch.bfloat16:
+            return LAYOUT_BF16_B8, int(t.shape[0]), int(t.b8_channels), int(t.shape[2]), int(t.shape[3])
+        return LAYOUT_F32_NCHW, int(t.shape[0]), int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
+
+    @staticmethod
+    def b8_schedule(cout, out_h, out_w, kh, kw, sh, sw, batch, phases):
+        """(MB, NB, waves) of a mr_conv2d_b8 launch: as many of the output channels per workgroup as 4 blocks of 16 allow (the input tile
+        is then read once), 8 waves x 2 pixel blocks (8 x 32 pixels) where that still gives every CU two workgroups, smaller tiles below;
+        bounded by the 160 KB of LDS and two staged tile positions per thread (csrc/conv_b8.hip: derive8)."""
+        cb16 = (cout + 15) // 16
+        mb = cb16 if cb16 <= 4 else (4 if cb16 % 4 == 0 else (3 if cb16 % 3 == 0 else 4))
+        groups = math.ceil(cb16 / mb)
+        for waves, nb in ((8, 2), (4, 2), (4, 1)):
+            th = waves * nb // 2
+            ih, iw = (th - 1) * sh + kh, 31 * sw + kw
+            plane = ih * iw
+            wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * groups * batch * phases
+            lds = 2 * (64 * plane + 1024 * kh * kw * mb)
+            if lds <= 160 * 1024 and plane <= 2 * 64 * waves and (wgs >= 512 or (waves, nb) == (4, 1)):
+                return mb, nb, waves
+        for waves, nb in ((8, 2), (8, 1), (4, 2), (4, 1)):          # whatever launches
+            th = waves * nb // 2
+            plane = ((th - 1) * sh + kh) * (31 * sw + kw)
+            for m in (mb, 2, 1):
+                if 2 * (64 * plane + 1024 * kh * kw * m) <= 160 * 1024 and plane <= 2 * 64 * waves:
+                    return m, nb, waves
+        raise ValueError("no launchable B8 schedule")
+
+    def conv_b8(self, stage, name, srcs, weight, bias, out, *, stride=(1, 1), pad=(0, 0), grid=None, act=ACT_NONE, p0=0.0,
+                out_step=(1, 1), phases=None, ref_macs=None):
+        """Append one mr_conv2d_b8 launch.  srcs: activations (B8 or dense fp32 NCHW) concatenated on channels; out: B8 or fp32 NCHW.
+        phases: optional list of 4 (weight, pad_top, pad_left, out_off_h, out_off_w) run in one launch."""
+        lib = self.lib
+        infos = [self._act_info(s_) for s_ in srcs]
+        n, hs, ws = infos[0][1], infos[0][3], infos[0][4]
+        assert all(i[1] == n and i[3] == hs and i[4] == ws for i in infos) and all(s_.is_contiguous() for s_ in srcs), name
+        src_channels = [i[2] for i in infos]
+        plist = [(weight, pad[0], pad[1], 0, 0)] if phases is None else phases
+        cout, cin = int(plist[0][0].shape[0]), int(plist[0][0].shape[1])
+        assert cin == sum(src_channels), (name, cin, src_channels)
+        kh, kw = max(p[0].shape[2] for p in plist), max(p[0].shape[3] for p in plist)
+        out_h, out_w = grid
+        olay, on, oc, oh, ow = self._act_info(out)
+        assert on == n and oc == cout and out.is_contiguous(), (name, on, n, oc, cout)
+        mb, nb, waves = self.schedule_override.get(name) or self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist))
+        d = B8ConvDesc()
+        sc = (ctypes.c_int32 * len(srcs))(*src_channels)
+        for i, s_ in enumerate(srcs):
+            d.src[i], d.src_channels[i], d.src_layout[i] = s_.data_ptr(), src_channels[i], infos[i][0]
+            if "keyframe" in self.buf and s_ is self.buf["keyframe"]:
+                self._input_srcs.append((d, i, "keyframe"))
+        d.num_src, d.batch, d.src_h, d.src_w = len(srcs), n, hs, ws
+        d.kh, d.kw, d.stride_h, d.stride_w = kh, kw, stride[0], stride[1]
+        d.out_h, d.out_w = out_h, out_w
+        d.dst, d.dst_layout, d.out_channels = out.data_ptr(), olay, cout
+        d.dst_plane_h, d.dst_plane_w, d.out_step_h, d.out_step_w = oh, ow, out_step[0], out_step[1]
+        d.bias = self._dev(bias).data_ptr() if bias is not None else None
+        d.activation, d.act_p0 = act, p0
+        d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.waves_per_wg = mb, nb, waves
+        d.num_phases = len(plist)
+        for i, (wp, pt, pl, oh_, ow_) in enumerate(plist):
+            wc = wp.detach().to(torch.float32).contiguous().cpu()
+            pk, pkw = int(wc.shape[2]), int(wc.shape[3])
+            nbytes = lib.mr_b8_packed_weight_bytes(cout, sc, len(srcs), pk, pkw, mb)
+            assert nbytes > 0, (name, mb)
+            packed = torch.empty(nbytes, dtype=torch.uint8)
+            _lib.check(lib.mr_b8_pack_weights(wc.data_ptr(), cout, sc, len(srcs), pk, pkw, mb, packed.data_ptr()), "mr_b8_pack_weights")
+            dev_w = packed.to(self.device)
+            self.keep.append(dev_w)
+            d.phase_weights[i] = dev_w.data_ptr()
+            d.phase_kh[i], d.phase_kw[i] = pk, pkw
+            d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh_, ow_
+        lds = lib.mr_conv2d_b8_lds_bytes(ctypes.byref(d))
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name} b8 sched={(mb, nb, waves)}")
+        taps = sum(int(p[0].shape[2]) * int(p[0].shape[3]) for p in plist)
+        macs = n * out_h * out_w * cout * cin * taps
+        th = waves * nb // 2
+        wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * math.ceil(((cout + 15) // 16) / mb) * n * len(plist)
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=1, ck=32, waves=waves, kws=0,
+                                  wgs=wgs, lds=int(lds), cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=len(plist), bf16=1, b8=True,
+                                  sig=f"b8_co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{stride[0]}x{stride[1]}_o{out_h}x{out_w}_b{n}_p{len(plist)}",
+                                  spec=dict(src_shapes=[(i[1], i[2], i[3], i[4]) for i in infos], src_layouts=[i[0] for i in infos], w_shape=(cout, cin, kh, kw),
+                                            stride=tuple(stride), pad=tuple(pad), grid=(out_h, out_w), act=act, p0=p0, out_layout=olay,
+                                            out_step=tuple(out_step))))
+        self.keep += [d, out, sc] + list(srcs)
+
+        def run(stream):
+            _lib.check(lib.mr_conv2d_b8(ctypes.byref(d), stream), name)
+        run.native = (_lib.LAUNCH_CONV_B8, d, 0)
+        self.stages[stage].append((name, run))
+        return out
+
+    def same_conv_b8(self, stage, name, srcs, wkey, bkey, out, *, stride=(1, 1), act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE):
+        """PadSameConv2d + Conv2d (+ activation), model/layers.py:241-252,329-335, on the B8 kernel."""
+        w = self.sd[wkey]
+        _, _, _, hs, ws = self._act_info(srcs[0])
+        kh, kw = w.shape[2], w.shape[3]
+        pt, _ = same_pad(hs, kh, stride[0])
+        pl, _ = same_pad(ws, kw, stride[1])
+        grid = (math.ceil(hs / stride[0]), math.ceil(ws / stride[1]))
+        return self.conv_b8(stage, name, srcs, w, self.sd[bkey] if bkey else None, out, stride=stride, pad=(pt, pl), grid=grid, act=act, p0=p0)
+
+    def conv_relu2_b8(self, stage, name, srcs, prefix, mid, out, stride=1):
+        """layers.ConvReLU2 (model/layers.py:308-314): k x 1 stride (s,1), then 1 x k stride (1,s)."""
+        self.same_conv_b8(stage, name + ".conv_y", srcs, prefix + ".conv_y.weight", prefix + ".conv_y.bias", mid, stride=(stride, 1))
+        return self.same_conv_b8(stage, name + ".conv_x", [mid], prefix + ".conv_x.weight", prefix + ".conv_x.bias", out, stride=(1, stride))
+
+    def refine_b8(self, stage, name, srcs, prefix, out):
+        """layers.Refine (model/layers.py:389-397): the four output parities as the four phases of one launch."""
+        wt = self.sd[prefix + ".conv2d_t.weight"]
+        _, _, _, h, w = self._act_info(srcs[0])
+        phases = [(wp, pt, pl, py, px) for (py, px), (wp, pt, pl) in transposed_phase_weights(wt).items()]
+        return self.conv_b8(stage, name, srcs, None, self.sd[prefix + ".conv2d_t.bias"], out, grid=(h, w), act=ACT_LEAKY_RELU, p0=LEAKY_SLOPE,
+                            out_step=(2, 2), phases=phases)
+
+    def upconv_b8(self, stage, name, srcs, wkey, bkey, out):
+        """layers.Upconv (model/layers.py:349-356) phase-decomposed on the low-resolution input (upconv_phase_weights)."""
+        _, n, _, h, w = self._act_info(srcs[0])
+        cout, cin = self.sd[wkey].shape[:2]
+        phases = [(wp, 0, 0, py, px) for (py, px), wp in upconv_phase_weights(self.sd[wkey]).items()]
+        return self.conv_b8(stage, name, srcs, None, self.sd[bkey] if bkey else None, out, grid=(h, w), act=ACT_NONE, out_step=(2, 2), phases=phases,
+                            ref_macs=n * 4 * h * w * cout * cin * 4)
+
     def add(self, stage, name, fn):
         self.stages[stage].append((name, fn))
 
@@ -983,6 +1126,11 @@ class Plan:
             self.add(st, "cost_volume", run_cv)
         with_mask = self.pretrain_mode in (0, 2)
         with_depth = self.pretrain_mode != 2
+        self.feats = feats
+        if (self.b8 and self.pretrain_mode == 0 and not self.no_cv and not self.simple_mask and self.mask_use_cv and self.mask_use_feats and
+                self.one_channel_kernels):
+            return self._build_mask_depth_b8(feats, sfcv, cv, kf)
+        self.b8 = False                    # the option variants keep the fp32-storage path
 
         # ---------------- MaskModule (monorec_model.py:345-385), frames batched as F*B ----------------
         am = "att_module"
@@ -1157,6 +1305,126 @@ class Plan:
             self.add(st, "depth.heads", run_heads)
             self.aux_log.append(dict(name="depth.heads", ref_macs=sum(int(s_.shape[0] * s_.shape[1] * s_.shape[2] * s_.shape[3]) * 9
                                                                        for _, s_, _ in heads)))
+        self.preds = preds
+
+    def _build_mask_depth_b8(self, feats, sfcv, cv, kf):
+        """MaskModule (monorec_model.py:345-385) and DepthModule (:526-557) of the full model in the bf16 MFMA mode with B8 activation
+        storage (csrc/conv_b8.hip).  Dense fp32 stay: what the path hands out (single-frame / fused volumes, image features, `cv_mask`,
+        the four depth scales) and the maps the HBM-bound one-channel kernels read (classifier input; the four head inputs)."""
+        B, H, W, F, D = self.B, self.H, self.W, self.F, self.D
+        sd, lib = self.sd, self.lib
+        am, dm = "att_module", "depth_module"
+        st = "cv"
+        enc_ch = (int(sd[f"{am}.enc.0.0.conv.weight"].shape[0]), 48, 64, 96, 96)
+        enc_ch = tuple(int(sd[f"{am}.enc.{i}.{0 if i == 0 else 1}.conv.weight"].shape[0]) for i in range(5))
+        x = sfcv.view(F * B, D, H, W)
+        cvf = []
+        for i in range(5):
+            hi, wi = H >> i, W >> i
+            i0, i1 = (0, 1) if i == 0 else (1, 2)       # index 0 of stages 1-4 is the MaxPool
+            a = self.alloc_b8(f"mask.enc{i}.a", F * B, enc_ch[i], hi, wi)
+            xo = self.alloc_b8(f"mask.enc{i}.x", F * B, enc_ch[i], hi, wi)
+            self.same_conv_b8(st, f"mask.enc{i}.0", [x], f"{am}.enc.{i}.{i0}.conv.weight", f"{am}.enc.{i}.{i0}.conv.bias", a)
+            self.same_conv_b8(st, f"mask.enc{i}.1", [a], f"{am}.enc.{i}.{i1}.conv.weight", f"{am}.enc.{i}.{i1}.conv.bias", xo)
+            m = self.alloc_b8(f"mask.cvf{i}", B, enc_ch[i], hi, wi)
+            cvf.append(m)
+            planes = B * ((enc_ch[i] + 7) // 8)
+            if i < 4:
+                xp = self.alloc_b8(f"mask.enc{i + 1}.pool", F * B, enc_ch[i], hi // 2, wi // 2)
+
+                def run_pool_max(stream, src=xo, dst=xp, mx=m, planes=planes, hh_=hi, ww_=wi):
+                    _lib.check(lib.mr_pool2x2_framemax_b8(src.data_ptr(), dst.data_ptr(), mx.data_ptr(), F, planes, hh_, ww_, stream),
+                               "mr_pool2x2_framemax_b8")
+                self.add(st, f"mask.poolmax{i}", run_pool_max)
+                x = xp
+            else:
+                def run_max(stream, src=xo, dst=m, count=planes * hi * wi):
+                    _lib.check(lib.mr_max_over_frames_b8(src.data_ptr(), dst.data_ptr(), F, count, stream), "mr_max_over_frames_b8")
+                self.add(st, f"mask.max{i}", run_max)
+        st = "main"
+        x_srcs = [cvf[4], feats[3]]                                                  # :372
+        for i in range(4):
+            hi, wi = H >> (3 - i), W >> (3 - i)
+            up_ch = int(sd[f"{am}.dec.{i}.0.conv.weight"].shape[0])
+            dec_ch = int(sd[f"{am}.dec.{i}.1.conv.weight"].shape[0])
+            u = self.alloc_b8(f"mask.dec{i}.up", B, up_ch, hi, wi)
+            self.upconv_b8(st, f"mask.dec{i}.0", x_srcs, f"{am}.dec.{i}.0.conv.weight", f"{am}.dec.{i}.0.conv.bias", u)   # layers.py:349-356
+            cat = [cvf[3 - i], u] if i == 3 else [cvf[3 - i], feats[2 - i], u]       # :374-380
+            a = self.alloc_b8(f"mask.dec{i}.a", B, dec_ch, hi, wi)
+            # the last decoder map feeds the classifier kernel (csrc/heads.hip), which reads dense fp32
+            xo = self.alloc(f"mask.dec{i}.x", B, dec_ch, hi, wi) if i == 3 else self.alloc_b8(f"mask.dec{i}.x", B, dec_ch, hi, wi)
+            self.same_conv_b8(st, f"mask.dec{i}.1", cat, f"{am}.dec.{i}.1.conv.weight", f"{am}.dec.{i}.1.conv.bias", a)
+            self.same_conv_b8(st, f"mask.dec{i}.2", [a], f"{am}.dec.{i}.2.conv.weight", f"{am}.dec.{i}.2.conv.bias", xo)
+            x_srcs = [xo]
+        cv_mask = self.alloc("cv_mask", B, 1, H, W)
+        feat = x_srcs[0]
+        cw_ = self._dev(sd[f"{am}.classifier.0.weight"].reshape(-1))
+        cb_ = self._dev(sd[f"{am}.classifier.0.bias"].reshape(-1))
+        cv_ref, mask_ref = self.ref(cv), self.ref(cv_mask)
+
+        def run_classifier(stream, feat=feat, cw_=cw_, cb_=cb_):
+            _lib.check(lib.mr_mask_classifier_f32(feat.data_ptr(), cw_.data_ptr(), cb_.data_ptr(), B, int(feat.shape[1]), H * W,
+                                                  mask_ref.ptr(), cv_ref.ptr(), D, stream), "mr_mask_classifier_f32")
+        self.add(st, "mask.classifier", run_classifier)
+        self.aux_log.append(dict(name="mask.classifier", ref_macs=B * H * W * int(feat.shape[1])))
+
+        # ---------------- DepthModule ----------------
+        enc_spec = tuple((int(sd[f"{dm}.enc.{i}.0.conv_y.weight"].shape[0]), k, s_)
+                         for i, (k, s_) in enumerate(((7, 1), (7, 2), (5, 2), (5, 2), (3, 2))))
+        dch = [int(sd[f"{dm}.dec.0.conv2d_t.weight"].shape[1]), int(sd[f"{dm}.dec.1.0.conv2d_t.weight"].shape[1]),
+               int(sd[f"{dm}.dec.2.0.conv2d_t.weight"].shape[1]), int(sd[f"{dm}.dec.3.conv2d_t.weight"].shape[1]),
+               int(sd[f"{dm}.dec.4.0.conv_y.weight"].shape[0]), int(sd[f"{dm}.dec.4.2.weight"].shape[0])]
+        x_srcs = [cv, kf]                                                            # :531
+        dfe = []
+        hh, ww = H, W
+        for i, (ch, _, s_) in enumerate(enc_spec):
+            h2, w2 = hh // s_, ww // s_
+            mid0 = self.alloc_b8(f"depth.enc{i}.0.mid", B, ch, h2, ww)
+            o0 = self.alloc_b8(f"depth.enc{i}.0.out", B, ch, h2, w2)
+            self.conv_relu2_b8(st, f"depth.enc{i}.0", x_srcs, f"{dm}.enc.{i}.0", mid0, o0, stride=s_)
+            mid1 = self.alloc_b8(f"depth.enc{i}.1.mid", B, ch, h2, w2)
+            o1 = self.alloc_b8(f"depth.enc{i}.1.out", B, ch, h2, w2)
+            self.conv_relu2_b8(st, f"depth.enc{i}.1", [o0], f"{dm}.enc.{i}.1", mid1, o1)
+            dfe.append(o1)
+            x_srcs, hh, ww = [o1], h2, w2
+        lo, hi_ = self.inv_depth_min_max[1], self.inv_depth_min_max[0]
+        # the maps the depth heads read (csrc/heads.hip) stay dense fp32: r0, x1, x2, x4
+        r0 = self.alloc("depth.dec0", B, dch[0], H // 8, W // 8)
+        self.refine_b8(st, "depth.dec0", [dfe[4]], f"{dm}.dec.0", r0)
+        r1 = self.alloc_b8("depth.dec1.t", B, dch[1], H // 4, W // 4)
+        self.refine_b8(st, "depth.dec1.0", [dfe[3], feats[2], r0], f"{dm}.dec.1.0", r1)  # :545
+        m1 = self.alloc_b8("depth.dec1.mid", B, dch[1], H // 4, W // 4)
+        x1 = self.alloc("depth.dec1", B, dch[1], H // 4, W // 4)
+        self.conv_relu2_b8(st, "depth.dec1.1", [r1], f"{dm}.dec.1.1", m1, x1)
+        r2 = self.alloc_b8("depth.dec2.t", B, dch[2], H // 2, W // 2)
+        self.refine_b8(st, "depth.dec2.0", [dfe[2], feats[1], x1], f"{dm}.dec.2.0", r2)
+        m2 = self.alloc_b8("depth.dec2.mid", B, dch[2], H // 2, W // 2)
+        x2 = self.alloc("depth.dec2", B, dch[2], H // 2, W // 2)
+        self.conv_relu2_b8(st, "depth.dec2.1", [r2], f"{dm}.dec.2.1", m2, x2)
+        x3 = self.alloc_b8("depth.dec3", B, dch[3], H, W)
+        self.refine_b8(st, "depth.dec3", [dfe[1], feats[0], x2], f"{dm}.dec.3", x3)
+        m4 = self.alloc_b8("depth.dec4.mid", B, dch[4], H, W)
+        x4a = self.alloc_b8("depth.dec4.a", B, dch[4], H, W)
+        self.conv_relu2_b8(st, "depth.dec4.0", [dfe[0], x3], f"{dm}.dec.4.0", m4, x4a)   # :543
+        x4 = self.alloc("depth.dec4", B, dch[5], H, W)
+        self.same_conv_b8(st, "depth.dec4.2", [x4a], f"{dm}.dec.4.2.weight", f"{dm}.dec.4.2.bias", x4)
+        heads = [(0, r0, 3), (1, x1, 2), (2, x2, 1), (3, x4, 0)]
+        preds = [None] * 4
+        descs = (HeadDesc * len(heads))()
+        for i, (idx, src, slot) in enumerate(heads):
+            p = self.alloc(f"pred{slot}", B, 1, int(src.shape[2]), int(src.shape[3]))
+            preds[slot] = p
+            w_ = self._dev(sd[f"{dm}.predictors.{idx}.1.weight"])
+            b_ = self._dev(sd[f"{dm}.predictors.{idx}.1.bias"].reshape(-1))
+            descs[i].src, descs[i].weight, descs[i].bias, descs[i].dst = src.data_ptr(), w_.data_ptr(), b_.data_ptr(), p.data_ptr()
+            descs[i].batch, descs[i].channels, descs[i].height, descs[i].width = [int(v) for v in src.shape]
+            self.keep += [src, p]
+        self.keep.append(descs)
+
+        def run_heads(stream, descs=descs, n=len(heads)):
+            _lib.check(lib.mr_depth_heads_f32(descs, n, lo, hi_, stream), "mr_depth_heads_f32")
+        self.add(st, "depth.heads", run_heads)
+        self.aux_log.append(dict(name="depth.heads", ref_macs=sum(int(s_.shape[0] * s_.shape[1] * s_.shape[2] * s_.shape[3]) * 9 for _, s_, _ in heads)))
         self.preds = preds
 
     # ------------------------------------------------------------------ inputs

@@ -1023,3 +1023,76 @@ def test_forward_slot_avoids_uncollected_handles_of_copying_plans():
         m._forward_slot(prep)
     h.collected = True
     assert m._forward_slot(prep) == 0
+
+
+# ------------------------------------------------------------------------------------------ bf16 MFMA path with B8 activation storage
+def test_b8_conv_desc_layout_matches_the_c_struct():
+    fields = ", ".join(f'offsetof(mr_b8_conv_desc, {n})' for n, _ in _lib.B8ConvDesc._fields_)
+    src = f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(){{ size_t o[] = {{{fields}}};' \
+          'printf("%zu", sizeof(mr_b8_conv_desc)); for (unsigned i = 0; i < sizeof(o)/sizeof(o[0]); ++i) printf(" %zu", o[i]); return 0; }'
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", c, "-o", exe], check=True)
+        vals = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_lib.B8ConvDesc)
+    assert vals[1:] == [getattr(_lib.B8ConvDesc, n).offset for n, _ in _lib.B8ConvDesc._fields_]
+
+
+def test_b8_weight_packing(hip_lib):
+    """mr_b8_pack_weights: the bf16 A-fragment stream of csrc/conv_b8.hip - [cout group of 16 mb][chunk of 32 channels, source-major][tap]
+    [cout block][64 lanes][8]; lane l = (cout l & 15, channel block l >> 4 of the chunk), element e = channel 8 (l >> 4) + e of the chunk;
+    chunks never straddle sources; padded channels / couts are zero; values rounded to bf16, nearest even."""
+    g = torch.Generator().manual_seed(21)
+    srcs_c, cout, kh, kw, mb = [5, 44], 40, 3, 2, 2
+    cin, taps = sum(srcs_c), kh * kw
+    w = torch.randn(cout, cin, kh, kw, generator=g)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    nch = [((c + 7) // 8 + 3) // 4 for c in srcs_c]                  # 1 + 2 chunks
+    groups = ((cout + 15) // 16 + mb - 1) // mb
+    n = hip_lib.mr_b8_packed_weight_bytes(cout, sc, len(srcs_c), kh, kw, mb)
+    assert n == groups * sum(nch) * taps * mb * 1024
+    packed = torch.empty(n // 2, dtype=torch.bfloat16)
+    _lib.check(hip_lib.mr_b8_pack_weights(w.data_ptr(), cout, sc, len(srcs_c), kh, kw, mb, packed.data_ptr()))
+    st = packed.float().view(groups, sum(nch), taps, mb, 64, 8)
+    wb = w.to(torch.bfloat16).float().view(cout, cin, taps)
+    q0, cin_off = 0, 0
+    for c, nq in zip(srcs_c, nch):
+        for q in range(nq):
+            for lane in range(64):
+                for e in range(8):
+                    cl = q * 32 + (lane >> 4) * 8 + e
+                    for gi in range(groups):
+                        for m in range(mb):
+                            co = (gi * mb + m) * 16 + (lane & 15)
+                            exp = wb[co, cin_off + cl] if (co < cout and cl < c) else torch.zeros(taps)
+                            assert torch.equal(st[gi, q0 + q, :, m, lane, e], exp), (co, cl)
+        q0, cin_off = q0 + nq, cin_off + c
+    assert hip_lib.mr_b8_pack_weights(w.data_ptr(), cout, sc, len(srcs_c), kh, kw, 5, packed.data_ptr()) == -1
+
+
+def test_bf16_mode_plan_stores_mask_and_depth_activations_in_b8(hip_lib, monkeypatch):
+    """hip_bf16=True: the mask and depth nets run on mr_conv2d_b8 with B8 activations between their convolutions; dense fp32 stay the
+    path's outputs and the maps the one-channel kernels read; MR_B8=0 and the option variants keep the fp32-storage path."""
+    m = MonoRecModel(cv_depth_steps=32)
+    sd = synth.seeded_state_dict(m.state_dict())
+    plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", bf16=1)
+    b8 = [c for c in plan.conv_log if c.get("b8")]
+    assert plan.b8 and len(b8) == 53 and len(plan.conv_log) == 73 and all(c["name"].startswith("resnet.") for c in plan.conv_log if not c.get("b8"))
+    assert abs(plan.conv_ref_macs() / 1e9 - (61.07 - 0.068)) < 0.01          # the reference's conv multiply-adds, as in the fp32 plan
+    by = {c["name"]: c for c in b8}
+    assert by["mask.enc0.0"]["spec"]["src_layouts"] == [0] and by["mask.enc0.0"]["spec"]["out_layout"] == 1       # fp32 single-frame volumes in
+    assert by["mask.dec1.1"]["spec"]["src_layouts"] == [1, 0, 1]                                                   # B8 / fp32 image features / B8
+    assert by["depth.enc0.0.conv_y"]["spec"]["src_layouts"] == [0, 0]                                              # fused volume + keyframe
+    fp32_out = {c["name"] for c in b8 if c["spec"]["out_layout"] == 0}
+    assert fp32_out == {"mask.dec3.2", "depth.dec0", "depth.dec1.1.conv_x", "depth.dec2.1.conv_x", "depth.dec4.2"}     # classifier / head inputs
+    assert all(0 < c["lds"] <= 160 * 1024 for c in b8)
+    assert plan.buf["mask.enc0.x"].dtype == torch.bfloat16 and tuple(plan.buf["mask.enc0.x"].shape) == (2, 4, 256, 512, 8)
+    assert plan.buf["cost_volume"].dtype == torch.float32 and plan.buf["feat2"].dtype == torch.float32 and plan.buf["pred0"].dtype == torch.float32
+    assert plan.outputs_rebindable and {r[3] for r in plan._relocs} >= {"cost_volume", "sfcv", "feat0", "feat1", "feat2", "pred0", "pred3"}
+    monkeypatch.setenv("MR_B8", "0")
+    old = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", bf16=1)
+    assert not old.b8 and not any(c.get("b8") for c in old.conv_log) and all(c["bf16"] == 1 for c in old.conv_log)
+    monkeypatch.delenv("MR_B8")
+    var = engine.Plan(sd, 1, 64, 96, 2, 32, (0.33, 0.0025), "cpu", bf16=1, mask_use_feats=False)
+    assert not var.b8 and not any(c.get("b8") for c in var.conv_log)

@@ -103,7 +103,7 @@ def main():
         for k, v in agg.items():
             short = short_kernel_name(k)
             summary[short] = v
-            if "conv_mfma_kernel" in k or "conv3x3_wino" in k or "convt4x4_wino" in k or "conv1d3_wino" in k or "conv1d_ct_kernel" in k or "upconv2x2_wino" in k:
+            if "conv_mfma_kernel" in k or "conv_b8_kernel" in k or "conv3x3_wino" in k or "convt4x4_wino" in k or "conv1d3_wino" in k or "conv1d_ct_kernel" in k or "upconv2x2_wino" in k:
                 for cn, d in v.items():
                     conv[cn] += d["sum"]
                 conv_n += next(iter(v.values()))["dispatches"]

@@ -278,6 +278,17 @@ int mr_conv2d_b8(const mr_b8_conv_desc* desc, void* stream);
  * src (frames, planes, h, w) 16-byte groups, planes = batch * channel blocks -> pooled (frames, planes, h/2, w/2), fmax (planes, h, w) */
 int mr_pool2x2_framemax_b8(const void* src, void* pooled, void* fmax, int32_t frames, int64_t planes, int32_t h, int32_t w, void* stream);
 int mr_max_over_frames_b8(const void* src, void* dst, int32_t frames, int64_t groups16, void* stream);
+/* The two producers of the nets' fp32 inputs, writing a B8 copy on the side so that the first layers read no fp32 volume:
+ * mr_cost_volume_b8_f32 = mr_cost_volume_mode_f32 of the default configuration (3x3 patch, sfcv * mask; 32 / 48 / 64 depth steps) with
+ * sfcv_b8[f] = (batch, num_depths / 8, height, width, 8) bf16 per frame next to the dense single-frame volumes (which stay the outputs);
+ * mr_mask_classifier_b8_f32 = mr_mask_classifier_f32 with the masked volume (monorec_model.py:713) also as
+ * cost_volume_b8 = (batch, num_depths / 8, plane, 8) bf16 (num_depths % 16 == 0). */
+int mr_cost_volume_b8_f32(const float* keyframe, const float* const* frames, int32_t num_frames, const float* kinv, const float* proj,
+                          const float* depths, int32_t batch, int32_t num_depths, int32_t height, int32_t width, float alpha,
+                          const float* channel_weights, int32_t use_ssim, const float* pixel_depths, float* cost_volume,
+                          float* const* sfcv, void* const* sfcv_b8, void* stream);
+int mr_mask_classifier_b8_f32(const float* features, const float* weight, const float* bias, int32_t batch, int32_t channels, int64_t plane,
+                              float* cv_mask, float* cost_volume, int32_t num_depths, void* cost_volume_b8, void* stream);
 /* layout conversions: dense fp32 (n, c, hw) <-> B8 (n, ceil(c/8), hw, 8) bf16 */
 int mr_f32_nchw_to_b8(const float* src, void* dst, int32_t n, int32_t c, int64_t hw, void* stream);
 int mr_b8_to_f32_nchw(const void* src, float* dst, int32_t n, int32_t c, int64_t hw, void* stream);

@@ -85,7 +85,8 @@ DIAGNOSTIC = {"conv_mfma.hip": "-DMR_CONV_TIMELINE",     # per-workgroup timesta
               "cost_volume.hip": "-DMR_TUNING_ENV",      # MR_CV_MARCH_TY / MR_CV_MARCH_DP / MR_CV_NO_KF_PREPASS (tools/bench_cv.py sweeps)
               "heads.hip": "-DMR_TUNING_ENV",            # MR_HEADS_QUAD_MIN (tools/bench_heads.py)
               "conv1d_wino.hip": "-DMR_DIAGNOSTIC_FORMS",   # the F(2,7) instantiations
-              "eltwise.hip": "-DMR_DIAGNOSTIC_FORMS"}       # MR_LAUNCH_WINO44 in mr_run_launches
+              "eltwise.hip": "-DMR_DIAGNOSTIC_FORMS",       # MR_LAUNCH_WINO44 in mr_run_launches
+              "conv_b8.hip": "-DMR_B8_ABLATE"}              # MR_B8_DBG ablation bits (tools/bench_b8.py)
 
 
 def build_timeline(verbose=False):

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 
@@ -56,11 +57,20 @@ struct B8Args {
     int act;
     float p0;
     int tiles_x, TH, IH, IW, PLANE;
+    int ntiles, tiles_per_wg;        // a workgroup walks tiles_per_wg consecutive tiles
     int nphase, batch;
     const void* w[4];
     long long wgroup_bytes[4];       // packed bytes per cout group
     int KHp[4], KWp[4], PT[4], PL[4], ooff_h[4], ooff_w[4];
+    int dbg;                         // diagnostic library only (MR_B8_DBG): 1 skip the sweep, 2 skip the input staging, 4 skip the weight DMA, 8 skip the stores
 };
+
+// ablation switches exist only in the diagnostic library (python -m monorec_amd.build --timeline, -DMR_B8_ABLATE): compile-time 0 in the product
+#ifdef MR_B8_ABLATE
+#define B8_DBG(bit) (a.dbg & (bit))
+#else
+#define B8_DBG(bit) 0
+#endif
 
 __device__ __forceinline__ void dma_buffer_x4(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
     unsigned keep;
@@ -102,72 +112,101 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {          // two fl
     return __builtin_bit_cast(unsigned, h);
 }
 
-template <int MB, int NB, int WV>
+// WRES: the whole weight stream of the workgroup's cout group (all K chunks) is loaded into LDS ONCE and stays there while the workgroup
+// walks `tiles_per_wg` consecutive tiles - the layers with few input channels (every full-resolution layer of the two nets) would
+// otherwise re-load 27-36 KB of weights per chunk and tile and expose the first chunk's latency in every workgroup (first hardware
+// run, r04_s2: mask.enc0.1 at 289 us = 1.4 TB/s).  The input pipeline runs across tile boundaries: chunk 0 of the next tile streams in
+// while the last chunk of the current tile is swept.
+// element s (0..2, wave-uniform) of a kernel-argument array without dynamic indexing (which would move the array to scratch)
+template <typename T>
+__device__ __forceinline__ T pick3(const T (&v)[MR_MAX_SOURCES], int s) { return s == 0 ? v[0] : (s == 1 ? v[1] : v[2]); }
+template <typename T>
+__device__ __forceinline__ T pick4(const T (&v)[4], int p) { return p == 0 ? v[0] : (p == 1 ? v[1] : (p == 2 ? v[2] : v[3])); }
+
+// F32SRC: some source is dense fp32 (register-staged path compiled in; 64 VGPRs of staging registers)
+template <int MB, int NB, int WV, bool WRES, bool F32SRC>
 __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x, grp = blockIdx.y;
+    const int grp = blockIdx.y;
     int z = blockIdx.z;
     const int ph = a.nphase == 4 ? (z & 3) : 0;
     const int b = a.nphase == 4 ? z >> 2 : z;
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * a.TH, ox0 = tx * 32;
-    const int iy_base = oy0 * a.SH - a.PT[ph], ix_base = ox0 * a.SW - a.PL[ph];
-    const int KH = a.KHp[ph], KW = a.KWp[ph], T = KH * KW;
+    const int KH = pick4(a.KHp, ph), KW = pick4(a.KWp, ph), T = KH * KW;
+    const int PT = pick4(a.PT, ph), PL = pick4(a.PL, ph), ooff_h = pick4(a.ooff_h, ph), ooff_w = pick4(a.ooff_w, ph);
     const int PLANE = a.PLANE;
-    const int stage_bytes = 64 * PLANE + 1024 * a.KH * a.KW * MB;      // [4 blocks][PLANE] x 16 B + [taps][MB][64 lanes] x 16 B
     const int wchunk_bytes = T * MB * 1024;
-
-    // ---- fixed staging positions of this thread: p = tid + 64 WV j -> (iy, ix) of the haloed tile ------------------------------------
-    int gpix[B8_MAX_PPT];                // gy * Ws + gx, or -1 outside the image / the tile
-    bool live[B8_MAX_PPT];
-#pragma unroll
-    for (int j = 0; j < B8_MAX_PPT; ++j) {
-        const int p = tid + 64 * WV * j;
-        const int iy = p / a.IW, ix = p - iy * a.IW;
-        const int gy = iy_base + iy, gx = ix_base + ix;
-        live[j] = p < PLANE;
-        gpix[j] = (live[j] && gy >= 0 && gy < a.Hs && gx >= 0 && gx < a.Ws) ? gy * a.Ws + gx : -1;
-    }
+    const int wres_bytes = WRES ? a.nchunks * a.KH * a.KW * MB * 1024 : 0;           // resident weights in front of the two stages
+    const int stage_bytes = 64 * PLANE + (WRES ? 0 : 1024 * a.KH * a.KW * MB);       // [4 blocks][PLANE] x 16 B (+ [taps][MB][64 lanes] x 16 B)
+    const int tile_begin = blockIdx.x * a.tiles_per_wg;
+    const int tile_end = min(tile_begin + a.tiles_per_wg, a.ntiles);
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
-    const unsigned char* wgrp = (const unsigned char*)a.w[ph] + (long long)grp * a.wgroup_bytes[ph];
+    const unsigned char* wgrp = (const unsigned char*)pick4(a.w, ph) + (long long)grp * pick4(a.wgroup_bytes, ph);
     const int HsWs = a.Hs * a.Ws;
 
-    // ---- staging ------------------------------------------------------------------------------------------------------------------------
-    // weights + B8 inputs: LDS-DMA, nothing to wait for until the barrier.  fp32 NCHW inputs: loaded into `stg` here (8 channel planes per
-    // position), converted and written to LDS by stage_store() AFTER the sweep of the previous chunk - the loads fly during the sweep.
-    float stg[B8_MAX_PPT][4][8];
-    auto source_of = [&](int q, int& s, int& blk0) {
-        s = 0;
+    if (WRES && !B8_DBG(4)) {
+        const int pieces = a.nchunks * T * MB;                                         // 1 KiB each, contiguous in the packed stream
+        for (int kb = wave; kb < pieces; kb += WV) dma_global_x4(lds_base + kb * 1024, wgrp + (long long)kb * 1024 + lane * 16);
+    }
+
+    // ---- load cursor: the next (tile, chunk) to stage; positions p = tid + 64 WV j of the haloed tile -> global pixel of that tile ---------
+    int ltile = tile_begin, lq = 0;
+    int gpix[B8_MAX_PPT];                // gy * Ws + gx, or -1 outside the image
+    bool live[B8_MAX_PPT];
 #pragma unroll
-        for (int i = 1; i < MR_MAX_SOURCES; ++i)
-            if (i < a.nsrc && q >= a.src_q0[i]) s = i;
-        blk0 = (q - a.src_q0[s]) * 4;
+    for (int j = 0; j < B8_MAX_PPT; ++j) live[j] = tid + 64 * WV * j < PLANE;
+    auto place = [&](int tile) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int iy_base = ty * a.TH * a.SH - PT, ix_base = tx * 32 * a.SW - PL;
+#pragma unroll
+        for (int j = 0; j < B8_MAX_PPT; ++j) {
+            const int p = tid + 64 * WV * j;
+            const int iy = p / a.IW, ix = p - iy * a.IW;
+            const int gy = iy_base + iy, gx = ix_base + ix;
+            gpix[j] = (live[j] && gy >= 0 && gy < a.Hs && gx >= 0 && gx < a.Ws) ? gy * a.Ws + gx : -1;
+        }
+    };
+    place(ltile);
+
+    // weights (unless resident) + B8 inputs: LDS-DMA, nothing to wait for until the barrier.  fp32 NCHW inputs: loaded into `stg` here (8
+    // channel planes per position), converted and written to LDS by stage_store() AFTER the sweep of the previous chunk - the loads fly
+    // during the sweep.
+    float stg[F32SRC ? B8_MAX_PPT : 1][4][8];
+    auto source_of = [&](int q, int& s, int& blk0) {
+        s = (a.nsrc > 2 && q >= a.src_q0[2]) ? 2 : ((a.nsrc > 1 && q >= a.src_q0[1]) ? 1 : 0);
+        blk0 = (q - pick3(a.src_q0, s)) * 4;
     };
     auto issue = [&](int q, int pb) {
-        const unsigned buf = lds_base + pb * stage_bytes;
-        const unsigned wbuf = buf + 64 * PLANE;
-        const unsigned char* wsrc = wgrp + (long long)q * wchunk_bytes;
-        for (int kb = wave; kb < T * MB; kb += WV) dma_global_x4(wbuf + kb * 1024, wsrc + kb * 1024 + lane * 16);
+        const unsigned buf = lds_base + wres_bytes + pb * stage_bytes;
+        if (!WRES && !B8_DBG(4)) {
+            const unsigned wbuf = buf + 64 * PLANE;
+            const unsigned char* wsrc = wgrp + (long long)q * wchunk_bytes;
+            for (int kb = wave; kb < T * MB; kb += WV) dma_global_x4(wbuf + kb * 1024, wsrc + kb * 1024 + lane * 16);
+        }
+        if (B8_DBG(2)) return;
         int s, blk0;
         source_of(q, s, blk0);
-        if (a.src_layout[s] == MR_LAYOUT_BF16_B8) {
-            const i32x4 srd = make_srd(a.src[s], a.src_bytes[s]);
+        const void* sp = pick3(a.src, s);
+        const int sbytes = pick3(a.src_bytes, s);
+        if (!F32SRC || pick3(a.src_layout, s) == MR_LAYOUT_BF16_B8) {
+            const int scb = pick3(a.src_cb, s);
+            const i32x4 srd = make_srd(sp, sbytes);
 #pragma unroll
             for (int j = 0; j < B8_MAX_PPT; ++j) {
                 if (!live[j]) continue;                                   // EXEC masks lanes beyond the tile
                 const unsigned lrow = buf + (wave * 64 + 64 * WV * j) * 16;      // wave-uniform; lane l lands at + 16 l
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool bok = blk0 + k < a.src_cb[s];              // padded blocks of the chunk read as zero
-                    const int so = ((b * a.src_cb[s] + (bok ? blk0 + k : 0)) * HsWs) * 16;
+                    const bool bok = blk0 + k < scb;                      // padded blocks of the chunk read as zero
+                    const int so = ((b * scb + (bok ? blk0 + k : 0)) * HsWs) * 16;
                     dma_buffer_x4(lrow + k * PLANE * 16, (bok && gpix[j] >= 0) ? gpix[j] * 16 : -1, srd, so);
                 }
             }
-        } else {
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[s], 0, a.src_bytes[s], 0x00020000);
+        } else if (F32SRC) {
+            const int sc = pick3(a.src_c, s);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sp, 0, sbytes, 0x00020000);
 #pragma unroll
             for (int j = 0; j < B8_MAX_PPT; ++j) {
                 if (!live[j]) continue;
@@ -176,18 +215,19 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int c = (blk0 + k) * 8 + e;                 // wave-uniform
-                        const bool cok = c < a.src_c[s];
-                        const int so = ((b * a.src_c[s] + (cok ? c : 0)) * HsWs) * 4;
-                        stg[j][k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (cok && gpix[j] >= 0) ? gpix[j] * 4 : -1, so, 0));
+                        const bool cok = c < sc;
+                        const int so = ((b * sc + (cok ? c : 0)) * HsWs) * 4;
+                        stg[F32SRC ? j : 0][k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (cok && gpix[j] >= 0) ? gpix[j] * 4 : -1, so, 0));
                     }
             }
         }
     };
     auto stage_store = [&](int q, int pb) {
+        if (!F32SRC || B8_DBG(2)) return;
         int s, blk0;
         source_of(q, s, blk0);
-        if (a.src_layout[s] == MR_LAYOUT_BF16_B8) return;
-        unsigned char* buf = lds + pb * stage_bytes;
+        if (pick3(a.src_layout, s) == MR_LAYOUT_BF16_B8) return;
+        unsigned char* buf = lds + wres_bytes + pb * stage_bytes;
 #pragma unroll
         for (int j = 0; j < B8_MAX_PPT; ++j) {
             if (!live[j]) continue;
@@ -195,12 +235,19 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 i32x4 v;
-                v.x = (int)pack2(stg[j][k][0], stg[j][k][1]);
-                v.y = (int)pack2(stg[j][k][2], stg[j][k][3]);
-                v.z = (int)pack2(stg[j][k][4], stg[j][k][5]);
-                v.w = (int)pack2(stg[j][k][6], stg[j][k][7]);
+                const int jj = F32SRC ? j : 0;
+                v.x = (int)pack2(stg[jj][k][0], stg[jj][k][1]);
+                v.y = (int)pack2(stg[jj][k][2], stg[jj][k][3]);
+                v.z = (int)pack2(stg[jj][k][4], stg[jj][k][5]);
+                v.w = (int)pack2(stg[jj][k][6], stg[jj][k][7]);
                 *(i32x4*)(buf + (k * PLANE + p) * 16) = v;
             }
+        }
+    };
+    auto advance = [&]() {                                                // load cursor to the next (tile, chunk)
+        if (++lq == a.nchunks) {
+            lq = 0;
+            if (++ltile < tile_end) place(ltile);
         }
     };
 
@@ -213,70 +260,170 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         pcol[i] = (pb_ & 1) * 16 + (lane & 15);
         lbase[i] = ((lane >> 4) * PLANE + prow[i] * a.SH * a.IW + pcol[i] * a.SW) * 16;
     }
-    f32x4 acc[MB][NB];
+    const int g4 = (lane >> 4) * 4;
+    // activation as ONE branch-free form: x > 0 ? x : x * slope with slope 1 (none), 0 (ReLU), p0 (LeakyReLU) - a switch per element compiled
+    // into ~190 scalar branches per tile epilogue (r04_s6: 3 us of every 12 us tile)
+    const float slope = a.act == MR_ACT_RELU ? 0.f : (a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f);
+    // bias of this lane's output channels: once per workgroup (a load per tile costs a memory round trip each - 1 us of the 12 us tile)
+    float bias[MB][4];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) {
+            const int co = (grp * MB + m) * 16 + g4 + r;
+            bias[m][r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+    // B8 destination: a tile's results wait, packed, in `pend` and are stored while the NEXT tile's first chunk is swept (r04_s5: stored right
+    // behind the last sweep, 8 bytes per lane, they cost 90 of the 218 us of mask.enc0.1 - every chunk barrier waits for vmcnt(0)).  Two
+    // pixel blocks at a time: lanes (pixel, channel quad g) and (pixel, g ^ 1) swap halves through the LDS crossbar (ds_swizzle, no LDS
+    // memory), so that every lane stores one complete 16-byte group - 256 contiguous bytes per 16 lanes.
+    constexpr int NPAIR = NB >= 2 ? NB / 2 : 1;
+    i32x4 pend[MB][NPAIR];
+    int pend_tile = -1;
+    const bool b8_out = a.dst_layout == MR_LAYOUT_BF16_B8;
+    const int dcb = (a.Cout + 7) >> 3;
+    auto flush = [&]() {
+        if (pend_tile < 0) return;
+        const int ty = pend_tile / a.tiles_x, tx = pend_tile - ty * a.tiles_x;
+        const int oy0 = ty * a.TH, ox0 = tx * 32;
+        pend_tile = -1;
+        if (B8_DBG(8)) return;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int blk = ((grp * MB + m) * 16 + g4) >> 3;
+            if (blk >= dcb) continue;
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                if (NB >= 2) {
+                    const int i = 2 * pr + ((lane >> 4) & 1);             // even quad: the pair's first pixel block, odd quad: its second
+                    const int oy = oy0 + (wave * NB + i) / 2, ox = ox0 + ((wave * NB + i) & 1) * 16 + (lane & 15);
+                    if (oy >= a.Ho || ox >= a.Wo) continue;
+                    const int dy = oy * a.ostep_h + ooff_h, dx = ox * a.ostep_w + ooff_w;
+                    *((i32x4*)a.dst + (((long long)b * dcb + blk) * a.dst_H + dy) * a.dst_W + dx) = pend[m][pr];
+                } else {                                                  // one pixel block per wave: 8 bytes per lane
+                    const int oy = oy0 + wave / 2, ox = ox0 + (wave & 1) * 16 + (lane & 15);
+                    if (oy >= a.Ho || ox >= a.Wo) continue;
+                    const int dy = oy * a.ostep_h + ooff_h, dx = ox * a.ostep_w + ooff_w;
+                    unsigned long long* o = (unsigned long long*)a.dst + ((((long long)b * dcb + blk) * a.dst_H + dy) * a.dst_W + dx) * 2 + ((g4 >> 2) & 1);
+                    *o = (unsigned long long)(unsigned)pend[m][0].x | ((unsigned long long)(unsigned)pend[m][0].y << 32);
+                }
+            }
+        }
+    };
 
     issue(0, 0);
     stage_store(0, 0);
-    for (int q = 0; q < a.nchunks; ++q) {
-        const int pb = q & 1;
-        const unsigned char* buf = lds + pb * stage_bytes;
-        const unsigned char* wl = buf + 64 * PLANE + lane * 16;
-        dma_wait_all();
-        __syncthreads();                                      // chunk q visible; everyone is done with the other buffer
-        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
-        for (int kh = 0; kh < KH; ++kh)
-            for (int kw = 0; kw < KW; ++kw) {
-                const int tapoff = (kh * a.IW + kw) * 16;
-                bf16x8 av[MB], bv[NB];
+    advance();
+    int pb = 0;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        f32x4 acc[MB][NB];
 #pragma unroll
-                for (int m = 0; m < MB; ++m) av[m] = *(const bf16x8*)(wl + ((kh * KW + kw) * MB + m) * 1024);
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < a.nchunks; ++q) {
+            const unsigned char* buf = lds + wres_bytes + pb * stage_bytes;
+            const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
+            dma_wait_all();
+            __syncthreads();                                  // this chunk (and the resident weights) visible; everyone is done with the other buffer
+            const bool more = ltile < tile_end;               // wave-uniform
+            const int nq = lq;
+            if (more) issue(nq, pb ^ 1);
+            if (q == 0) flush();                              // the previous tile's results leave while this chunk is swept
+            // taps flattened and software-pipelined over two register sets: the fragments of tap t + 1 are on their way from LDS while the
+            // MB * NB MFMAs of tap t issue (first hardware run: one set, 20 % of the MFMA rate - every tap waited out its own ds_reads)
+            bf16x8 av0[MB], bv0[NB], av1[MB], bv1[NB];
+            auto frags = [&](bf16x8 (&av)[MB], bf16x8 (&bv)[NB], int t, int tapoff) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) av[m] = *(const bf16x8*)(wl + (t * MB + m) * 1024);
 #pragma unroll
                 for (int i = 0; i < NB; ++i) bv[i] = *(const bf16x8*)(buf + lbase[i] + tapoff);
+            };
+            auto mfmas = [&](const bf16x8 (&av)[MB], const bf16x8 (&bv)[NB]) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[i], acc[m][i], 0, 0, 0);
-            }
-        if (q + 1 < a.nchunks) stage_store(q + 1, pb ^ 1);    // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
-    }
-
-    // ---- epilogue: D fragment lane l holds pixel (l & 15), couts (l >> 4) * 4 + r ------------------------------------------------------------
-    const int g4 = (lane >> 4) * 4;
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        const int cout0 = (grp * MB + m) * 16 + g4;
-        if (cout0 >= a.CB16 * 16) continue;
-        float bias[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = (a.bias && cout0 + r < a.Cout) ? a.bias[cout0 + r] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
-            if (oy >= a.Ho || ox >= a.Wo) continue;
-            const int dy = oy * a.ostep_h + a.ooff_h[ph], dx = ox * a.ostep_w + a.ooff_w[ph];
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (cout0 + r < a.Cout) ? act1(acc[m][i][r] + bias[r], a.act, a.p0) : 0.f;
-            if (a.dst_layout == MR_LAYOUT_BF16_B8) {
-                const int dcb = (a.Cout + 7) >> 3;
-                if ((cout0 >> 3) < dcb) {
-                    unsigned long long* o = (unsigned long long*)a.dst +
-                                            ((((long long)b * dcb + (cout0 >> 3)) * a.dst_H + dy) * a.dst_W + dx) * 2 + ((cout0 >> 2) & 1);
-                    *o = (unsigned long long)pack2(v[0], v[1]) | ((unsigned long long)pack2(v[2], v[3]) << 32);
+            };
+            int kh = 0, kw = 0;                                   // tap t + 1 as (kh, kw)
+            auto next_off = [&]() {
+                if (++kw == KW) { kw = 0; ++kh; }
+                return (kh * a.IW + kw) * 16;
+            };
+            if (!B8_DBG(1)) frags(av0, bv0, 0, 0);
+            for (int t = 0; t < (B8_DBG(1) ? 0 : T); t += 2) {
+                if (t + 1 < T) frags(av1, bv1, t + 1, next_off());
+                mfmas(av0, bv0);
+                if (t + 1 < T) {
+                    if (t + 2 < T) frags(av0, bv0, t + 2, next_off());
+                    mfmas(av1, bv1);
                 }
-            } else {
-                float* o = (float*)a.dst + (((long long)b * a.Cout + cout0) * a.dst_H + dy) * a.dst_W + dx;
-                const long long chs = (long long)a.dst_H * a.dst_W;
+            }
+            if (more) {
+                stage_store(nq, pb ^ 1);                      // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
+                advance();
+            }
+            pb ^= 1;
+        }
+
+        // ---- epilogue of the tile: D fragment lane l holds pixel (l & 15), couts (l >> 4) * 4 + r ------------------------------------------
+        if (b8_out) {
+            const bool odd = (lane >> 4) & 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (cout0 + r < a.Cout) o[r * chs] = v[r];
+            for (int m = 0; m < MB; ++m) {
+                const int cout0 = (grp * MB + m) * 16 + g4;
+                unsigned lo[NB], hi[NB];                           // this lane's 4 channels of every pixel block, as bf16
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[m][i][r] + bias[m][r];          // (padded channels: zero weights and zero bias give 0)
+                        v[r] = x > 0.f ? x : x * slope;
+                    }
+                    lo[i] = pack2(v[0], v[1]);
+                    hi[i] = pack2(v[2], v[3]);
+                }
+                if (NB >= 2) {
+#pragma unroll
+                    for (int pr = 0; pr < NPAIR; ++pr) {
+                        // even quad keeps block 2 pr and needs the partner's half of it; odd quad keeps block 2 pr + 1: each sends the other one
+                        const unsigned slo = odd ? lo[2 * pr] : lo[2 * pr + 1], shi = odd ? hi[2 * pr] : hi[2 * pr + 1];
+                        const unsigned rlo = (unsigned)__builtin_amdgcn_ds_swizzle((int)slo, 0x401F);     // lane ^ 16
+                        const unsigned rhi = (unsigned)__builtin_amdgcn_ds_swizzle((int)shi, 0x401F);
+                        pend[m][pr] = odd ? (i32x4){(int)rlo, (int)rhi, (int)lo[2 * pr + 1], (int)hi[2 * pr + 1]}
+                                          : (i32x4){(int)lo[2 * pr], (int)hi[2 * pr], (int)rlo, (int)rhi};
+                    }
+                } else {
+                    pend[m][0] = (i32x4){(int)lo[0], (int)hi[0], 0, 0};
+                }
+            }
+            pend_tile = tile;
+        } else if (!B8_DBG(8)) {
+            const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+            const int oy0 = ty * a.TH, ox0 = tx * 32;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int cout0 = (grp * MB + m) * 16 + g4;
+                if (cout0 >= a.Cout) continue;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
+                    if (oy >= a.Ho || ox >= a.Wo) continue;
+                    const int dy = oy * a.ostep_h + ooff_h, dx = ox * a.ostep_w + ooff_w;
+                    float* o = (float*)a.dst + (((long long)b * a.Cout + cout0) * a.dst_H + dy) * a.dst_W + dx;
+                    const long long chs = (long long)a.dst_H * a.dst_W;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cout0 + r < a.Cout) {
+                            const float x = acc[m][i][r] + bias[m][r];
+                            o[r * chs] = x > 0.f ? x : x * slope;
+                        }
+                }
             }
         }
     }
+    flush();
 }
 
 // ---- element-wise companions on B8 tensors ------------------------------------------------------------------------------------------------
@@ -355,6 +502,7 @@ struct B8Derived {
     dim3 grid;
     size_t lds_bytes;
     int mb, nb, wv;
+    bool wres;
 };
 
 bool valid_mb8(int mb) { return mb >= 1 && mb <= 4; }
@@ -420,27 +568,54 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     k.IW = 31 * k.SW + k.KW;
     k.PLANE = k.IH * k.IW;
     if ((k.PLANE + 64 * wv - 1) / (64 * wv) > B8_MAX_PPT) return MR_ERR_UNSUPPORTED;
-    out->lds_bytes = 2 * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);
+    const long long ntiles = (long long)k.tiles_x * tiles_y;
+    if (ntiles >= (1ll << 31) || ngroups >= 65536 || (long long)d->batch * nphase >= 65536) return MR_ERR_UNSUPPORTED;
+    k.ntiles = (int)ntiles;
+    // resident weights where the whole stream of a cout group fits next to the two input stages (every layer with few input channels)
+    const size_t wall = (size_t)nchunks * k.KH * k.KW * mb * 1024;
+    const size_t tile2 = 2 * (size_t)64 * k.PLANE;
+    out->wres = wall + tile2 <= 160 * 1024 && wall <= 112 * 1024;
+    if (out->wres) {
+        out->lds_bytes = wall + tile2;
+        const long long jobs = ntiles * ngroups * d->batch * nphase;
+        long long tpw = (jobs + 1023) / 1024;                 // ~4 workgroups per CU over the launch, each keeps its weights for tpw tiles
+        if (tpw < 1) tpw = 1;
+        if (tpw > 32) tpw = 32;
+        k.tiles_per_wg = (int)tpw;
+    } else {
+        out->lds_bytes = 2 * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);
+        k.tiles_per_wg = 1;
+    }
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;
-    if ((long long)k.tiles_x * tiles_y >= (1ll << 31) || ngroups >= 65536 || (long long)d->batch * nphase >= 65536) return MR_ERR_UNSUPPORTED;
-    out->grid = dim3((unsigned)(k.tiles_x * tiles_y), (unsigned)ngroups, (unsigned)(d->batch * nphase));
+    out->grid = dim3((unsigned)((ntiles + k.tiles_per_wg - 1) / k.tiles_per_wg), (unsigned)ngroups, (unsigned)(d->batch * nphase));
     out->mb = mb; out->nb = nb; out->wv = wv;
+#ifdef MR_B8_ABLATE
+    { const char* e = getenv("MR_B8_DBG"); k.dbg = e ? atoi(e) : 0; }
+#endif
     return 0;
 }
 
-template <int MB, int NB, int WV>
-int launch8(const B8Derived& dv, hipStream_t stream) {
+template <int MB, int NB, int WV, bool WRES, bool F32SRC>
+int launch8w(const B8Derived& dv, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_set{0};      // dynamic-LDS ceiling once per instantiation AND device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b8_kernel<MB, NB, WV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b8_kernel<MB, NB, WV, WRES, F32SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_b8_kernel<MB, NB, WV>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
+    hipLaunchKernelGGL((conv_b8_kernel<MB, NB, WV, WRES, F32SRC>), dv.grid, dim3(WV * 64), dv.lds_bytes, stream, dv.k);
     return (int)hipGetLastError();
+}
+
+template <int MB, int NB, int WV>
+int launch8(const B8Derived& dv, hipStream_t stream) {
+    bool f32 = false;
+    for (int s = 0; s < dv.k.nsrc; ++s) f32 = f32 || dv.k.src_layout[s] == MR_LAYOUT_F32_NCHW;
+    if (f32) return dv.wres ? launch8w<MB, NB, WV, true, true>(dv, stream) : launch8w<MB, NB, WV, false, true>(dv, stream);
+    return dv.wres ? launch8w<MB, NB, WV, true, false>(dv, stream) : launch8w<MB, NB, WV, false, false>(dv, stream);
 }
 
 template <int MB>

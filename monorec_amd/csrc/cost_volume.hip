@@ -54,6 +54,8 @@ struct CvArgs {
     float rwm1, rhm1;     // fp32(1 / wm1), fp32(1 / hm1)
     int fast_w, fast_h;   // 1: the 3-instruction sequence div_const() equals the correctly rounded quotient for EVERY fp32 dividend
                           // (checked exhaustively on the host, mr_exact_const_division); 0: IEEE division
+    void* sfcv_b8[MR_MAX_FRAMES];   // optional second copy of the single-frame volumes in the channel-blocked bf16 layout of csrc/conv_b8.hip
+                                    // ((B, D / 8, H, W, 8) bf16 per frame; the bf16 MFMA mode's mask encoder reads it), or null
 };
 
 // a / 9.0f in 3 instructions instead of the ~10 of the IEEE division sequence: q0 = a*y, r = fma(-9, q0, a),
@@ -743,7 +745,17 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
 
 // Per-pixel frame fusion with the raw sads of a pixel held in registers: every sad is read once, every output written once
 // (cv_fuse_kernel reads the F*D raw values three times - twice from L2).  Same arithmetic, same order.
-template <int DD>
+__device__ __forceinline__ unsigned cv_pack_bf16x2(float a, float b) {      // round to nearest even, a in the low half
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// B8OUT: besides the dense fp32 single-frame volumes (the path's outputs, written exactly as before) every pixel's D values of a frame
+// also leave as D / 8 groups of 8 bf16 (16 bytes each) - the layout the bf16 MFMA mode's first mask-encoder layer consumes without
+// the register-staged fp32 reads (r04_s5: 170 of that layer's 470 us at 512x1024).  The kernel is VALU-bound; the extra stores are free.
+template <int DD, bool B8OUT>
 __global__ __launch_bounds__(256) void cv_fuse_reg_kernel(const CvArgs a) {
     const int HWp = a.H * a.W;
     const int b = blockIdx.y;
@@ -780,11 +792,21 @@ __global__ __launch_bounds__(256) void cv_fuse_reg_kernel(const CvArgs a) {
         float w = 1.0f - a.inv_dm1 * (se - 1.0f);                        // :258
         w = w * vm;                                                      // :260
         wsum = f == 0 ? w : wsum + w;                                    // :264
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t* b8 = B8OUT ? (u32x4_t*)a.sfcv_b8[f] + (long long)b * (DD / 8) * HWp : nullptr;
 #pragma unroll
-        for (int d = 0; d < DD; ++d) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((1.0f - v[d] * 2.0f) * vm), sf, voff, d * HWp * 4, 0);   // :251
-            const float t = v[d] * w;                                    // :262
-            num[d] = f == 0 ? t : num[d] + t;
+        for (int d0 = 0; d0 < DD; d0 += 8) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = d0 + j;
+                o[j] = (1.0f - v[d] * 2.0f) * vm;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[j]), sf, voff, d * HWp * 4, 0);   // :251
+                const float t = v[d] * w;                                // :262
+                num[d] = f == 0 ? t : num[d] + t;
+            }
+            if (B8OUT && p < HWp)
+                b8[(long long)(d0 / 8) * HWp + p] = (u32x4_t){cv_pack_bf16x2(o[0], o[1]), cv_pack_bf16x2(o[2], o[3]), cv_pack_bf16x2(o[4], o[5]), cv_pack_bf16x2(o[6], o[7])};
         }
     }
     const bool nz = wsum != 0.f;
@@ -1070,9 +1092,10 @@ void launch_fuse(const CvArgs& k, bool plane_flags, bool tiled, hipStream_t stre
     const long long total = (long long)k.B * k.H * k.W;
     if (!plane_flags && !tiled && (k.D == 32 || k.D == 48 || k.D == 64)) {
         const dim3 grid((unsigned)(((long long)k.H * k.W + 255) / 256), (unsigned)k.B);
-        if (k.D == 32) hipLaunchKernelGGL(cv_fuse_reg_kernel<32>, grid, dim3(256), 0, stream, k);
-        else if (k.D == 48) hipLaunchKernelGGL(cv_fuse_reg_kernel<48>, grid, dim3(256), 0, stream, k);
-        else hipLaunchKernelGGL(cv_fuse_reg_kernel<64>, grid, dim3(256), 0, stream, k);
+        const bool b8 = k.sfcv_b8[0] != nullptr;
+        if (k.D == 32) { if (b8) hipLaunchKernelGGL((cv_fuse_reg_kernel<32, true>), grid, dim3(256), 0, stream, k); else hipLaunchKernelGGL((cv_fuse_reg_kernel<32, false>), grid, dim3(256), 0, stream, k); }
+        else if (k.D == 48) { if (b8) hipLaunchKernelGGL((cv_fuse_reg_kernel<48, true>), grid, dim3(256), 0, stream, k); else hipLaunchKernelGGL((cv_fuse_reg_kernel<48, false>), grid, dim3(256), 0, stream, k); }
+        else { if (b8) hipLaunchKernelGGL((cv_fuse_reg_kernel<64, true>), grid, dim3(256), 0, stream, k); else hipLaunchKernelGGL((cv_fuse_reg_kernel<64, false>), grid, dim3(256), 0, stream, k); }
         return;
     }
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -1230,7 +1253,7 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
                       float alpha, const float* channel_weights, int32_t use_ssim,
                       const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size, bool tiled,
-                      float* cost_volume, float* const* sfcv, void* stream) {
+                      float* cost_volume, float* const* sfcv, void* stream, void* const* sfcv_b8 = nullptr) {
     if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
     if (patch_size < 1 || patch_size > 7 || !(patch_size & 1)) return MR_ERR_UNSUPPORTED;
     if (!sfcv_mult_mask && num_depths < num_frames) return MR_ERR_UNSUPPORTED;      // validity words live in planes 0..F-1
@@ -1243,8 +1266,11 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
     for (int f = 0; f < MR_MAX_FRAMES; ++f) {
         a.frames[f] = f < num_frames ? frames[f] : nullptr;
         a.sfcv[f] = f < num_frames ? sfcv[f] : nullptr;
-        if (f < num_frames && (!a.frames[f] || !a.sfcv[f])) return MR_ERR_BAD_ARGUMENT;
+        a.sfcv_b8[f] = (sfcv_b8 && f < num_frames) ? sfcv_b8[f] : nullptr;
+        if (f < num_frames && (!a.frames[f] || !a.sfcv[f] || (sfcv_b8 && !a.sfcv_b8[f]))) return MR_ERR_BAD_ARGUMENT;
     }
+    // the bf16 copy is written by the register-held fusion kernel of the default configuration only
+    if (sfcv_b8 && !(patch_size == 3 && sfcv_mult_mask && !tiled && (num_depths == 32 || num_depths == 48 || num_depths == 64))) return MR_ERR_UNSUPPORTED;
     a.kinv = kinv; a.proj = proj; a.depths = depths; a.pix_depths = pixel_depths; a.cv = cost_volume;
     a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
     a.tiles_x = 0; a.nchunk = 1; a.dchunk = num_depths;
@@ -1318,6 +1344,18 @@ extern "C" int mr_cost_volume_mode_f32(const float* keyframe, const float* const
                                        float* cost_volume, float* const* sfcv, void* stream) {
     return mr_cost_volume_patch_f32(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
                                     channel_weights, use_ssim, pixel_depths, sfcv_mult_mask, 3, cost_volume, sfcv, stream);
+}
+
+// mr_cost_volume_mode_f32 of the default configuration (3x3 patch, sfcv * mask, 32 / 48 / 64 depth steps) that ALSO writes every
+// single-frame volume in the channel-blocked bf16 layout of mr_conv2d_b8: sfcv_b8[f] = (batch, num_depths / 8, height, width, 8) bf16.
+extern "C" int mr_cost_volume_b8_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                     const float* kinv, const float* proj, const float* depths,
+                                     int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                     float alpha, const float* channel_weights, int32_t use_ssim, const float* pixel_depths,
+                                     float* cost_volume, float* const* sfcv, void* const* sfcv_b8, void* stream) {
+    if (!sfcv_b8) return MR_ERR_BAD_ARGUMENT;
+    return cost_volume_entry(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                             channel_weights, use_ssim, pixel_depths, 1, 3, false, cost_volume, sfcv, stream, sfcv_b8);
 }
 
 extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,

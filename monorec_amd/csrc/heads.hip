@@ -170,10 +170,19 @@ __device__ __forceinline__ float vget(float2 v, int i) { return i ? v.y : v.x; }
 __device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
 __device__ __forceinline__ void vset(float2& v, int i, float x) { if (i) v.y = x; else v.x = x; }
 
+__device__ __forceinline__ unsigned hd_pack_bf16x2(float a, float b) {      // round to nearest even, a in the low half
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// cvb8 (optional; D % 16 == 0): the masked volume once more in the channel-blocked bf16 layout of csrc/conv_b8.hip - what the first
+// layer of the depth net reads in the bf16 MFMA mode instead of staging the fp32 volume through registers
 template <int VEC>
 __global__ __launch_bounds__(256) void mask_classifier_kernel(const float* __restrict__ feat_, const float* __restrict__ w,
                                                               const float* __restrict__ bias, int C, long long planev, long long totalv,
-                                                              float* __restrict__ mask_, float* cv_, int D) {
+                                                              float* __restrict__ mask_, float* cv_, int D, u32x4* __restrict__ cvb8) {
     typedef typename VecF<VEC>::type V;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= totalv) return;
@@ -223,6 +232,17 @@ __global__ __launch_bounds__(256) void mask_classifier_kernel(const float* __res
                 for (int j = 0; j < VEC; ++j) vset(t[u], j, keep[j] * vget(t[u], j));
                 v[(long long)(d + u) * planev] = t[u];
             }
+            if (cvb8) {
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const int u0 = h8 * 8;
+                        cvb8[((b * (D >> 3) + ((d >> 3) + h8)) * planev + p) * VEC + j] =
+                            (u32x4){hd_pack_bf16x2(vget(t[u0], j), vget(t[u0 + 1], j)), hd_pack_bf16x2(vget(t[u0 + 2], j), vget(t[u0 + 3], j)),
+                                    hd_pack_bf16x2(vget(t[u0 + 4], j), vget(t[u0 + 5], j)), hd_pack_bf16x2(vget(t[u0 + 6], j), vget(t[u0 + 7], j))};
+                    }
+            }
         }
         for (; d < D; ++d) {
             V t = v[(long long)d * planev];
@@ -270,9 +290,29 @@ extern "C" int mr_depth_heads_f32(const mr_head_desc* heads, int32_t num_heads, 
     return (int)hipGetLastError();
 }
 
+namespace {
+int mask_classifier_launch(const float* features, const float* weight, const float* bias, int32_t batch, int32_t channels, int64_t plane,
+                           float* cv_mask, float* cost_volume, int32_t num_depths, void* cv_b8, void* stream);
+}
+
 extern "C" int mr_mask_classifier_f32(const float* features, const float* weight, const float* bias, int32_t batch,
                                       int32_t channels, int64_t plane, float* cv_mask, float* cost_volume, int32_t num_depths,
                                       void* stream) {
+    return mask_classifier_launch(features, weight, bias, batch, channels, plane, cv_mask, cost_volume, num_depths, nullptr, stream);
+}
+
+// mr_mask_classifier_f32 that ALSO writes the masked cost volume in the channel-blocked bf16 layout of mr_conv2d_b8:
+// cost_volume_b8 = (batch, num_depths / 8, plane, 8) bf16; num_depths % 16 == 0, cost_volume required.
+extern "C" int mr_mask_classifier_b8_f32(const float* features, const float* weight, const float* bias, int32_t batch,
+                                         int32_t channels, int64_t plane, float* cv_mask, float* cost_volume, int32_t num_depths,
+                                         void* cost_volume_b8, void* stream) {
+    if (!cost_volume || !cost_volume_b8 || (num_depths & 15)) return MR_ERR_BAD_ARGUMENT;
+    return mask_classifier_launch(features, weight, bias, batch, channels, plane, cv_mask, cost_volume, num_depths, cost_volume_b8, stream);
+}
+
+namespace {
+int mask_classifier_launch(const float* features, const float* weight, const float* bias, int32_t batch, int32_t channels, int64_t plane,
+                           float* cv_mask, float* cost_volume, int32_t num_depths, void* cv_b8, void* stream) {
     if (!features || !weight || !bias || !cv_mask || batch < 1 || channels < 1 || plane < 2 || (plane & 1)) return MR_ERR_BAD_ARGUMENT;
     if (cost_volume && num_depths < 1) return MR_ERR_BAD_ARGUMENT;
     // one pixel per thread while that still leaves the chip short of waves (<= 2 workgroups of 256 per CU), two beyond
@@ -282,9 +322,10 @@ extern "C" int mr_mask_classifier_f32(const float* features, const float* weight
     if (blocks >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
     if (vec == 1)
         hipLaunchKernelGGL(mask_classifier_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, features, weight, bias,
-                           channels, planev, totalv, cv_mask, cost_volume, num_depths);
+                           channels, planev, totalv, cv_mask, cost_volume, num_depths, (u32x4*)cv_b8);
     else
         hipLaunchKernelGGL(mask_classifier_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, features, weight, bias,
-                           channels, planev, totalv, cv_mask, cost_volume, num_depths);
+                           channels, planev, totalv, cv_mask, cost_volume, num_depths, (u32x4*)cv_b8);
     return (int)hipGetLastError();
 }
+}  // namespace

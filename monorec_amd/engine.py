@@ -914,20 +914,25 @@ class Plan:
         return LAYOUT_F32_NCHW, int(t.shape[0]), int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
 
     @staticmethod
-    def b8_schedule(cout, out_h, out_w, kh, kw, sh, sw, batch, phases):
+    def b8_schedule(cout, out_h, out_w, kh, kw, sh, sw, batch, phases, f32_source=False):
         """(MB, NB, waves) of a mr_conv2d_b8 launch: as many of the output channels per workgroup as 4 blocks of 16 allow (the input tile
         is then read once), 8 waves x 2 pixel blocks (8 x 32 pixels) where that still gives every CU two workgroups, smaller tiles below;
         bounded by the 160 KB of LDS and two staged tile positions per thread (csrc/conv_b8.hip: derive8)."""
         cb16 = (cout + 15) // 16
         mb = cb16 if cb16 <= 4 else (4 if cb16 % 4 == 0 else (3 if cb16 % 3 == 0 else 4))
         groups = math.ceil(cb16 / mb)
-        for waves, nb in ((8, 2), (4, 2), (4, 1)):
+        import os
+        # 16 x 32 pixel tiles first for the 2-D filters (7 LDS fragment reads per 12 MFMAs instead of 5 per 6: the 3x3 layers of 512x1024
+        # gain 7-13 %, the k x 1 / 1 x k layers lose 20-30 %: r04_s4); MR_B8_NB4=0: A/B aid.  (>= 3 output blocks with 4 pixel blocks spill
+        # next to the fp32 staging registers.)
+        first = ((8, 4),) if (os.environ.get("MR_B8_NB4", "1") != "0" and not (mb >= 3 and f32_source) and kh > 1 and kw > 1) else ()
+        for waves, nb in first + ((8, 2), (4, 2), (4, 1)):
             th = waves * nb // 2
             ih, iw = (th - 1) * sh + kh, 31 * sw + kw
             plane = ih * iw
             wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * groups * batch * phases
             lds = 2 * (64 * plane + 1024 * kh * kw * mb)
-            if lds <= 160 * 1024 and plane <= 2 * 64 * waves and (wgs >= 512 or (waves, nb) == (4, 1)):
+            if lds <= 160 * 1024 and plane <= 2 * 64 * waves and (wgs >= (1024 if nb == 4 else 512) or (waves, nb) == (4, 1)):
                 return mb, nb, waves
         for waves, nb in ((8, 2), (8, 1), (4, 2), (4, 1)):          # whatever launches
             th = waves * nb // 2
@@ -953,7 +958,8 @@ class Plan:
         out_h, out_w = grid
         olay, on, oc, oh, ow = self._act_info(out)
         assert on == n and oc == cout and out.is_contiguous(), (name, on, n, oc, cout)
-        mb, nb, waves = self.schedule_override.get(name) or self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist))
+        mb, nb, waves = self.schedule_override.get(name) or self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist),
+                                                                             f32_source=any(i[0] == LAYOUT_F32_NCHW for i in infos))
         d = B8ConvDesc()
         sc = (ctypes.c_int32 * len(srcs))(*src_channels)
         for i, s_ in enumerate(srcs):
@@ -1107,9 +1113,15 @@ class Plan:
         kinv, proj, depths = self.buf["kinv"], self.buf["proj"], self.buf["depths"]
         cv_ref = self.ref(cv)
 
+        self._sfcv_b8_ptrs = None          # bf16 MFMA mode: pointer array of the B8 copies of the single-frame volumes (see _build_mask_depth_b8)
+
         def run_cv(stream):
             pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
-            if self.cv_patch_size == 3:
+            if self._sfcv_b8_ptrs is not None:
+                _lib.check(lib.mr_cost_volume_b8_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                                     depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
+                                                     cv_ref.ptr(), sfcv_ptrs, self._sfcv_b8_ptrs, stream), "mr_cost_volume_b8_f32")
+            elif self.cv_patch_size == 3:
                 _lib.check(lib.mr_cost_volume_mode_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                        depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                        1 if self.sfcv_mult_mask else 0,
@@ -1318,6 +1330,15 @@ class Plan:
         enc_ch = (int(sd[f"{am}.enc.0.0.conv.weight"].shape[0]), 48, 64, 96, 96)
         enc_ch = tuple(int(sd[f"{am}.enc.{i}.{0 if i == 0 else 1}.conv.weight"].shape[0]) for i in range(5))
         x = sfcv.view(F * B, D, H, W)
+        if D in (32, 48, 64) and self.cv_patch_size == 3 and self.sfcv_mult_mask:
+            # the fusion kernel of the cost volume writes every single-frame volume a second time in B8 (free: it is VALU-bound), so the
+            # first mask-encoder layer reads 2 bytes per element by LDS-DMA instead of staging 4-byte planes through registers
+            xb = self.alloc_b8("sfcv_b8", F * B, D, H, W)
+            per_frame = B * (D // 8) * H * W * 16
+            ptrs = (ctypes.c_void_p * F)(*[xb.data_ptr() + f * per_frame for f in range(F)])
+            self.keep.append(ptrs)
+            self._sfcv_b8_ptrs = ptrs
+            x = xb
         cvf = []
         for i in range(5):
             hi, wi = H >> i, W >> i
@@ -1361,10 +1382,15 @@ class Plan:
         cw_ = self._dev(sd[f"{am}.classifier.0.weight"].reshape(-1))
         cb_ = self._dev(sd[f"{am}.classifier.0.bias"].reshape(-1))
         cv_ref, mask_ref = self.ref(cv), self.ref(cv_mask)
+        cvb = self.alloc_b8("cost_volume_b8", B, D, H, W) if D % 16 == 0 else None     # the masked volume for the depth net, B8 copy
 
         def run_classifier(stream, feat=feat, cw_=cw_, cb_=cb_):
-            _lib.check(lib.mr_mask_classifier_f32(feat.data_ptr(), cw_.data_ptr(), cb_.data_ptr(), B, int(feat.shape[1]), H * W,
-                                                  mask_ref.ptr(), cv_ref.ptr(), D, stream), "mr_mask_classifier_f32")
+            if cvb is not None:
+                _lib.check(lib.mr_mask_classifier_b8_f32(feat.data_ptr(), cw_.data_ptr(), cb_.data_ptr(), B, int(feat.shape[1]), H * W,
+                                                         mask_ref.ptr(), cv_ref.ptr(), D, cvb.data_ptr(), stream), "mr_mask_classifier_b8_f32")
+            else:
+                _lib.check(lib.mr_mask_classifier_f32(feat.data_ptr(), cw_.data_ptr(), cb_.data_ptr(), B, int(feat.shape[1]), H * W,
+                                                      mask_ref.ptr(), cv_ref.ptr(), D, stream), "mr_mask_classifier_f32")
         self.add(st, "mask.classifier", run_classifier)
         self.aux_log.append(dict(name="mask.classifier", ref_macs=B * H * W * int(feat.shape[1])))
 
@@ -1374,7 +1400,7 @@ class Plan:
         dch = [int(sd[f"{dm}.dec.0.conv2d_t.weight"].shape[1]), int(sd[f"{dm}.dec.1.0.conv2d_t.weight"].shape[1]),
                int(sd[f"{dm}.dec.2.0.conv2d_t.weight"].shape[1]), int(sd[f"{dm}.dec.3.conv2d_t.weight"].shape[1]),
                int(sd[f"{dm}.dec.4.0.conv_y.weight"].shape[0]), int(sd[f"{dm}.dec.4.2.weight"].shape[0])]
-        x_srcs = [cv, kf]                                                            # :531
+        x_srcs = [cv if cvb is None else cvb, kf]                                    # :531
         dfe = []
         hh, ww = H, W
         for i, (ch, _, s_) in enumerate(enc_spec):

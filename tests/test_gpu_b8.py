@@ -67,8 +67,10 @@ def _run_b8(plan, srcs_cpu, layouts, weight, bias, out_c, out_hw, out_layout, **
 
 
 def _check(got, ref, out_layout, tag):
+    """`ref`: the UNROUNDED fp32 reference.  A B8 destination rounds it once to bf16: at most half a bf16 ulp = 2^-8 relative (comparing
+    against a rounded reference instead would flag every value whose fp32 sum lands on the other side of a rounding boundary)."""
     scale = max(1.0, float(ref.abs().max()))
-    if out_layout == LAYOUT_BF16_B8:        # one bf16 rounding of the output (2^-9 relative) on top of the fp32 accumulation-order noise
+    if out_layout == LAYOUT_BF16_B8:
         err = (got - ref).abs()
         tol = 2.0 ** -8 * ref.abs() + 1e-4 * scale
         assert bool((err <= tol).all()), (tag, float((err - tol).max()))
@@ -114,7 +116,7 @@ def test_conv_b8_matches_torch_on_bf16_rounded_operands(hip_lib, case):
     assert tuple(ref.shape[2:]) == (oh, ow)
     plan = engine.Plan.bare(DEV, schedule_override={"t": sched} if sched else None, bf16=1)
     got, _ = _run_b8(plan, srcs, lays, wt, bias, cout, (oh, ow), olay, stride=(sh, sw), pad=(pt, pl), grid=(oh, ow), act=act, p0=0.1)
-    _check(got, bf(ref) if olay == LAYOUT_BF16_B8 else ref, olay, B8_CASES[case])
+    _check(got, ref, olay, B8_CASES[case])
     log = plan.conv_log[0]
     assert log["b8"] and log["macs"] == batch * oh * ow * cout * cin * kh * kw and 0 < log["lds"] <= 160 * 1024
 
@@ -169,7 +171,7 @@ def test_b8_transposed_and_upsampling_layers(hip_lib, layer, olay):
     torch.cuda.synchronize()
     got = from_b8(out.cpu(), cout) if olay else out.cpu()
     assert torch.isfinite(got).all()
-    _check(got, bf(ref) if olay else ref, olay, (layer, olay))
+    _check(got, ref, olay, (layer, olay))
 
 
 def test_b8_pool_framemax_and_layout_conversions(hip_lib):
@@ -202,3 +204,57 @@ def test_b8_bad_arguments_are_rejected_without_a_launch(hip_lib):
     assert hip_lib.mr_conv2d_b8_lds_bytes(ctypes.byref(d)) == -1
     sc = (ctypes.c_int32 * 1)(16)
     assert hip_lib.mr_b8_packed_weight_bytes(16, sc, 1, 3, 3, 5) == 0 and hip_lib.mr_b8_packed_weight_bytes(16, sc, 1, 3, 3, 1) == 9 * 1024
+
+
+def test_cost_volume_and_classifier_write_their_b8_copies(hip_lib):
+    """mr_cost_volume_b8_f32 / mr_mask_classifier_b8_f32: the dense fp32 outputs are bit-identical to the plain entry points', and the B8
+    copies are those values rounded to bf16 (nearest even) in the (batch, D / 8, H, W, 8) layout."""
+    from monorec_amd import synth
+    from monorec_amd.model import MonoRecModel, host_geometry, depth_hypotheses
+    lib = hip_lib
+    b, h, w, nf, d = 2, 64, 96, 2, 32
+    batch = synth.make_batch(b, h, w, nf, seed=5)
+    kinv, proj = host_geometry(batch["keyframe_intrinsics"], batch["keyframe_pose"], batch["intrinsics"], batch["poses"])
+    kf = batch["keyframe"].to(DEV)
+    frames = [f.to(DEV) for f in batch["frames"]]
+    kinv_d, proj_d = kinv.to(DEV), proj.to(DEV)
+    depths = depth_hypotheses((0.33, 0.0025), d).to(DEV)
+    cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
+    fptr = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
+    outs = {}
+    for tag in ("plain", "b8"):
+        cv = torch.empty(b, d, h, w, device=DEV)
+        sf = torch.empty(nf, b, d, h, w, device=DEV)
+        sptr = (ctypes.c_void_p * nf)(*[sf[f].data_ptr() for f in range(nf)])
+        if tag == "plain":
+            _lib.check(lib.mr_cost_volume_mode_f32(kf.data_ptr(), fptr, nf, kinv_d.data_ptr(), proj_d.data_ptr(), depths.data_ptr(), b, d, h, w, 10.0, cw, 1, None, 1,
+                                                   cv.data_ptr(), sptr, _stream()), "cv")
+        else:
+            sfb = torch.full((nf * b, d // 8, h, w, 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+            bptr = (ctypes.c_void_p * nf)(*[sfb.data_ptr() + f * b * (d // 8) * h * w * 16 for f in range(nf)])
+            _lib.check(lib.mr_cost_volume_b8_f32(kf.data_ptr(), fptr, nf, kinv_d.data_ptr(), proj_d.data_ptr(), depths.data_ptr(), b, d, h, w, 10.0, cw, 1, None,
+                                                 cv.data_ptr(), sptr, bptr, _stream()), "cv b8")
+        torch.cuda.synchronize()
+        outs[tag] = (cv.cpu(), sf.cpu())
+    assert torch.equal(outs["plain"][0], outs["b8"][0]) and torch.equal(outs["plain"][1], outs["b8"][1])
+    want = outs["plain"][1].view(nf * b, d, h, w)
+    assert torch.equal(from_b8(sfb.cpu(), d), bf(want))
+    # classifier + mask multiply
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(b, 48, h, w, generator=g).to(DEV)
+    wgt, bias = (torch.randn(48, generator=g) * 0.2).to(DEV), torch.zeros(1, device=DEV)
+    res = {}
+    for tag in ("plain", "b8"):
+        cv = outs["plain"][0].clone().to(DEV)
+        mask = torch.empty(b, 1, h, w, device=DEV)
+        if tag == "plain":
+            _lib.check(lib.mr_mask_classifier_f32(feat.data_ptr(), wgt.data_ptr(), bias.data_ptr(), b, 48, h * w, mask.data_ptr(), cv.data_ptr(), d, _stream()), "cls")
+        else:
+            cvb = torch.full((b, d // 8, h, w, 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+            _lib.check(lib.mr_mask_classifier_b8_f32(feat.data_ptr(), wgt.data_ptr(), bias.data_ptr(), b, 48, h * w, mask.data_ptr(), cv.data_ptr(), d, cvb.data_ptr(),
+                                                     _stream()), "cls b8")
+        torch.cuda.synchronize()
+        res[tag] = (cv.cpu(), mask.cpu())
+    assert torch.equal(res["plain"][0], res["b8"][0]) and torch.equal(res["plain"][1], res["b8"][1])
+    assert torch.equal(from_b8(cvb.cpu(), d), bf(res["plain"][0]))
+    assert lib.mr_mask_classifier_b8_f32(feat.data_ptr(), wgt.data_ptr(), bias.data_ptr(), b, 48, h * w, mask.data_ptr(), cv.data_ptr(), 24, cvb.data_ptr(), _stream()) == -1

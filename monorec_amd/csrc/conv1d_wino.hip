@@ -78,12 +78,11 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
     return r;
 }
 
+// none / ReLU / LeakyReLU as ONE branch-free form (x > 0 ? x : x * slope, slope 1 / 0 / p0; the slope is wave-uniform and hoisted): as a
+// switch the compiler emitted scalar branches around every stored element of the epilogue (round 4: 200-450 branches per workgroup)
 __device__ __forceinline__ float act1(float v, int act, float p0) {
-    switch (act) {
-        case MR_ACT_RELU: return v > 0.f ? v : 0.f;
-        case MR_ACT_LEAKY_RELU: return v > 0.f ? v : v * p0;
-        default: return v;
-    }
+    const float slope = act == MR_ACT_RELU ? 0.f : (act == MR_ACT_LEAKY_RELU ? p0 : 1.f);
+    return v > 0.f ? v : v * slope;
 }
 
 template <int AXIS, int MBW>

@@ -155,17 +155,21 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
     int ltile = tile_begin, lq = 0;
     int gpix[B8_MAX_PPT];                // gy * Ws + gx, or -1 outside the image
     bool live[B8_MAX_PPT];
+    int piy[B8_MAX_PPT], pix_[B8_MAX_PPT];      // (row, column) of the position inside the tile: the same for every tile (one division per kernel)
 #pragma unroll
-    for (int j = 0; j < B8_MAX_PPT; ++j) live[j] = tid + 64 * WV * j < PLANE;
+    for (int j = 0; j < B8_MAX_PPT; ++j) {
+        const int p = tid + 64 * WV * j;
+        live[j] = p < PLANE;
+        piy[j] = p / a.IW;
+        pix_[j] = p - piy[j] * a.IW;
+    }
     auto place = [&](int tile) {
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int iy_base = ty * a.TH * a.SH - PT, ix_base = tx * 32 * a.SW - PL;
 #pragma unroll
         for (int j = 0; j < B8_MAX_PPT; ++j) {
-            const int p = tid + 64 * WV * j;
-            const int iy = p / a.IW, ix = p - iy * a.IW;
-            const int gy = iy_base + iy, gx = ix_base + ix;
-            gpix[j] = (live[j] && gy >= 0 && gy < a.Hs && gx >= 0 && gx < a.Ws) ? gy * a.Ws + gx : -1;
+            const int gy = iy_base + piy[j], gx = ix_base + pix_[j];
+            gpix[j] = (live[j] && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws) ? gy * a.Ws + gx : -1;
         }
     };
     place(ltile);
@@ -578,9 +582,13 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     if (out->wres) {
         out->lds_bytes = wall + tile2;
         const long long jobs = ntiles * ngroups * d->batch * nphase;
-        long long tpw = (jobs + 1023) / 1024;                 // ~4 workgroups per CU over the launch, each keeps its weights for tpw tiles
+        long long wgs_target = 1024;                          // ~4 workgroups per CU over the launch, each keeps its weights for tpw tiles
+#ifdef MR_B8_ABLATE
+        { const char* e = getenv("MR_B8_WGS"); if (e && atoi(e) > 0) wgs_target = atoi(e); }
+#endif
+        long long tpw = (jobs + wgs_target - 1) / wgs_target;
         if (tpw < 1) tpw = 1;
-        if (tpw > 32) tpw = 32;
+        if (tpw > 64) tpw = 64;
         k.tiles_per_wg = (int)tpw;
     } else {
         out->lds_bytes = 2 * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);

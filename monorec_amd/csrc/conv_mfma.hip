@@ -30,6 +30,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/monorec_hip.h"
 #include "conv_layout.h"
@@ -669,7 +670,11 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     }
     {
         // bias / residual operands are fetched in batches ahead of the stores that need them: a load issued
-        // between two stores would wait out a full memory round trip per output element
+        // between two stores would wait out a full memory round trip per output element.
+        // The activation of the common layers (none / ReLU / LeakyReLU) is ONE branch-free form, x > 0 ? x : x * slope (slope 1 / 0 / p0):
+        // as a switch per element it compiled into two scalar branches and an inlined tanh / exp body per stored value (r04: 180
+        // instructions per store in the <1,1> kernel, 59 branches for its 4 stores); the sigmoid / |tanh| layers keep the general form
+        // behind ONE uniform branch around the whole store loop.
         const long long chs = (long long)a.dst_H * a.dst_W;
         float bias[MB][4];
 #pragma unroll
@@ -680,35 +685,40 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
                 bias[m][r] = (a.bias && cout < a.Cout) ? a.bias[cout] : 0.f;
             }
         const long long bbase = (long long)b * a.dst_bstride;
+        const float slope = a.act == MR_ACT_RELU ? 0.f : (a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f);
+        auto store_all = [&](auto simple_tag) {
+            constexpr bool SIMPLE = decltype(simple_tag)::value;
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int cout0 = (cb0 + m) * 16 + lq4;
-            long long idx0[NB];
-            float rv[NB][4];
+            for (int m = 0; m < MB; ++m) {
+                const int cout0 = (cb0 + m) * 16 + lq4;
+                long long idx0[NB];
+                float rv[NB][4];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
-                const bool ok = oy < a.Ho && ox < a.Wo && (!KWS || ((m * NB + i) % WV) == wave);
-                idx0[i] = ok ? bbase + ((long long)(a.ch_off + cout0) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
-                                   (ox * a.ostep_w + a.ooff_w[ph])
-                             : -1;
+                for (int i = 0; i < NB; ++i) {
+                    const int oy = oy0 + prow[i], ox = ox0 + pcol[i];
+                    const bool ok = oy < a.Ho && ox < a.Wo && (!KWS || ((m * NB + i) % WV) == wave);
+                    idx0[i] = ok ? bbase + ((long long)(a.ch_off + cout0) * a.dst_H + (oy * a.ostep_h + a.ooff_h[ph])) * a.dst_W +
+                                       (ox * a.ostep_w + a.ooff_w[ph])
+                                 : -1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    rv[i][r] = (a.res && ok && cout0 + r < a.Cout) ? a.res[idx0[i] + r * chs] : 0.f;
+                    for (int r = 0; r < 4; ++r)
+                        rv[i][r] = (a.res && ok && cout0 + r < a.Cout) ? a.res[idx0[i] + r * chs] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (idx0[i] < 0) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cout0 + r < a.Cout) {
+                            float v = acc[m][i][r] + bias[m][r];              // (no bias: + 0)
+                            v += rv[i][r];                                    // (no residual: + 0)
+                            a.dst[idx0[i] + r * chs] = SIMPLE ? (v > 0.f ? v : v * slope) : mr_activate(v, a.act, a.p0, a.p1);
+                        }
+                }
             }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if (idx0[i] < 0) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (cout0 + r < a.Cout) {
-                        float v = acc[m][i][r];
-                        if (a.bias) v += bias[m][r];
-                        if (a.res) v += rv[i][r];
-                        a.dst[idx0[i] + r * chs] = mr_activate(v, a.act, a.p0, a.p1);
-                    }
-            }
-        }
+        };
+        if (a.act <= MR_ACT_LEAKY_RELU) store_all(std::true_type{});
+        else store_all(std::false_type{});
     }
     if (MR_DBG(16)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(a, 3); }
 }
@@ -766,12 +776,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue4_kernel(const ConvKArgs a
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) v += part[ks];
     f32x4 o;
+    const float slope = a.act == MR_ACT_RELU ? 0.f : (a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f);
+    if (a.act <= MR_ACT_LEAKY_RELU) {                 // branch-free form of none / ReLU / LeakyReLU (see conv_mfma_kernel's epilogue)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float x = v[r];
-        if (a.bias) x += bias;
-        if (a.res) x += rv[r];
-        o[r] = mr_activate(x, a.act, a.p0, a.p1);
+        for (int r = 0; r < 4; ++r) {
+            const float x = (v[r] + bias) + rv[r];
+            o[r] = x > 0.f ? x : x * slope;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = mr_activate((v[r] + bias) + rv[r], a.act, a.p0, a.p1);
     }
     *(f32x4*)(a.dst + idx) = o;
 }

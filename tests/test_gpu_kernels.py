@@ -1053,7 +1053,8 @@ def test_plan_routes_layers_to_the_cooktoom_forms(hip_lib, monkeypatch):
     (codes 10 m + mbw; 7-tap layers under the keys `x7_` / `y7_`), through the native launch list as well."""
     g = torch.Generator().manual_seed(79)
     x = torch.randn(1, 24, 24, 64, generator=g)
-    for taps, codes in ((3, (0, 2, 42)), (7, (0, 22, 43))):
+    seven = (0, 22, 43) if hip_lib.has_diagnostic_forms else (0, 43)        # F(2,7) (code 2x on a 7-tap key): diagnostic library only since round 4
+    for taps, codes in ((3, (0, 2, 42)), (7, seven)):
         for axis in (0, 1):
             kk = (1, taps) if axis == 0 else (taps, 1)
             wt = torch.randn(48, 24, *kk, generator=g) * (1.0 / math.sqrt(24.0 * taps))
@@ -1074,7 +1075,7 @@ def test_plan_routes_layers_to_the_cooktoom_forms(hip_lib, monkeypatch):
                     assert log["wino_m"] == m_ and log["macs"] == log["ref_macs"] * (m_ + taps - 1) // (m_ * taps)
                 plan.run_stage("main", _stream())
                 torch.cuda.synchronize()
-                tol = 1.5e-4 if code == 43 else 2e-5
+                tol = 6e-5 if code == 43 else 2e-5
                 assert float((out.cpu() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max())), (taps, axis, code)
 
 

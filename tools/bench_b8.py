@@ -23,6 +23,9 @@ LAYERS = {
     "dec3.1": ((48, 64), (1, 1), 48, (3, 3), (1, 1), 1, 1),
     "enc0.0y": ((48, 3), (0, 0), 48, (7, 1), (1, 1), 1, 1),
     "enc0.1x": ((48,), (1,), 48, (1, 3), (1, 1), 1, 1),
+    "dec3": ((64, 64, 64), (1, 0, 0), 48, (2, 2), (1, 1), 1, 1),          # depth.dec3 as ONE 2x2 phase on the 256x512 input (of four)
+    "dec2.1": ((64, 64, 96), (1, 0, 1), 64, (3, 3), (1, 1), 1, 1),        # mask.dec2.1 at 256x512 (use --height 256 --width 512)
+    "enc1.0": ((48,), (1,), 48, (3, 3), (1, 1), 1, 4),                    # mask.enc1.* at 256x512
 }
 
 

@@ -623,6 +623,8 @@ def main():
         shape = (args.batch, args.height, args.width, args.frames, args.depths)
         fp32 = not (args.bf16 or args.bf16x3)
         cfg_tag = {(1, 256, 512, 2, 32): "c2", (8, 256, 512, 4, 64): "c3"}.get(shape) if fp32 else None
+        if args.bf16 and shape == (1, 512, 1024, 4, 48):
+            cfg_tag = "c5bf16"                                         # BASELINE configs[4]: profiles/*_c5bf16_*
         is_c2_fp32 = cfg_tag == "c2"                                   # the committed profiles are of these commands
         current, stamp_info = profile_is_current(cfg_tag) if cfg_tag else (False, None)
         pmc, pmc_src = committed_pmc(cfg_tag) if (cfg_tag and current) else ({}, None)

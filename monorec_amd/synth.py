@@ -90,6 +90,16 @@ def make_depth_pair(batch=2, height=64, width=96, seed=7, valid_fraction=0.18):
     return pred.contiguous(), (gt * keep).contiguous()
 
 
+def make_metric_flag_inputs(batch, height, width, seed):
+    """(prediction with exact zeros on ~10 % of the pixels, sparse target, moving-object mask) for the `pred_all_valid=False` /
+    `use_cvmask=True` options of the sparse metrics (sparse_metrics.py:81-212) - seeded, reproducible anywhere."""
+    pred, gt = make_depth_pair(batch, height, width, seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    pred = torch.where(torch.rand(pred.shape, generator=g) < 0.1, torch.zeros_like(pred), pred)
+    mv = (torch.rand(pred.shape, generator=g) < 0.35).float()
+    return pred.contiguous(), gt, mv.contiguous()
+
+
 def clone_batch(batch, device=None):
     def cv(v):
         if isinstance(v, torch.Tensor):

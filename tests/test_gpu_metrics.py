@@ -38,8 +38,6 @@ def test_metric_edge_cases(hip_lib):
     assert torch.isnan(metrics.rmse_sparse_metric(data, None, 80)) and torch.isnan(ref["rmse_sparse_metric"])
     got, want = float(metrics.abs_rel_sparse_metric(data, None, 80)), float(ref["abs_rel_sparse_metric"])
     assert abs(got - want) <= RTOL * max(1.0, abs(want))
-    with pytest.raises(NotImplementedError):
-        metrics.a1_sparse_metric(data, None, 80, pred_all_valid=False)
     # predictions below 1/max_distance and negative ones are clamped exactly like the reference
     pred2 = pred.clone()
     pred2[0, 0, :4] = -0.1
@@ -67,3 +65,29 @@ def test_metrics_on_model_output(hip_lib):
     for fn in metrics.SPARSE_METRICS:
         got, want = float(getattr(metrics, fn)(data, None, 80)), float(ref[fn])
         assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (fn, got, want)
+
+
+@pytest.mark.parametrize("name", ["flags_eval", "flags_roi"])
+def test_onlyvalid_and_onlydynamic_variants_match_the_reference_fixture(hip_lib, name):
+    """pred_all_valid=False (`*_sparse_onlyvalid_metric`) and use_cvmask=True (`*_sparse_onlydynamic_metric`) - sparse_metrics.py:81-212,
+    utils/util.py:101-107 - against the committed outputs of the reference's own functions (oracle/make_golden_metric_flags.py)."""
+    BASES = ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")
+    case = json.load(open(os.path.join(GOLDEN, "sparse_metrics_flags.json")))[name]
+    b, h, w, seed, roi, maxd = case["config"]
+    pred, gt, mv = synth.make_metric_flag_inputs(b, h, w, seed)
+    assert float((pred == 0).float().mean()) > 0.05
+    data = {"result": pred.to(DEV), "target": gt.to(DEV), "mvobj_mask": mv.to(DEV)}
+    checked = 0
+    for key, want in case["metrics"].items():
+        if key.endswith("_both"):
+            got = float(getattr(metrics, key[:-5] + "_sparse_metric")(data, roi, maxd, False, True))
+        else:
+            got = float(getattr(metrics, key)(data, roi, maxd))
+        assert abs(got - want) <= RTOL * max(1.0, abs(want)), (key, got, want)
+        checked += 1
+    assert checked == (21 if roi is None else 7) and set(k.split("_sparse_")[0] for k in case["metrics"] if "_sparse_" in k) == set(BASES)
+    if roi is not None:
+        with pytest.raises(RuntimeError):
+            metrics.a1_sparse_onlydynamic_metric(data, roi, maxd)
+    plain = float(metrics.a1_sparse_metric(data, roi, maxd))
+    assert abs(plain - case["metrics"]["a1_sparse_onlyvalid_metric"]) > 1e-4        # the option does change the value on this input

@@ -526,6 +526,40 @@ __device__ __forceinline__ void bilinear_batch(float (&out)[N * 3], __amdgpu_buf
     for (int i = 0; i < N * 3; ++i) out[i] = fmaf(d[i], sp[i / 3].se, out[i]);
 }
 
+// The same in two halves for the prefetching marching step: the 12 N gathers of a row are issued one step ahead of their use.
+template <int N>
+struct Gathered {
+    float a[N * 3], b[N * 3], c[N * 3], d[N * 3];     // the four taps of every (plane, channel)
+    float nw[N], ne[N], sw[N], se[N];                 // bilinear weights
+    bool hit[N];                                      // border-mask sample != 0
+    float K[3];                                       // keyframe pixel + 0.5
+    float kmu[3], ksg[3];                             // keyframe window statistics of SSIM position (r - 1, x) (prepass)
+};
+
+template <int N>
+__device__ __forceinline__ void bilinear_issue(Gathered<N>& g, __amdgpu_buffer_rsrc_t img, int plane_bytes, const Taps (&t)[N]) {
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) {
+        const int so = (i % 3) * plane_bytes;
+        g.a[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].a, so, 0));
+        g.b[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].b, so, 0));
+        g.c[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].c, so, 0));
+        g.d[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(img, t[i / 3].d, so, 0));
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void bilinear_combine(float (&out)[N * 3], const Gathered<N>& g) {
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = g.a[i] * g.nw[i / 3];
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = fmaf(g.b[i], g.ne[i / 3], out[i]);
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = fmaf(g.c[i], g.sw[i / 3], out[i]);
+#pragma unroll
+    for (int i = 0; i < N * 3; ++i) out[i] = fmaf(g.d[i], g.se[i / 3], out[i]);
+}
+
 struct MarchGeom {
     int strips, pitch, TY, ysegs, npairs;
 };
@@ -559,38 +593,58 @@ struct MarchCtx {
 // One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
 // sad of output row r - 2 (box over the e rows), then turn `mid` into the next top sums.  The caller alternates two MarchRow
 // objects as mid / cur, so the raw rows never move between registers.
+// First half of a marching step: project virtual row r for DP planes and ISSUE every global load the step needs (12 DP gathers, the
+// keyframe pixel, the prepass statistics of SSIM row r - 1).  Nothing here waits for a load.
 template <int DP, bool PIXD, bool KFS, bool FD>
-__device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid, MarchRow<DP, KFS>& cur,
-                                           unsigned (&hits)[DP]) {
-    constexpr int NQ = DP * 9 + (KFS ? 0 : 6), KQ = DP * 9;
+__device__ __forceinline__ void march_issue(const MarchCtx<DP>& c, int r, Gathered<DP>& g) {
     const CvArgs& a = c.a;
     const int H = a.H, W = a.W;
     const int HWp = H * W;
-    const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;   // fp32(0.01**2), fp32(0.03**2)  layers.py:116-117
-    // ---- warp virtual row r (image row reflect(r)) for DP planes ---------------------------------------------------------
     int wr = r < 0 ? -r : (r >= H ? 2 * H - 2 - r : r);
     wr = min(max(wr, 0), H - 1);
     const int pix = wr * W + c.cx;
     float ray[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) ray[i] = fmaf(c.Ki[3 * i + 2], 1.0f, fmaf(c.Ki[3 * i + 1], (float)wr, c.kix[i]));
-    float K[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) K[ch] = c.kimg[ch * HWp + pix] + 0.5f;
+    for (int ch = 0; ch < 3; ++ch) g.K[ch] = c.kimg[ch * HWp + pix] + 0.5f;
+    if (KFS) {                                                              // keyframe statistics of SSIM position (r - 1, x): prepass
+        const int sp_ = min(max(r - 1, 0), H - 1) * W + c.cx;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { g.kmu[ch] = c.kstats[ch * HWp + sp_]; g.ksg[ch] = c.kstats[(3 + ch) * HWp + sp_]; }
+    }
     Sample sp[DP];
     Taps tp[DP];
     float dep[DP];
 #pragma unroll
     for (int u = 0; u < DP; ++u) dep[u] = PIXD ? c.pixd[(long long)u * HWp + pix] : c.depth[u];
-    bool hit[DP];
-    project_batch<DP, FD>(sp, hit, ray[0], ray[1], ray[2], dep, c.P, H, W, a);
+    project_batch<DP, FD>(sp, g.hit, ray[0], ray[1], ray[2], dep, c.P, H, W, a);
 #pragma unroll
     for (int u = 0; u < DP; ++u) {
-        hits[u] = (hits[u] << 1) | (hit[u] ? 1u : 0u);                    // monorec_model.py:218-219
         tp[u] = tap_offsets(sp[u], H, W);
+        g.nw[u] = sp[u].nw; g.ne[u] = sp[u].ne; g.sw[u] = sp[u].sw; g.se[u] = sp[u].se;
     }
+    bilinear_issue<DP>(g, c.img, HWp * 4, tp);
+}
+
+// One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
+// sad of output row r - 2 (box over the e rows), then turn `mid` into the next top sums.  The caller alternates two MarchRow
+// objects as mid / cur, so the raw rows never move between registers.  `g`: what march_issue() gathered for row r.
+template <int DP, bool PIXD, bool KFS, bool FD>
+__device__ __forceinline__ void march_finish(const MarchCtx<DP>& c, int r, const Gathered<DP>& g, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid,
+                                             MarchRow<DP, KFS>& cur, unsigned (&hits)[DP]) {
+    constexpr int NQ = DP * 9 + (KFS ? 0 : 6), KQ = DP * 9;
+    const CvArgs& a = c.a;
+    const int H = a.H, W = a.W;
+    const int HWp = H * W;
+    const float C1 = 0x1.a36e2ep-14f, C2 = 0x1.d7dbf4p-11f;   // fp32(0.01**2), fp32(0.03**2)  layers.py:116-117
+    float K[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) K[ch] = g.K[ch];
+#pragma unroll
+    for (int u = 0; u < DP; ++u) hits[u] = (hits[u] << 1) | (g.hit[u] ? 1u : 0u);                    // monorec_model.py:218-219
     float xw[DP * 3];
-    bilinear_batch<DP>(xw, c.img, HWp * 4, tp, sp);
+    bilinear_combine<DP>(xw, g);
 #pragma unroll
     for (int i = 0; i < DP * 3; ++i) cur.q[i * 3] = xw[i] + 0.5f;
     if (!KFS) {
@@ -613,10 +667,9 @@ __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRo
     const int q = r - 1;
     const bool row_in = q >= 0 && q < H;                                    // wave-uniform
     float kmu[3], kmu2[3], ksg[3];
-    if (KFS) {                                                              // keyframe statistics of SSIM position (q, x): prepass
-        const int sp_ = min(max(q, 0), H - 1) * W + c.cx;
+    if (KFS) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { kmu[ch] = c.kstats[ch * HWp + sp_]; ksg[ch] = c.kstats[(3 + ch) * HWp + sp_]; }
+        for (int ch = 0; ch < 3; ++ch) { kmu[ch] = g.kmu[ch]; ksg[ch] = g.ksg[ch]; }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) kmu2[ch] = kmu[ch] * kmu[ch];
     } else {
@@ -667,6 +720,15 @@ __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRo
     hsum3_batch<DP>(top.e, mid.e);
 }
 
+// issue + finish back to back: the step as rounds 2-3 ran it (every wave waits out its own gathers; the other waves of the SIMD cover)
+template <int DP, bool PIXD, bool KFS, bool FD>
+__device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid, MarchRow<DP, KFS>& cur,
+                                           unsigned (&hits)[DP]) {
+    Gathered<DP> g;
+    march_issue<DP, PIXD, KFS, FD>(c, r, g);
+    march_finish<DP, PIXD, KFS, FD>(c, r, g, top, mid, cur, hits);
+}
+
 // Keyframe statistics of the SSIM windows, once per keyframe instead of once per (frame, plane pair, row) in every wave: 3x3
 // reflection-padded mean and variance of keyframe + 0.5 per channel (layers.py:120-130; row-major sum / 9 like AvgPool2d).
 // Written into planes 0..5 of the sample's (not yet written) cost-volume buffer, which cv_fuse overwrites afterwards.
@@ -698,7 +760,9 @@ __global__ __launch_bounds__(256) void cv_kf_stats_kernel(const CvArgs a) {
     }
 }
 
-template <int DP, bool PIXD, bool KFS, bool FD>
+// PF: software prefetch - the gathers of row r + 1 are issued before the arithmetic of row r (two Gathered sets alternate), so a wave
+// covers its own memory latency instead of relying on the other waves of its SIMD (c2 leaves a SIMD only ~4 waves).
+template <int DP, bool PIXD, bool KFS, bool FD, bool PF = false>
 __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const MarchGeom g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -737,6 +801,25 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
 #pragma unroll
     for (int u = 0; u < DP; ++u) hits[u] = 0u;
     const int r_last = c.y1 + 1;
+    if (PF) {
+        // (sched_barrier: the machine scheduler must not interleave the projection of row r + 1 with the arithmetic of row r - left alone
+        // it does, and the live ranges of both halves take 256 VGPRs at two planes per wave)
+        Gathered<DP> g0, g1;
+        march_issue<DP, PIXD, KFS, FD>(c, y0 - 2, g0);
+        for (int r = y0 - 2; r <= r_last; r += 2) {
+            if (r + 1 <= r_last) march_issue<DP, PIXD, KFS, FD>(c, r + 1, g1);
+            __builtin_amdgcn_sched_barrier(0);
+            march_finish<DP, PIXD, KFS, FD>(c, r, g0, top, rowA, rowB, hits);
+            __builtin_amdgcn_sched_barrier(0);
+            if (r + 1 <= r_last) {
+                if (r + 2 <= r_last) march_issue<DP, PIXD, KFS, FD>(c, r + 2, g0);
+                __builtin_amdgcn_sched_barrier(0);
+                march_finish<DP, PIXD, KFS, FD>(c, r + 1, g1, top, rowB, rowA, hits);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
     for (int r = y0 - 2; r <= r_last; r += 2) {
         march_step<DP, PIXD, KFS, FD>(c, r, top, rowA, rowB, hits);
         if (r + 1 <= r_last) march_step<DP, PIXD, KFS, FD>(c, r + 1, top, rowB, rowA, hits);
@@ -1107,6 +1190,9 @@ void launch_fuse(const CvArgs& k, bool plane_flags, bool tiled, hipStream_t stre
 // segments of TY rows.  A wave is the unit of work (it never migrates), so the makespan is ceil(waves / SIMDs) wave-lengths: TY
 // trades the 4 halo rows every segment warps twice against how evenly the waves divide over the chip's 1024 SIMDs
 // (c2: TY 32 -> 2304 waves = 3 rounds at 2.25 average; TY 37 -> 2016 waves = 2 full rounds).
+// software prefetch of the marching kernel by plane count per wave (dp1: one plane): set from the measurement of tools/sessions/r04_s12.sh
+#define MR_CV_PREFETCH_DEFAULT(dp1) (false)
+
 MarchGeom march_geometry(const CvArgs& a, int dp) {
     MarchGeom g;
     g.strips = (a.W + 59) / 60;
@@ -1168,9 +1254,16 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         const bool kfs = dp1 || (a.D >= 6 && !no_prepass);
         if (kfs)                             // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
             hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
+#ifdef MR_TUNING_ENV
+        static const int pf_env = [] { const char* e = getenv("MR_CV_PREFETCH"); return e ? atoi(e) : -1; }();
+#else
+        const int pf_env = -1;
+#endif
+        const bool pf = pf_env >= 0 ? pf_env != 0 : MR_CV_PREFETCH_DEFAULT(dp1);
 #define MR_MARCH(DP_, PIXD_, KFS_)                                                                                              \
     do {                                                                                                                        \
-        if (fd) hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, true>), grid, dim3(256), 0, stream, k, g);               \
+        if (fd && pf && DP_ == 1) hipLaunchKernelGGL((cv_sad_march_kernel<1, PIXD_, KFS_, true, true>), grid, dim3(256), 0, stream, k, g); \
+        else if (fd) hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, true>), grid, dim3(256), 0, stream, k, g);          \
         else hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, false>), grid, dim3(256), 0, stream, k, g);                 \
     } while (0)
         if (dp1) MR_MARCH(1, false, true);   // twice the waves, each with one plane: for shapes that leave the SIMDs short of waves

@@ -558,7 +558,8 @@ def test_marching_cost_volume_kernel_codegen():
         subprocess.run([_build._hipcc(), f"--offload-arch={_build.ARCH}", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj", "-c", src,
                         "-o", os.path.join(d, "cv.o")] + flags, check=True, cwd=d, capture_output=True)
         asm = open(os.path.join(d, "cost_volume-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-    for variant in ("ILi2ELb0ELb1ELb1E", "ILi2ELb0ELb0ELb1E", "ILi1ELb0ELb1ELb1E"):   # <DP, shared depths, keyframe prepass on / off, exact constant division>
+    # <DP, shared depths, keyframe prepass on / off, exact constant division, software prefetch off>
+    for variant in ("ILi2ELb0ELb1ELb1ELb0E", "ILi2ELb0ELb0ELb1ELb0E", "ILi1ELb0ELb1ELb1ELb0E"):
         m = re.search(r"_ZN12_GLOBAL__N_119cv_sad_march_kernel" + variant + r"EEvNS_6CvArgsENS_9MarchGeomE:(.*?)\.Lfunc_end", asm, re.S)
         assert m, variant
         body = m.group(1)

@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
+    ap.add_argument("--step-times", action="store_true", help="diagnostic: host time stamps after every timed step and after the drain, on the line as `step_marks_ms`")
     ap.add_argument("--spinup-seconds", type=float, default=3.0, help="minimum untimed spin-up before the timed steps")
     ap.add_argument("--bf16x3", action="store_true",
                     help="EXPERIMENTAL: convolutions as three bf16 MFMAs over hi/lo bf16 splits of both operands (fp32-class accuracy, "
@@ -153,13 +154,12 @@ def _latest_profile(cfg, suffix):
     return files[-1] if files else None
 
 
-def profile_is_current(cfg):
+def profile_is_current(cfg, now):
     """(True, stamp) when the newest committed profile set of workload `cfg` was taken on the plan that is running now: its
-    `profiles/*_<cfg>_stamp.json` (tools/summarize_prof.py) equals engine.plan_stamp() (sha256 over tuned_schedules.json +
-    tuned_winograd.json + ABI).  A stale or unstamped set is NOT quoted on the line (the round-3 driver line carried
-    kernel-only figures of a plan two launches behind HEAD)."""
-    from monorec_amd import engine
-    now = engine.plan_stamp()
+    `profiles/*_<cfg>_stamp.json` (tools/summarize_prof.py: the `Plan.launch_stamp()` of the profiled run - sha256 over every
+    convolution launch's kernel family, variant and schedule + ABI) equals `now`, the stamp of the plan being timed.  A stale or
+    unstamped set is NOT quoted on the line (the round-3 driver line carried kernel-only figures of a plan two launches
+    behind HEAD)."""
     path = _latest_profile(cfg, "stamp.json")
     if not path:
         return False, {"running_plan": now, "profile": None, "note": "no stamped profile set committed for this workload"}
@@ -575,9 +575,14 @@ def main():
     enq0 = list(model.host_enqueue_stats)
     cpu0 = time.process_time()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         step()
+        if args.step_times:
+            step_marks.append(time.perf_counter() - t0)
     out = drain()
+    if args.step_times:
+        step_marks.append(time.perf_counter() - t0)
     cpu1 = time.process_time()
     enq1 = list(model.host_enqueue_stats)
     summary[0] = args.steps * args.batch
@@ -626,7 +631,7 @@ def main():
         if args.bf16 and shape == (1, 512, 1024, 4, 48):
             cfg_tag = "c5bf16"                                         # BASELINE configs[4]: profiles/*_c5bf16_*
         is_c2_fp32 = cfg_tag == "c2"                                   # the committed profiles are of these commands
-        current, stamp_info = profile_is_current(cfg_tag) if cfg_tag else (False, None)
+        current, stamp_info = profile_is_current(cfg_tag, model._plans[plan_key].launch_stamp()) if cfg_tag else (False, None)
         pmc, pmc_src = committed_pmc(cfg_tag) if (cfg_tag and current) else ({}, None)
         kst, kst_src = committed_kernel_stats(cfg_tag) if (cfg_tag and current) else (None, None)
         cfg_name = {(1, 256, 512, 2, 32): "c2 (BASELINE configs[1])", (8, 256, 512, 4, 64): "c3 (BASELINE configs[2])",
@@ -703,7 +708,7 @@ def main():
         if cfg_tag:
             roof["profile_stamp"] = stamp_info
             if not current:
-                roof["stale_profile"] = ("the committed rocprofv3 profile set of this workload was not taken on the running plan (tables / ABI changed "
+                roof["stale_profile"] = ("the committed rocprofv3 profile set of this workload was not taken on the running plan (its launches / ABI changed "
                                          "since, or no stamped set exists): frac_kernel_only, mfma_util_pmc and traffic are omitted, not quoted")
         # one-channel layers: every input element read once, every output written once; the classifier launch also scales the D planes
         hw_ = args.height * args.width
@@ -724,6 +729,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "untimed_spinup_steps": n_spin,
+            **({"step_marks_ms": [round(1e3 * t, 3) for t in step_marks], "elapsed_ms": round(1e3 * elapsed, 3)} if args.step_times else {}),
             "primer_process": primed,
             "ms_per_step": elapsed / args.steps * 1e3,
             "host_enqueue_ms": (enq1[1] - enq0[1]) / max(1, enq1[0] - enq0[0]) * 1e3,

@@ -367,7 +367,7 @@ int mr_convt4x4s2_winograd_f32(const mr_wino_desc* desc, void* stream);
  *   depths : D depth hypotheses (1/linspace(inv_max, inv_min, D)), far to near
  * keyframe: (batch,3,H,W); frames[f]: (batch,3,H,W), all in [-0.5,0.5].
  * Outputs: cost_volume (batch,D,H,W); sfcv[f] (batch,D,H,W).
- * D must be even, F <= MR_MAX_FRAMES.  sfcv[f] doubles as scratch for the raw matching cost between the two
+ * D >= 2 (any parity: the kernels take the planes in pairs, an odd D's last pair repeats the last hypothesis and drops its second plane), F <= MR_MAX_FRAMES.  sfcv[f] doubles as scratch for the raw matching cost between the two
  * internal launches (sad kernel, per-pixel fusion kernel); no other workspace is needed.
  */
 int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,

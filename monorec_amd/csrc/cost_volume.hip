@@ -267,8 +267,9 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
         // ---- (a) warp own pixel + one halo position, DPI depth planes ---------------------------
 #pragma unroll
         for (int u = 0; u < DPI; ++u) {
-            const float depth = PIXD ? 0.f : a.depths[d + u];
-            const float* pd = PIXD ? a.pix_depths + ((long long)b * D + d + u) * HWp : nullptr;
+            const int du = min(d + u, D - 1);      // odd D: the second plane of the last pair repeats the last hypothesis and is not stored
+            const float depth = PIXD ? 0.f : a.depths[du];
+            const float* pd = PIXD ? a.pix_depths + ((long long)b * D + du) * HWp : nullptr;
             float* wru = wr + u * 3 * HY * HX;
             if (own_in) {
                 const Sample sp = project(ro[0], ro[1], ro[2], PIXD ? pd[opy * W + opx] : depth, P, H, W, a);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(TX * TY) void cv_sad_kernel(const CvArgs a) {
                     }
                 if (PFLAG) { if (!pflag[u]) s = -s; }           // per-plane flag in the sign bit
                 else if (d + u == d_hi - 1 && !hit_all) s = -s; // sad >= 0: the sign bit is free (-0.0 keeps it)
-                sad_out[(long long)(d + u) * HWp] = s;
+                if (d + u < d_hi) sad_out[(long long)(d + u) * HWp] = s;
             }
         }
     }
@@ -588,6 +589,7 @@ struct MarchCtx {
     __amdgpu_buffer_rsrc_t outr;   // raw sad planes d0 .. d0 + DP - 1 of frame f, sample b
     int cx, vx, y0, y1;
     bool col_in, out_lane;
+    int planes;             // planes of this wave that exist: DP, or 1 for the last wave of an odd D
 };
 
 // One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
@@ -617,7 +619,7 @@ __device__ __forceinline__ void march_issue(const MarchCtx<DP>& c, int r, Gather
     Taps tp[DP];
     float dep[DP];
 #pragma unroll
-    for (int u = 0; u < DP; ++u) dep[u] = PIXD ? c.pixd[(long long)u * HWp + pix] : c.depth[u];
+    for (int u = 0; u < DP; ++u) dep[u] = PIXD ? c.pixd[(long long)(u < c.planes ? u : 0) * HWp + pix] : c.depth[u];
     project_batch<DP, FD>(sp, g.hit, ray[0], ray[1], ray[2], dep, c.P, H, W, a);
 #pragma unroll
     for (int u = 0; u < DP; ++u) {
@@ -760,9 +762,10 @@ __global__ __launch_bounds__(256) void cv_kf_stats_kernel(const CvArgs a) {
     }
 }
 
-// PF: software prefetch - the gathers of row r + 1 are issued before the arithmetic of row r (two Gathered sets alternate), so a wave
-// covers its own memory latency instead of relying on the other waves of its SIMD (c2 leaves a SIMD only ~4 waves).
-template <int DP, bool PIXD, bool KFS, bool FD, bool PF = false>
+// (Software prefetch - the gathers of row r + 1 issued before the arithmetic of row r, two Gathered sets alternating - was measured in
+// tools/sessions/r04_s12.sh: 120.3 -> 119.7 us at c2 with one plane per wave (99 instead of 63 registers), slower at 512x1024, and at
+// two planes per wave the second set does not fit the register file (256 VGPRs).  The other waves of the SIMD cover the gathers.)
+template <int DP, bool PIXD, bool KFS, bool FD>
 __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const MarchGeom g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -787,39 +790,22 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
                       __builtin_amdgcn_make_buffer_rsrc((void*)(a.frames[f] + (long long)b * 3 * HWp), 0, 3 * HWp * 4, 0x00020000),
                       {0.f, 0.f, 0.f}, {}, PIXD ? a.pix_depths + ((long long)b * D + d0) * HWp : nullptr,
                       KFS ? a.cv + (long long)b * D * HWp : nullptr,
-                      __builtin_amdgcn_make_buffer_rsrc((void*)(a.sfcv[f] + ((long long)b * D + d0) * HWp), 0, DP * HWp * 4, 0x00020000),
+                      // (odd D: the last wave's second plane repeats the last hypothesis; its stores fall outside the descriptor and are dropped)
+                      __builtin_amdgcn_make_buffer_rsrc((void*)(a.sfcv[f] + ((long long)b * D + d0) * HWp), 0, min(DP, D - d0) * HWp * 4, 0x00020000),
                       cx, vx, y0, min(y0 + g.TY, H),
                       vx >= 0 && vx < W,                      // SSIM positions outside the image contribute 0 to the box (:247)
-                      lane >= 2 && lane < 2 + g.pitch && vx < W};
+                      lane >= 2 && lane < 2 + g.pitch && vx < W,
+                      min(DP, D - d0)};
 #pragma unroll
     for (int i = 0; i < 3; ++i) c.kix[i] = c.Ki[3 * i] * (float)cx;   // Kinv[:, 0] * x, the first product of the ray's FMA chain (:199)
 #pragma unroll
-    for (int u = 0; u < DP; ++u) c.depth[u] = PIXD ? 0.f : a.depths[d0 + u];
+    for (int u = 0; u < DP; ++u) c.depth[u] = PIXD ? 0.f : a.depths[min(d0 + u, D - 1)];
 
     MarchRow<DP, KFS> top = {}, rowA = {}, rowB = {};
     unsigned hits[DP];                                        // bit j: border-mask sample of the row warped j steps ago != 0
 #pragma unroll
     for (int u = 0; u < DP; ++u) hits[u] = 0u;
     const int r_last = c.y1 + 1;
-    if (PF) {
-        // (sched_barrier: the machine scheduler must not interleave the projection of row r + 1 with the arithmetic of row r - left alone
-        // it does, and the live ranges of both halves take 256 VGPRs at two planes per wave)
-        Gathered<DP> g0, g1;
-        march_issue<DP, PIXD, KFS, FD>(c, y0 - 2, g0);
-        for (int r = y0 - 2; r <= r_last; r += 2) {
-            if (r + 1 <= r_last) march_issue<DP, PIXD, KFS, FD>(c, r + 1, g1);
-            __builtin_amdgcn_sched_barrier(0);
-            march_finish<DP, PIXD, KFS, FD>(c, r, g0, top, rowA, rowB, hits);
-            __builtin_amdgcn_sched_barrier(0);
-            if (r + 1 <= r_last) {
-                if (r + 2 <= r_last) march_issue<DP, PIXD, KFS, FD>(c, r + 2, g0);
-                __builtin_amdgcn_sched_barrier(0);
-                march_finish<DP, PIXD, KFS, FD>(c, r + 1, g1, top, rowB, rowA, hits);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        return;
-    }
     for (int r = y0 - 2; r <= r_last; r += 2) {
         march_step<DP, PIXD, KFS, FD>(c, r, top, rowA, rowB, hits);
         if (r + 1 <= r_last) march_step<DP, PIXD, KFS, FD>(c, r + 1, top, rowB, rowA, hits);
@@ -1190,14 +1176,12 @@ void launch_fuse(const CvArgs& k, bool plane_flags, bool tiled, hipStream_t stre
 // segments of TY rows.  A wave is the unit of work (it never migrates), so the makespan is ceil(waves / SIMDs) wave-lengths: TY
 // trades the 4 halo rows every segment warps twice against how evenly the waves divide over the chip's 1024 SIMDs
 // (c2: TY 32 -> 2304 waves = 3 rounds at 2.25 average; TY 37 -> 2016 waves = 2 full rounds).
-// software prefetch of the marching kernel by plane count per wave (dp1: one plane): set from the measurement of tools/sessions/r04_s12.sh
-#define MR_CV_PREFETCH_DEFAULT(dp1) (false)
 
 MarchGeom march_geometry(const CvArgs& a, int dp) {
     MarchGeom g;
     g.strips = (a.W + 59) / 60;
     g.pitch = (a.W + g.strips - 1) / g.strips;
-    g.npairs = a.D / dp;
+    g.npairs = (a.D + dp - 1) / dp;
 #ifdef MR_TUNING_ENV         // tuning aids: diagnostic library only (python -m monorec_amd.build --timeline); the product reads no environment
     static const int forced = [] { const char* e = getenv("MR_CV_MARCH_TY"); return e ? atoi(e) : 0; }();
 #else
@@ -1254,16 +1238,9 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         const bool kfs = dp1 || (a.D >= 6 && !no_prepass);
         if (kfs)                             // keyframe window statistics once, into planes 0..5 of the cost-volume buffer
             hipLaunchKernelGGL(cv_kf_stats_kernel, dim3((unsigned)((a.H * a.W + 255) / 256), (unsigned)a.B), dim3(256), 0, stream, k);
-#ifdef MR_TUNING_ENV
-        static const int pf_env = [] { const char* e = getenv("MR_CV_PREFETCH"); return e ? atoi(e) : -1; }();
-#else
-        const int pf_env = -1;
-#endif
-        const bool pf = pf_env >= 0 ? pf_env != 0 : MR_CV_PREFETCH_DEFAULT(dp1);
 #define MR_MARCH(DP_, PIXD_, KFS_)                                                                                              \
     do {                                                                                                                        \
-        if (fd && pf && DP_ == 1) hipLaunchKernelGGL((cv_sad_march_kernel<1, PIXD_, KFS_, true, true>), grid, dim3(256), 0, stream, k, g); \
-        else if (fd) hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, true>), grid, dim3(256), 0, stream, k, g);          \
+        if (fd) hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, true>), grid, dim3(256), 0, stream, k, g);          \
         else hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, false>), grid, dim3(256), 0, stream, k, g);                 \
     } while (0)
         if (dp1) MR_MARCH(1, false, true);   // twice the waves, each with one plane: for shapes that leave the SIMDs short of waves
@@ -1353,7 +1330,7 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
     if (!keyframe || !frames || !kinv || !proj || (!depths && !pixel_depths) || !cost_volume || !sfcv || !channel_weights)
         return MR_ERR_BAD_ARGUMENT;
     if (num_frames < 1 || num_frames > MR_MAX_FRAMES || batch < 1 || height < 5 || width < 5) return MR_ERR_BAD_ARGUMENT;
-    if (num_depths < 2 || (num_depths & 1)) return MR_ERR_UNSUPPORTED;   // two planes per iteration
+    if (num_depths < 2) return MR_ERR_BAD_ARGUMENT;                       // (:258 divides by num_depths - 1)
     CvArgs a;
     a.keyframe = keyframe;
     for (int f = 0; f < MR_MAX_FRAMES; ++f) {

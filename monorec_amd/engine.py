@@ -157,7 +157,8 @@ TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from t
 def _load_tuned():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_schedules.json")
+    # (MR_TUNED_SCHEDULES / MR_TUNED_WINOGRAD: another table file - the tuning sessions A/B a candidate table before it replaces this one)
+    path = os.environ.get("MR_TUNED_SCHEDULES") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_schedules.json")
     if os.path.exists(path):
         with open(path) as f:
             TUNED.update({k: tuple(v) for k, v in json.load(f).items()})
@@ -172,7 +173,7 @@ WINOGRAD = {}       # signature (without the phase / mode suffixes) -> 0 (direct
 def _load_winograd():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_winograd.json")
+    path = os.environ.get("MR_TUNED_WINOGRAD") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_winograd.json")
     if os.path.exists(path):
         with open(path) as f:
             WINOGRAD.update({k: int(v) for k, v in json.load(f).items()})
@@ -194,23 +195,6 @@ def _load_winograd_f2():
 
 
 _load_winograd_f2()
-
-
-def plan_stamp():
-    """What decides which kernels a plan launches: sha256 over the two measured tables (tuned_schedules.json, tuned_winograd.json) and
-    the library's ABI version.  tools/summarize_prof.py stamps every committed profile with it; bench.py quotes a committed rocprof
-    figure on its line only when the stamp of that profile equals the stamp of the running plan (the round-3 driver line
-    quoted profiles that were one table behind HEAD)."""
-    import hashlib
-    import os
-    h = hashlib.sha256()
-    here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("tuned_schedules.json", "tuned_winograd.json"):
-        path = os.path.join(here, name)
-        h.update(name.encode())
-        h.update(open(path, "rb").read() if os.path.exists(path) else b"-")
-    h.update(f"abi{_lib.MR_ABI_VERSION}".encode())
-    return h.hexdigest()[:16]
 
 
 def winograd_signature(cout, src_channels, h, w, batch):
@@ -364,8 +348,8 @@ class Plan:
                  one_channel_kernels=None, winograd=None, conv_forms="table"):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
-        if build and depth_steps % 4:
-            raise NotImplementedError("cv_depth_steps must be a multiple of 4 for the gfx950 kernels")
+        if build and depth_steps < 2:
+            raise ValueError("cv_depth_steps must be >= 2 (monorec_model.py:258 divides by cv_depth_steps - 1)")
         self.lib = _lib.load()
         self.B, self.H, self.W, self.F, self.D = batch, height, width, num_frames, depth_steps
         self.device = torch.device(device)
@@ -425,6 +409,20 @@ class Plan:
     def bare(cls, device, state=None, schedule_override=None, bf16=False):
         """Plan without the network: lets tests / micro-benchmarks launch single ops through the C ABI."""
         return cls(state or {}, 1, 32, 32, 1, 4, (0.33, 0.0025), device, schedule_override=schedule_override, build=False, bf16=bf16)
+
+    def launch_stamp(self):
+        """What THIS plan launches: sha256 over (layer, kernel family / variant, schedule) of every convolution launch + the
+        library's ABI version.  tools/summarize_prof.py stamps a committed profile set with the stamp of the plan that was profiled
+        (taken from the bench line of the profiled run); bench.py quotes a committed rocprof figure only when that stamp equals the
+        stamp of the plan it is timing (the round-3 driver line quoted profiles one table behind HEAD).  Table entries
+        for OTHER shapes do not move it."""
+        import hashlib
+        h = hashlib.sha256()
+        for c in self.conv_log:
+            h.update(repr((c["name"], c.get("winograd", 0), c.get("wino_variant", 0), c.get("wino_axis", 0), c.get("wino_m", 0), c.get("b8", 0),
+                           c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"], c["kws"], int(c.get("bf16", 0)))).encode())
+        h.update(f"abi{_lib.MR_ABI_VERSION}".encode())
+        return h.hexdigest()[:16]
 
     def finalize(self):
         """Allocate the per-stage split-K workspace once all launches are known."""

@@ -253,6 +253,24 @@ def test_checkpoint_loading_strips_dataparallel_prefix(tmp_path):
     assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
 
 
+def test_launch_stamp_follows_the_launches_of_the_plan_not_the_tables(hip_lib, monkeypatch):
+    """Profile sets are stamped with Plan.launch_stamp() (bench.py quotes a committed rocprof figure only on an equal stamp): equal for
+    equal launch lists, different as soon as one layer's schedule or kernel family differs, untouched by table entries of other shapes."""
+    m = MonoRecModel(cv_depth_steps=32)
+    sd = synth.seeded_state_dict(m.state_dict())
+    p1 = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    p2 = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
+    assert p1.launch_stamp() == p2.launch_stamp() and len(p1.launch_stamp()) == 16
+    monkeypatch.setitem(engine.TUNED, "co999_ci1_k3x3_s1x1_o8x8_b1_p1", (1, 1, 1, 8, 8, 0))      # a foreign shape
+    assert engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu").launch_stamp() == p1.launch_stamp()
+    direct = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)
+    assert [c for c in p1.conv_log if c.get("winograd")] and direct.launch_stamp() != p1.launch_stamp()
+    first = next(c for c in p1.conv_log if not c.get("winograd"))
+    other = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu",
+                        schedule_override={first["name"]: (first["mb"], first["nb"], first["split_k"], max(8, first["ck"] // 2) if first["ck"] > 8 else 16, first["waves"], first["kws"])})
+    assert other.launch_stamp() != p1.launch_stamp()
+
+
 def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     """Builds the whole launch plan with CPU buffers (no launches): every descriptor validates, LDS stays
     inside a CU, and the conv MACs equal the reference's hook count (61.07 GMAC @ c1)."""
@@ -558,8 +576,7 @@ def test_marching_cost_volume_kernel_codegen():
         subprocess.run([_build._hipcc(), f"--offload-arch={_build.ARCH}", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj", "-c", src,
                         "-o", os.path.join(d, "cv.o")] + flags, check=True, cwd=d, capture_output=True)
         asm = open(os.path.join(d, "cost_volume-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-    # <DP, shared depths, keyframe prepass on / off, exact constant division, software prefetch off>
-    for variant in ("ILi2ELb0ELb1ELb1ELb0E", "ILi2ELb0ELb0ELb1ELb0E", "ILi1ELb0ELb1ELb1ELb0E"):
+    for variant in ("ILi2ELb0ELb1ELb1E", "ILi2ELb0ELb0ELb1E", "ILi1ELb0ELb1ELb1E"):   # <DP, shared depths, keyframe prepass on / off, exact constant division>
         m = re.search(r"_ZN12_GLOBAL__N_119cv_sad_march_kernel" + variant + r"EEvNS_6CvArgsENS_9MarchGeomE:(.*?)\.Lfunc_end", asm, re.S)
         assert m, variant
         body = m.group(1)

@@ -319,8 +319,10 @@ def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch
     kinv, proj = host_geometry(batch["keyframe_intrinsics"], batch["keyframe_pose"], batch["intrinsics"], batch["poses"])
     kinv, proj = kinv.to(DEV), proj.to(DEV)
     depths = depth_hypotheses((0.33, 0.0025), d).to(DEV)
-    cv = torch.full((b, d, h, w), float("nan"), device=DEV)
-    sf = [torch.full((b, d, h, w), float("nan"), device=DEV) for _ in range(nf)]
+    # every output is the front of a larger NaN-filled allocation: a plane written past the end of a volume would land in the guard
+    backing = [torch.full((b * d * h * w + h * w,), float("nan"), device=DEV) for _ in range(nf + 1)]
+    cv = backing[0][: b * d * h * w].view(b, d, h, w)
+    sf = [t[: b * d * h * w].view(b, d, h, w) for t in backing[1:]]
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
@@ -344,6 +346,7 @@ def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch
                                                cv.data_ptr(), sp, _stream()),
                    "mr_cost_volume_mode_f32")
     torch.cuda.synchronize()
+    assert all(bool(torch.isnan(t[b * d * h * w:]).all()) for t in backing), "a cost-volume kernel wrote past the end of an output"
     return cv.cpu(), [s.cpu() for s in sf]
 
 
@@ -383,7 +386,7 @@ def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 72, 3, 12), (1, 64, 96, 2, 8), (2, 96, 160, 2, 32), (1, 256, 512, 2, 32),
-                                   (1, 37, 1024, 1, 48), (2, 128, 192, 4, 64), (1, 33, 61, 2, 6)])
+                                   (1, 37, 1024, 1, 48), (2, 128, 192, 4, 64), (1, 33, 61, 2, 6), (1, 40, 72, 2, 7), (2, 64, 96, 3, 9)])
 @pytest.mark.parametrize("pixel_depths", [False, True])
 def test_marching_cost_volume_is_bit_identical_to_the_tiled_kernels(hip_lib, shape, pixel_depths):
     """The default configuration runs cv_sad_march_kernel + cv_fuse_reg_kernel (registers + DPP wave shifts, no LDS); the
@@ -404,6 +407,31 @@ def test_marching_cost_volume_is_bit_identical_to_the_tiled_kernels(hip_lib, sha
         assert not diff.any(), (f, int(diff.sum()), float((sf_m[f] - sf_t[f]).abs().max()), diff.nonzero()[:5].tolist())
     assert torch.equal(cv_m, cv_t), float((cv_m - cv_t).abs().max())
     assert float((sf_m[0] == 0).all(1).float().mean()) < 0.9      # not trivially all-invalid
+
+
+@pytest.mark.parametrize("depths", [2, 5, 7, 10, 33])
+@pytest.mark.parametrize("variant", ["default", "pixel_depths", "abs_diff", "patch5"])
+def test_cost_volume_with_any_number_of_hypotheses_matches_the_oracle(hip_lib, depths, variant):
+    """The reference accepts any cv_depth_steps (monorec_model.py:184); the kernels take planes in pairs - an odd count's last pair repeats
+    the last hypothesis and drops its second plane (rounds 1-3 refused odd counts, and the plan anything but multiples of 4)."""
+    b, h, w, nf = 1, 48, 80, 2
+    batch = synth.make_batch(b, h, w, nf, seed=11)
+    kw, okw = {}, {}
+    if variant == "pixel_depths":
+        gen = torch.Generator().manual_seed(3)
+        cvd = depth_hypotheses((0.33, 0.0025), depths).view(1, depths, 1, 1) * (0.9 + 0.2 * torch.rand(b, depths, h, w, generator=gen))
+        kw, okw = {"cv_depths": cvd.to(DEV)}, {"cv_depths": cvd}
+    elif variant == "abs_diff":
+        kw, okw = {"use_ssim": 0}, {"use_ssim": False}
+    elif variant == "patch5":
+        kw, okw = {"patch": 5}, {"patch_size": 5}
+    cv, sf = _hip_cost_volume(batch, depths, **kw)
+    ocv, osf = orc.cost_volume(batch, steps=depths, **okw)
+    assert not torch.isnan(cv).any()
+    for f in range(nf):
+        assert ((sf[f] == 0).all(1) != (osf[f] == 0).all(1)).float().mean().item() <= 1e-4
+        assert ((sf[f] - osf[f]).abs() > 1e-4).float().mean().item() <= 1e-4, (f, (sf[f] - osf[f]).abs().max().item())
+    assert ((cv - ocv).abs() > 2e-4).float().mean().item() <= (5e-3 if variant == "abs_diff" else 1e-4), (cv - ocv).abs().max().item()
 
 
 @pytest.mark.parametrize("mode", [0, 2, 3])

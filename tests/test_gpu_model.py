@@ -401,6 +401,19 @@ def test_cv_patch_size_through_the_model(hip_lib):
     _check_against(out, ref, "cv_patch_size=5")
 
 
+@pytest.mark.parametrize("depths", [6, 7, 13])
+def test_any_number_of_depth_hypotheses_through_the_model(hip_lib, depths):
+    """cv_depth_steps that are not multiples of 4, odd ones included (the reference takes any: monorec_model.py:184): the whole forward
+    against the oracle (rounds 1-3 raised NotImplementedError)."""
+    batch = synth.make_batch(1, 64, 96, 2, seed=21)
+    m, sd = _model(depths, False)
+    with torch.no_grad():
+        out = m(_to_dev(batch))
+    torch.cuda.synchronize()
+    assert out["cost_volume"].shape[1] == depths and all(s.shape[1] == depths for s in out["single_frame_cvs"])
+    _check_against(out, orc.forward(sd, batch, cv_depth_steps=depths), f"D={depths}")
+
+
 def test_depth_large_model(hip_lib):
     """depth_large_model=True (monorec_model.py:482-483): the plan takes the DepthModule widths from the weights."""
     g = Golden("small_large_depth")

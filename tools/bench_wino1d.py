@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--no-upconv", action="store_true", help="skip the Upconv layers (their table does not change)")
     ap.add_argument("--taps", default="3,7", help="which filter lengths to measure")
     a = ap.parse_args()
-    _lib.load()
+    diagnostic = _lib.load().has_diagnostic_forms      # F(2,7) lives in the diagnostic build only (round 4)
     m = MonoRecModel(cv_depth_steps=a.depths)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
     ref_plan = engine.Plan(sd, a.batch, a.height, a.width, a.frames, a.depths, (0.33, 0.0025), "cpu", winograd=False)
@@ -53,7 +53,7 @@ def main():
         sig = ("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_" + engine.winograd_signature(cout, sc, sp["grid"][0], sp["grid"][1], sp["out_shape"][0])
         row = {"name": c["name"], "sig": sig, "cin": cin, "cout": cout, "hw": list(sp["grid"]), "n": sp["out_shape"][0]}
         outs = {}
-        codes = (0, 1, 2, 3, 4, 41, 42, 43, 44) if taps == 3 else (0, 21, 22, 23, 24, 41, 42, 43)
+        codes = (0, 1, 2, 3, 4, 41, 42, 43, 44) if taps == 3 else ((0, 21, 22, 23, 24, 41, 42, 43) if diagnostic else (0, 41, 42, 43))
         for code in codes:
             if code and 16 * (code % 10) >= 2 * cout and code % 10 > 1:
                 continue

@@ -24,7 +24,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_
   echo "pmc pass $i ($C) rc=$?"
 done
 cd $REPO
-python tools/summarize_prof.py --tag $TAG --stats $(find $OUT/trace -name "*_results.db" | head -1) --stats-seq $(find $OUT/trace_seq -name "*_results.db" | head -1) --pmc $(find $OUT/pmc* -name "*_results.db") | tail -40
+python tools/summarize_prof.py --tag $TAG --bench-line $OUT/bench.json --stats $(find $OUT/trace -name "*_results.db" | head -1) --stats-seq $(find $OUT/trace_seq -name "*_results.db" | head -1) --pmc $(find $OUT/pmc* -name "*_results.db") | tail -40
 cp $OUT/layers.json profiles/${TAG}_layer_times.json
 tail -1 $OUT/bench.json > profiles/${TAG}_bench.json
 mkdir -p $REPO/gpurun_out/profiles_out && cp profiles/${TAG}_* $REPO/gpurun_out/profiles_out/

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--stats-seq", default=None, help="kernel trace of the same command with --in-flight 1 (no overlap between keyframes): "
                                                       "kernel-only durations that are not inflated by a second keyframe's kernels")
     ap.add_argument("--pmc", nargs="*", default=[])
+    ap.add_argument("--bench-line", default=None, help="JSON line of bench.py from the profiled session: its roofline.profile_stamp.running_plan becomes the stamp of this set")
     ap.add_argument("--launches-per-step", type=int, default=None, help="dispatches of each kernel instance per profiled run / steps")
     args = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
@@ -83,13 +84,22 @@ def main():
             w = csv.writer(f)
             w.writerow(cols + ["note: durations in us; rocprofv3 --kernel-trace --stats; bench.py --in-flight 1 (one keyframe at a time)"])
             w.writerows(rows)
-    # every profile set carries the stamp of the plan it was taken on (tables + ABI): bench.py refuses to quote a stale one
+    # every profile set carries the stamp of the plan it was taken on (Plan.launch_stamp() of the profiled run, read from the bench
+    # line of the same session): bench.py refuses to quote a stale one
     import sys
     sys.path.insert(0, ROOT)
-    from monorec_amd import engine, _lib
+    from monorec_amd import _lib
+    stamp = None
+    if args.bench_line and os.path.exists(args.bench_line):
+        try:
+            line = json.loads(open(args.bench_line).read().strip().splitlines()[-1])
+            stamp = line["roofline"]["profile_stamp"]["running_plan"]
+        except Exception:
+            stamp = None
     with open(os.path.join(out_dir, f"{args.tag}_stamp.json"), "w") as f:
-        json.dump({"plan_stamp": engine.plan_stamp(), "abi": _lib.MR_ABI_VERSION,
-                   "note": "sha256(tuned_schedules.json + tuned_winograd.json + ABI)[:16] at the time the traces / counters of this tag were taken"}, f)
+        json.dump({"plan_stamp": stamp, "abi": _lib.MR_ABI_VERSION,
+                   "note": "Plan.launch_stamp() of the profiled run = sha256(kernel family, variant and schedule of every convolution launch + ABI)[:16], "
+                           "from the bench line of the session that took the traces / counters of this tag"}, f)
     agg = collections.defaultdict(dict)
     for path in args.pmc:
         c = sqlite3.connect(path)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 16
+#define MR_ABI_VERSION 17
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -222,15 +222,19 @@ int mr_conv3x3_winograd_f32(const mr_wino_desc* desc, void* stream);
  * way).  Same descriptor and conventions as mr_conv3x3_winograd_f32 (`cout_blocks_per_wave` and `variant` ignored); a workgroup (8 waves)
  * produces 16 x 64 output pixels x 32 output channels and uses 153 KB of LDS, so it pays where the layer has >= 256 such workgroups.
  *
- * DIAGNOSTIC LIBRARY ONLY since ABI 16 (python -m monorec_amd.build --timeline -> libmonorec_hip_timeline.so, selected with MR_HIP_LIBRARY):
- * measured on the MI355X it runs at a quarter of its matrix-core time (one 153 KB workgroup per CU), is 1.19x ahead of F(2x2,3x3) on one
- * pair of 37 us layers of c2 and moves keyframes/s by nothing - below the bar for a form with transform constants up to 8 in the product.
+ * In the product library again since ABI 17 (ABI 16 had moved it to the diagnostic build: at c2 it buys nothing end to end); measured on
+ * the c3 and configs[4] shapes it is 12-15 % ahead of the best F(2x2,3x3) variant on every full- and half-resolution 3x3 layer
+ * (tools/sessions/r04_s18.sh), and only those table entries select it.
  */
-#ifdef MR_DIAGNOSTIC_LIBRARY
 size_t mr_wino44_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src);
 int mr_wino44_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
 int64_t mr_conv3x3_winograd44_lds_bytes(const mr_wino_desc* desc);
 int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream);
+
+/* Exported by the DIAGNOSTIC build only (python -m monorec_amd.build --timeline -> libmonorec_hip_timeline.so, selected with MR_HIP_LIBRARY):
+ * bit 0 = the F(2,7) instantiations of mr_conv1d_cooktoom_f32 are present (no measured table entry ever selected them). */
+#ifdef MR_DIAGNOSTIC_LIBRARY
+int mr_diagnostic_forms(void);
 #endif
 
 /*

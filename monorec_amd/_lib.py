@@ -87,7 +87,7 @@ class B8ConvDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 16            # include/monorec_hip.h
+MR_ABI_VERSION = 17            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -233,6 +233,10 @@ ABI = {
     "mr_dso_inverse_depth_u16_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_double, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "mr_wino44_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
+    "mr_wino44_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
+    "mr_conv3x3_winograd44_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_conv3x3_winograd44_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_abi_version": (ctypes.c_int, []),
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }
@@ -240,10 +244,7 @@ ABI = {
 # exported by the diagnostic library only (python -m monorec_amd.build --timeline; include/monorec_hip.h under MR_DIAGNOSTIC_LIBRARY): typed
 # when present, never required
 DIAGNOSTIC_ABI = {
-    "mr_wino44_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
-    "mr_wino44_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
-    "mr_conv3x3_winograd44_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
-    "mr_conv3x3_winograd44_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
+    "mr_diagnostic_forms": (ctypes.c_int, []),      # bit 0: F(2,7) instantiations present
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmonorec_hip.so")

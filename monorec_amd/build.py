@@ -28,12 +28,13 @@ SOURCES = [
     ("convt_wino.hip", []),
     ("conv1d_wino.hip", []),
     ("conv_b8.hip", []),
+    ("conv_wino44.hip", []),
 ]
-# conv_wino44.hip (F(4x4,3x3)) is built into the DIAGNOSTIC library only since round 4: it runs at a quarter of its MFMA time, is 1.19x
-# ahead of F(2x2,3x3) on one 37 us layer pair of c2 and moved keyframes/s by nothing (697 -> 698) - below the bar for a kernel with
-# transform constants up to 8 in the product.  The same goes for the F(2,7) instantiations of conv1d_wino.hip,
-# which no table entry ever selected.
-DIAGNOSTIC_ONLY_SOURCES = [("conv_wino44.hip", [])]
+# conv_wino44.hip (F(4x4,3x3)): out of the product library for most of round 4 (at c2 it moved keyframes/s by nothing),
+# back in once its c3 / configs[4] tables were measured (tools/sessions/r04_s18.sh): 12-15 % ahead of the best F(2x2,3x3) variant on every
+# full- and half-resolution layer of those shapes (c3 mask.enc0.* 1682 -> 1469 us each; 0.63 ms of a 13.9 ms batch).  The F(2,7)
+# instantiations of conv1d_wino.hip, which no table entry ever selected, stay in the DIAGNOSTIC library only.
+DIAGNOSTIC_ONLY_SOURCES = []
 
 
 def _hipcc():
@@ -85,7 +86,7 @@ DIAGNOSTIC = {"conv_mfma.hip": "-DMR_CONV_TIMELINE",     # per-workgroup timesta
               "cost_volume.hip": "-DMR_TUNING_ENV",      # MR_CV_MARCH_TY / MR_CV_MARCH_DP / MR_CV_NO_KF_PREPASS (tools/bench_cv.py sweeps)
               "heads.hip": "-DMR_TUNING_ENV",            # MR_HEADS_QUAD_MIN (tools/bench_heads.py)
               "conv1d_wino.hip": "-DMR_DIAGNOSTIC_FORMS",   # the F(2,7) instantiations
-              "eltwise.hip": "-DMR_DIAGNOSTIC_FORMS",       # MR_LAUNCH_WINO44 in mr_run_launches
+              "eltwise.hip": "-DMR_DIAGNOSTIC_FORMS",       # exports mr_diagnostic_forms(): how _lib.load() tells the two builds apart
               "conv_b8.hip": "-DMR_B8_ABLATE"}              # MR_B8_DBG ablation bits (tools/bench_b8.py)
 
 

@@ -338,11 +338,7 @@ extern "C" int mr_run_launches(const mr_launch_item* items, int32_t num, void* s
             case MR_LAUNCH_WINO_T: rc = mr_convt4x4s2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_WINO_1D: rc = mr_conv1d3_winograd_f32((const mr_wino_desc*)items[i].desc, items[i].arg, stream); break;
             case MR_LAUNCH_UPCONV: rc = mr_upconv2x2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
-#ifdef MR_DIAGNOSTIC_FORMS
             case MR_LAUNCH_WINO44: rc = mr_conv3x3_winograd44_f32((const mr_wino_desc*)items[i].desc, stream); break;
-#else
-            case MR_LAUNCH_WINO44: rc = MR_ERR_UNSUPPORTED; break;      // F(4x4,3x3): diagnostic library only
-#endif
             case MR_LAUNCH_CONV_B8: rc = mr_conv2d_b8((const mr_b8_conv_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_COOKTOOM_1D:
                 rc = mr_conv1d_cooktoom_f32((const mr_wino_desc*)items[i].desc, items[i].arg & 15, (items[i].arg >> 4) & 15, (items[i].arg >> 8) & 15, stream);
@@ -368,3 +364,8 @@ extern "C" const char* mr_error_string(int code) {
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "monorec_hip: unknown error";
     }
 }
+
+#ifdef MR_DIAGNOSTIC_FORMS
+// exported by the diagnostic build only (bit 0: the F(2,7) instantiations of csrc/conv1d_wino.hip are present)
+extern "C" int mr_diagnostic_forms(void) { return 1; }
+#endif

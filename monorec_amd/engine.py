@@ -636,9 +636,6 @@ class Plan:
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = weight.detach().to(torch.float32).contiguous().cpu()
         if variant == 3:       # F(4x4,3x3) (csrc/conv_wino44.hip): 36 positions, 16 x 64 pixels x 32 channels per workgroup
-            if not lib.has_diagnostic_forms:
-                raise RuntimeError(f"{name}: table code 31 (F(4x4,3x3)) needs the diagnostic library (python -m monorec_amd.build --timeline, "
-                                   "MR_HIP_LIBRARY); the product library does not carry that kernel")
             nfl = lib.mr_wino44_packed_weight_floats(cout, sc, len(src_channels))
             packed = torch.empty(nfl, dtype=torch.float32)
             _lib.check(lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44_pack_weights_f32")

@@ -286,7 +286,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     wino = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3)]
     assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
                                          "mask.dec3.2", "depth.dec4.2"}
-    # (F(2x2,3x3): 16 of 36 multiplies; F(4x4,3x3), csrc/conv_wino44.hip, lives in the diagnostic library since round 4: no table entry)
+    # (F(2x2,3x3): 16 of 36 multiplies; F(4x4,3x3), csrc/conv_wino44.hip, is selected by the c3 / configs[4] entries only)
     assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
     assert not [c["name"] for c in wino if c.get("wino_variant") == 3]
     assert {c["name"] for c in wino if c.get("wino_variant") == 2} == {"mask.dec3.1", "mask.dec3.2"}     # 48 channels: 32 + a 16-channel tail
@@ -730,6 +730,17 @@ def test_winograd_weight_packing_and_algebra(hip_lib):
     assert np.abs(Y - ref).max() < 1e-12
 
 
+def test_c3_plan_runs_the_large_3x3_layers_as_f44(hip_lib):
+    """The c3 shape (batch 8, 4 frames, 64 bins): the table measured in tools/sessions/r04_s18.sh sends every full- and half-resolution 3x3
+    stride-1 layer to F(4x4,3x3) (csrc/conv_wino44.hip: 36 of 144 multiplies per 4x4 outputs, one 153 KB workgroup per CU); c2 keeps F(2x2,3x3)."""
+    m = MonoRecModel(cv_depth_steps=64)
+    plan = engine.Plan(synth.seeded_state_dict(m.state_dict()), 8, 256, 512, 4, 64, (0.33, 0.0025), "cpu")
+    f44 = [c for c in plan.conv_log if c.get("wino_variant") == 3]
+    assert {c["name"] for c in f44} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.enc2.0", "mask.enc2.1", "mask.dec2.1",
+                                        "mask.dec2.2", "mask.dec3.1", "mask.dec3.2", "depth.dec4.2"}
+    assert all(c["macs"] * 4 == c["ref_macs"] and c["lds"] <= 160 * 1024 and c["wgs"] >= 512 for c in f44)
+
+
 def test_winograd_choice_table_and_rule():
     """engine.choose_winograd: the measured table wins (c2: the two full-resolution mask stages and the big decoder layers go to the
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count
@@ -745,7 +756,7 @@ def test_winograd_choice_table_and_rule():
     assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
     assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) in (2, 12, 21)  # mask.enc0.*, mask.dec3.1 @ c2
     assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
-    assert engine.choose_winograd(64, [64], 256, 512, 32) in (2, 11, 12)                                                     # mask.enc0.* @ c3
+    assert engine.choose_winograd(64, [64], 256, 512, 32) == 31                                                              # mask.enc0.* @ c3: F(4x4,3x3) (r04_s18)
     assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct
     assert engine.choose_winograd(32, [32], 256, 768, 3) == 11         # unknown, 2304 workgroups, 32 couts: transform in registers
     assert engine.choose_winograd(96, [96], 256, 768, 3) == 2
@@ -885,8 +896,6 @@ def test_winograd44_weight_packing(hip_lib):
     """mr_wino44_pack_weights_f32: U = G g G^T (6 x 6, G of F(4,3): cooktoom.py) in double, rounded once, in the stream order conv_wino44.hip
     reads - [group of 32 couts][chunk of 8 channels, source-major][position 6 i + j][channel quad][block of 16][64 lanes]."""
     from monorec_amd import cooktoom
-    if not hip_lib.has_diagnostic_forms:
-        pytest.skip("F(4x4,3x3) is built into the diagnostic library only (python -m monorec_amd.build --timeline, MR_HIP_LIBRARY)")
     G = np.array([[float(v) for v in row] for row in cooktoom.cook_toom(4, 3)[1]])
     g = torch.Generator().manual_seed(13)
     srcs_c, cout = [5, 11], 40

@@ -871,8 +871,6 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
     """mr_conv3x3_winograd44_f32 (F(4x4,3x3), csrc/conv_wino44.hip) against F.conv2d(padding=1) on the CPU.  Its transforms have coefficients up
     to 8, so it rounds more than F(2x2,3x3): the fp32 emulation of the form (oracle/numerics_study_winograd.py) is within 9e-6 of the fp64
     result on these cases (F(2x2,3x3): 6e-7); bar 4e-5 of the output scale - model level: depth moves by 2.4e-7."""
-    if not hip_lib.has_diagnostic_forms:
-        pytest.skip("diagnostic library only since round 4 (python -m monorec_amd.build --timeline, MR_HIP_LIBRARY): not in the product")
     srcs_c, cout, (h, w), batch, act, residual, _ = (WINO_CASES + WINO44_EXTRA_CASES)[case]
     lib = hip_lib
     g = torch.Generator().manual_seed(100 + case)
@@ -915,7 +913,7 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
 def test_plan_routes_3x3_layers_to_the_f44_kernel(hip_lib, monkeypatch):
     """Table code 31 sends a 3x3 stride-1 layer to mr_conv3x3_winograd44_f32 (through the native launch list as well); the executed
     multiply-adds are a quarter of the reference's."""
-    codes = (0, 21, 31) if hip_lib.has_diagnostic_forms else (0, 21)     # F(4x4,3x3): diagnostic library only since round 4
+    codes = (0, 21, 31)
     g = torch.Generator().manual_seed(80)
     xs = [torch.randn(2, 16, 32, 128, generator=g), torch.randn(2, 24, 32, 128, generator=g)]
     wt = torch.randn(48, 40, 3, 3, generator=g) * (1.0 / (3.0 * math.sqrt(40.0)))

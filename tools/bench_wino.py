@@ -67,7 +67,7 @@ def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, varia
     return (lambda stream: _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), "wino")), keep
 
 
-CODES = (1, 2, 11, 12, 21, 31)       # 31 = F(4x4,3x3): measured only when the loaded library is the diagnostic build (round 4: not in the product)
+CODES = (1, 2, 11, 12, 21, 31)
 
 
 def main():
@@ -83,9 +83,6 @@ def main():
                                                  "transform in registers) to this JSON file; entries already in the file for other shapes are kept")
     a = ap.parse_args()
     lib = _lib.load()
-    global CODES
-    if not lib.has_diagnostic_forms:
-        CODES = tuple(c for c in CODES if c != 31)
     m = MonoRecModel(cv_depth_steps=a.depths)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
     ref_plan = engine.Plan(sd, a.batch, a.height, a.width, a.frames, a.depths, (0.33, 0.0025), "cpu", winograd=False)

@@ -28,7 +28,7 @@ SOURCES = [
     ("convt_wino.hip", []),
     ("conv1d_wino.hip", []),
     ("conv_b8.hip", []),
-    ("conv_wino44.hip", []),
+    ("conv_wino44.hip", ["-fno-slp-vectorize"]),      # packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md)
 ]
 # conv_wino44.hip (F(4x4,3x3)): out of the product library for most of round 4 (at c2 it moved keyframes/s by nothing),
 # back in once its c3 / configs[4] tables were measured (tools/sessions/r04_s18.sh): 12-15 % ahead of the best F(2x2,3x3) variant on every
@@ -87,7 +87,8 @@ DIAGNOSTIC = {"conv_mfma.hip": "-DMR_CONV_TIMELINE",     # per-workgroup timesta
               "heads.hip": "-DMR_TUNING_ENV",            # MR_HEADS_QUAD_MIN (tools/bench_heads.py)
               "conv1d_wino.hip": "-DMR_DIAGNOSTIC_FORMS",   # the F(2,7) instantiations
               "eltwise.hip": "-DMR_DIAGNOSTIC_FORMS",       # exports mr_diagnostic_forms(): how _lib.load() tells the two builds apart
-              "conv_b8.hip": "-DMR_B8_ABLATE"}              # MR_B8_DBG ablation bits (tools/bench_b8.py)
+              "conv_b8.hip": "-DMR_B8_ABLATE",              # MR_B8_DBG ablation bits (tools/bench_b8.py)
+              "conv_wino44.hip": "-DMR_W44_ABLATE"}         # MR_W44_DBG ablation bits (tools/sessions/r04_s23.sh)
 
 
 def build_timeline(verbose=False):

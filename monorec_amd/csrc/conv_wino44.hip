@@ -14,11 +14,14 @@
 // pitch 1296 = 16 mod 32 banks, hardware zero fill = padding) and the chunk's U fragments (36 positions; host-packed G g G^T, formed in double and
 // rounded once) arrive by LDS-DMA in one of two pipeline buffers (2 x 76.5 KB: one workgroup per CU - the 36 accumulator sets need 144 of a wave's
 // 256 registers, so two waves per SIMD is what fits anyway); ONE barrier per chunk.  A lane reads the 6x6 patch of its (tile, channel) as 18
-// 16-byte LDS reads, transforms rows then columns with the generated F(4,3) chain (one channel quad at a time: 36 live B operands) and issues
-// 36 MFMAs per quad; it ends up with all 36 positions of its (output channel, tile), so A^T M A, bias, residual, activation run in registers and
+// 16-byte LDS reads, transforms rows then columns with the generated F(4,3) chain (one channel quad at a time: 36 live B operands), reads the
+// quad's 36 A operands up front and issues 36 MFMAs (a variant with ONE 16-byte read per patch row and the outer columns from the
+// neighbouring lanes by DPP moved 2.4x fewer LDS bytes and was no faster - tools/sessions/r04_s24.sh: the reads cost their latency, not
+// their bandwidth); it ends up with all 36 positions of its (output channel, tile), so A^T M A, bias, residual, activation run in registers and
 // the 4x4 tile leaves as four 16-byte stores.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 
@@ -37,7 +40,7 @@ constexpr int ROWS = RH + 2, PITCH = RW + 8;             // raw region: rows oy0
 constexpr int G4 = PITCH / 4, NG = ROWS * G4;            // 16-byte groups per channel plane (324)
 constexpr int NI = (NG + 63) / 64;                       // DMA instructions per plane (6)
 constexpr int PLANE = ROWS * PITCH;                      // 1296 floats = 16 mod 32 banks
-constexpr int U_FLOATS = NP * 2 * 2 * 64;                // U fragments of one chunk: [p][channel quad][cout block][64 lanes]
+constexpr int U_FLOATS = NP * 2 * 2 * 64;                // U fragments of one chunk: [channel quad][cout block][j][64 lanes][i]
 constexpr int BUF = WCK * PLANE + U_FLOATS;              // one pipeline buffer
 static_assert(PLANE % 32 == 16 && PLANE % 4 == 0 && U_FLOATS % 256 == 0, "layout");
 
@@ -57,6 +60,11 @@ struct W44KArgs {
     const float* w;
     long long wgroup_stride;            // packed floats per group of 32 output channels
 };
+
+// Ablations (diagnostic library only: python -m monorec_amd.build --timeline, -DMR_W44_ABLATE; MR_W44_DBG picks an instantiation): compile-time,
+// because a run-time flag in a kernel at 254 registers changes what is measured (tried: 1352 -> 2896 us with the flag present and zero).
+// bits: 1 no input transform, 2 no MFMAs, 4 no patch reads, 8 no A reads, 16 no DMA
+#define W44_DBG(bit) (DBG & (bit))
 
 // LDS-DMA through inline asm (see conv_mfma.hip: the builtins make hipcc drain vmcnt before every sweep)
 __device__ __forceinline__ void dma_buffer_x4(unsigned lds_byte_addr, int voff, i32x4 srd, int soff) {
@@ -93,6 +101,13 @@ __device__ __forceinline__ float act44(float v, int act, float p0) {
     return v > 0.f ? v : v * slope;
 }
 
+// Measured and not kept (tools/sessions/r04_s23.sh - s25.sh, c3 mask.enc0.0, 1353 us): the ablations add up almost exactly - MFMA 398 + patch
+// reads 371 + input transform 279 + DMA wait 231 + A reads 70 us - i.e. the eight waves of a workgroup hit the LDS, the VALU and the matrix
+// pipe one after the other.  A "ping-pong" loop (the two waves of a SIMD one phase apart - one loads + transforms while the other issues its 36
+// MFMAs from registers - a barrier per phase) was correct and 19 % SLOWER (1587 us): a lone wave per SIMD stretches the load + transform phase
+// (dependent VALU chains, LDS round trips) beyond what the overlap buys, as round 2 found for F(2x2,3x3).  One 16-byte + one 4-byte LDS read per
+// patch row with the outer columns by DPP (2.4x fewer LDS bytes) and 24 % fewer transform instructions changed nothing either.
+template <int DBG>
 __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -121,6 +136,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
 
     int cs = 0, cc0 = 0;                                      // chunk cursor: source, first channel
     auto issue = [&](int q, int pb) {
+        if (W44_DBG(16)) return;
         const unsigned buf_addr = lds_base + pb * BUF * 4;
         const unsigned u_addr = buf_addr + WCK * PLANE * 4;
         const float* wsrc = wgrp + (long long)q * U_FLOATS;
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
     for (int q = 0; q < a.nchunks; ++q) {
         const int pb = q & 1;
         const float* raw = lds + pb * BUF;
-        const float* ub = raw + WCK * PLANE + cb * 64 + lane;
+        const float* ub = raw + WCK * PLANE + cb * (6 * 64 * 6) + lane * 6;   // U of a chunk: [quad][block][j][lane][i], position p = 6 i + j
         dma_wait_all();
         __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
         if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
@@ -153,19 +169,34 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
 #pragma nounroll
         for (int c4 = 0; c4 < 2; ++c4) {
             const float* rp = raw + patch0 + c4 * 4 * PLANE;
+            // the 36 A operands of the quad first, as 18 8-byte reads (lane pitch 24 bytes: conflict free), and nothing may sink them:
+            // left to itself hipcc reads every operand right in front of its MFMA (230 registers in use) and the wave waits out an LDS
+            // round trip a dozen times per quad
+            const float* uq = ub + c4 * (2 * 6 * 64 * 6);
+            float2 av[6][3];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) av[j][k] = W44_DBG(8) ? make_float2((float)(lane + j), (float)k) : *(const float2*)(uq + j * (64 * 6) + 2 * k);
+            __builtin_amdgcn_sched_barrier(0);
             float v[NP];                                      // h = d B per patch row first, then B^T h per column, in place
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 float x[12];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const f32x4 g = *(const f32x4*)(rp + r * PITCH + 4 * j);
+                    const f32x4 g = W44_DBG(4) ? (f32x4){(float)lane, (float)r, (float)j, 1.f} : *(const f32x4*)(rp + r * PITCH + 4 * j);
                     x[4 * j] = g.x; x[4 * j + 1] = g.y; x[4 * j + 2] = g.z; x[4 * j + 3] = g.w;
                 }
                 float d[6], h[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) d[c] = x[3 + c];
-                ct_input_4_3(d, h);
+                if (W44_DBG(1)) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) h[c] = d[c];
+                } else {
+                    ct_input_4_3(d, h);
+                }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) v[r * 6 + c] = h[c];
             }
@@ -174,13 +205,23 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
                 float d[6], h[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) d[r] = v[r * 6 + c];
-                ct_input_4_3(d, h);
+                if (W44_DBG(1)) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) h[r] = d[r];
+                } else {
+                    ct_input_4_3(d, h);
+                }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) v[r * 6 + c] = h[r];
             }
-            const float* uq = ub + c4 * 128;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[p * 256], v[p], acc[p], 0, 0, 0);
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float av_ = (i & 1) ? av[j][i >> 1].y : av[j][i >> 1].x;
+                    if (W44_DBG(2)) acc[i * 6 + j][0] += av_ * v[i * 6 + j];
+                    else acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, v[i * 6 + j], acc[i * 6 + j], 0, 0, 0);
+                }
         }
     }
     // ---- output transform Y = A^T M A per (cout, tile) in registers, epilogue --------------------------------------------------------
@@ -271,8 +312,9 @@ extern "C" size_t mr_wino44_packed_weight_floats(int32_t out_channels, const int
 }
 
 // weight: (out_channels, sum(src_channels), 3, 3) fp32, nn.Conv2d layout.  U = G g G^T (6 x 6; G of F(4,3): cooktoom_1d.h) in double, rounded
-// once to fp32; stream order [group of 32 output channels][chunk (source-major, 8 channels)][position p = 6 i + j][channel quad][block of
-// 16 channels of the group][64 lanes], lane l = (cout l & 15 of the block, channel l >> 4 of the quad).
+// once to fp32; stream order [group of 32 output channels][chunk (source-major, 8 channels)][channel quad][block of 16 channels of the
+// group][j][64 lanes][i] with position p = 6 i + j, lane l = (cout l & 15 of the block, channel l >> 4 of the quad): a lane reads the six
+// operands of a transform column as three 8-byte words.
 extern "C" int mr_wino44_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst) {
     if (!weight || !dst || !src_channels || num_src < 1 || num_src > MR_MAX_SOURCES || out_channels < 1) return MR_ERR_BAD_ARGUMENT;
     int cin_total = 0;
@@ -284,10 +326,12 @@ extern "C" int mr_wino44_pack_weights_f32(const float* weight, int32_t out_chann
         for (int s = 0; s < num_src; ++s) {
             const int cpad = pad8(src_channels[s]);
             for (int c0 = 0; c0 < cpad; c0 += WCK)
-                for (int p = 0; p < NP; ++p)
-                    for (int c4 = 0; c4 < 2; ++c4)
-                        for (int mb = 0; mb < 2; ++mb)
-                            for (int lane = 0; lane < 64; ++lane) {
+                for (int c4 = 0; c4 < 2; ++c4)
+                    for (int mb = 0; mb < 2; ++mb)
+                        for (int pj_ = 0; pj_ < 6; ++pj_)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int pi_ = 0; pi_ < 6; ++pi_) {
+                                const int p = pi_ * 6 + pj_;
                                 const int cout = g * 32 + mb * 16 + (lane & 15);
                                 const int cl = c0 + c4 * 4 + (lane >> 4);
                                 double u = 0.0;
@@ -318,15 +362,38 @@ extern "C" int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream)
     W44Derived dv;
     const int rc = derive44(desc, &dv);
     if (rc != 0) return rc;
-    static std::atomic<unsigned long long> attr_set{0};      // dynamic-LDS ceiling once per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino44_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set.fetch_or(bit, std::memory_order_release);
+    auto launch = [&](auto kernel, std::atomic<unsigned long long>& attr_set) -> int {      // dynamic-LDS ceiling once per device and instantiation
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kernel, dv.grid, dim3(512), dv.lds_bytes, (hipStream_t)stream, dv.k);
+        return 0;
+    };
+    static std::atomic<unsigned long long> set0{0};
+#ifdef MR_W44_ABLATE
+    static const int dbg = [] { const char* e = getenv("MR_W44_DBG"); return e ? atoi(e) : 0; }();
+    static std::atomic<unsigned long long> setd[8];
+    int rc2 = -1000;
+    switch (dbg) {
+        case 0: break;
+        case 1: rc2 = launch(conv3x3_wino44_kernel<1>, setd[0]); break;
+        case 2: rc2 = launch(conv3x3_wino44_kernel<2>, setd[1]); break;
+        case 4: rc2 = launch(conv3x3_wino44_kernel<4>, setd[2]); break;
+        case 8: rc2 = launch(conv3x3_wino44_kernel<8>, setd[3]); break;
+        case 16: rc2 = launch(conv3x3_wino44_kernel<16>, setd[4]); break;
+        case 5: rc2 = launch(conv3x3_wino44_kernel<5>, setd[5]); break;
+        case 13: rc2 = launch(conv3x3_wino44_kernel<13>, setd[6]); break;
+        case 29: rc2 = launch(conv3x3_wino44_kernel<29>, setd[7]); break;
+        default: return MR_ERR_BAD_ARGUMENT;
     }
-    hipLaunchKernelGGL(conv3x3_wino44_kernel, dv.grid, dim3(512), dv.lds_bytes, (hipStream_t)stream, dv.k);
+    if (rc2 != -1000) return rc2 != 0 ? rc2 : (int)hipGetLastError();
+#endif
+    const int rc3 = launch(conv3x3_wino44_kernel<0>, set0);
+    if (rc3 != 0) return rc3;
     return (int)hipGetLastError();
 }

@@ -286,10 +286,11 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     wino = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3)]
     assert {c["name"] for c in wino} == {"mask.enc0.0", "mask.enc0.1", "mask.enc1.0", "mask.enc1.1", "mask.dec2.1", "mask.dec2.2", "mask.dec3.1",
                                          "mask.dec3.2", "depth.dec4.2"}
-    # (F(2x2,3x3): 16 of 36 multiplies; F(4x4,3x3), csrc/conv_wino44.hip, is selected by the c3 / configs[4] entries only)
-    assert all(c["macs"] * 9 == c["ref_macs"] * 4 and c["lds"] <= 160 * 1024 for c in wino)
-    assert not [c["name"] for c in wino if c.get("wino_variant") == 3]
-    assert {c["name"] for c in wino if c.get("wino_variant") == 2} == {"mask.dec3.1", "mask.dec3.2"}     # 48 channels: 32 + a 16-channel tail
+    # (F(2x2,3x3): 16 of 36 multiplies; F(4x4,3x3), csrc/conv_wino44.hip: 36 of 144 - the four full-resolution layers since r04_s26)
+    f44 = {c["name"] for c in wino if c.get("wino_variant") == 3}
+    assert f44 == {"mask.enc0.0", "mask.enc0.1", "mask.dec3.1", "mask.dec3.2"}
+    assert all((c["macs"] * 4 == c["ref_macs"] if c["name"] in f44 else c["macs"] * 9 == c["ref_macs"] * 4) and c["lds"] <= 160 * 1024 for c in wino)
+    assert not [c["name"] for c in wino if c.get("wino_variant") == 2]     # (the 48-channel layers ran 32 + a 16-channel tail on F(2x2,3x3))
     # ... and the two large Refine layers (ConvTranspose2d(4, 2)) on the F(2x2,2x2) kernel (csrc/convt_wino.hip) at 9/16
     wino_t = [c for c in plan.conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv")]
     assert {c["name"] for c in wino_t} == {"depth.dec2.0", "depth.dec3"}
@@ -732,7 +733,7 @@ def test_winograd_weight_packing_and_algebra(hip_lib):
 
 def test_c3_plan_runs_the_large_3x3_layers_as_f44(hip_lib):
     """The c3 shape (batch 8, 4 frames, 64 bins): the table measured in tools/sessions/r04_s18.sh sends every full- and half-resolution 3x3
-    stride-1 layer to F(4x4,3x3) (csrc/conv_wino44.hip: 36 of 144 multiplies per 4x4 outputs, one 153 KB workgroup per CU); c2 keeps F(2x2,3x3)."""
+    stride-1 layer to F(4x4,3x3) (csrc/conv_wino44.hip: 36 of 144 multiplies per 4x4 outputs, one 153 KB workgroup per CU)."""
     m = MonoRecModel(cv_depth_steps=64)
     plan = engine.Plan(synth.seeded_state_dict(m.state_dict()), 8, 256, 512, 4, 64, (0.33, 0.0025), "cpu")
     f44 = [c for c in plan.conv_log if c.get("wino_variant") == 3]
@@ -754,7 +755,7 @@ def test_winograd_choice_table_and_rule():
     assert engine.choose_winograd_1d(0, 48, [48], 128, 256, 1, 7) == 0                                                                            # unknown 7-tap shape: direct
     assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
     assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
-    assert engine.choose_winograd(32, [32], 256, 512, 2) % 10 == 1 and engine.choose_winograd(48, [32, 64], 256, 512, 1) in (2, 12, 21)  # mask.enc0.*, mask.dec3.1 @ c2
+    assert engine.choose_winograd(32, [32], 256, 512, 2) == 31 and engine.choose_winograd(48, [32, 64], 256, 512, 1) == 31  # mask.enc0.*, mask.dec3.1 @ c2: F(4x4,3x3)
     assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
     assert engine.choose_winograd(64, [64], 256, 512, 32) == 31                                                              # mask.enc0.* @ c3: F(4x4,3x3) (r04_s18)
     assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct
@@ -894,7 +895,7 @@ def test_cooktoom_weight_packing_and_plan_routing(hip_lib, monkeypatch):
 
 def test_winograd44_weight_packing(hip_lib):
     """mr_wino44_pack_weights_f32: U = G g G^T (6 x 6, G of F(4,3): cooktoom.py) in double, rounded once, in the stream order conv_wino44.hip
-    reads - [group of 32 couts][chunk of 8 channels, source-major][position 6 i + j][channel quad][block of 16][64 lanes]."""
+    reads - [group of 32 couts][chunk of 8 channels, source-major][channel quad][block of 16][j][64 lanes][i], position p = 6 i + j."""
     from monorec_amd import cooktoom
     G = np.array([[float(v) for v in row] for row in cooktoom.cook_toom(4, 3)[1]])
     g = torch.Generator().manual_seed(13)
@@ -908,14 +909,14 @@ def test_winograd44_weight_packing(hip_lib):
     assert n == groups * sum(cpads) // 8 * (36 * 2 * 2 * 64)
     packed = torch.empty(n)
     _lib.check(hip_lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
-    st = packed.numpy().reshape(groups, sum(cpads) // 8, 36, 2, 2, 64)
+    st = packed.numpy().reshape(groups, sum(cpads) // 8, 2, 2, 6, 64, 6)      # [group][chunk][quad][block][j][lane][i], position p = 6 i + j
     want = np.einsum("ia,ocab,jb->ijoc", G, w.double().numpy(), G).reshape(36, cout, cin)
     off, cin_off = 0, 0
     for c, cp in zip(srcs_c, cpads):
         for cl in range(cp):
             q, c4, hi = (off + cl) // 8, ((off + cl) % 8) // 4, (off + cl) % 4
             for co in range(groups * 32):
-                got = st[co // 32, q, :, c4, (co // 16) % 2, hi * 16 + co % 16]
+                got = st[co // 32, q, c4, (co // 16) % 2, :, hi * 16 + co % 16, :].T.reshape(36)     # (j, i) -> p = 6 i + j
                 exp = want[:, co, cin_off + cl] if (co < cout and cl < c) else np.zeros(36)
                 assert np.allclose(got, exp, rtol=3e-7, atol=1e-9), (co, cl)
         off, cin_off = off + cp, cin_off + c

@@ -359,7 +359,9 @@ def secondary_dynamic_batching(sd, batch_dev, ref, dev, args, steps=160):
     two thirds of the launches are latency chains; `value` keeps one launch chain per request."""
     import collections
     from monorec_amd import MonoRecModel
-    out = {"unit": "keyframes/s", "steps": steps, "note": "requests coalesced per launch by submit(); secondary - the headline launches every request on its own"}
+    out = {"unit": "keyframes/s", "steps": steps,
+           "note": "requests coalesced per launch by submit(); secondary - the headline launches every request on its own.  2 and 4 are the batch sizes of the "
+                   "reference's own evaluation configs (configs/evaluate/eval_monorec.json:29, eval_monorec_oxrc.json:26); both have measured table entries"}
     for k in (2, 4):
         m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=2, hip_batch_keyframes=k)
         m.load_state_dict(sd)

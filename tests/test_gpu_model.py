@@ -455,6 +455,25 @@ def test_bf16_mode_end_to_end(hip_lib):
     assert cverr < 5e-2
 
 
+@pytest.mark.parametrize("depths", [7, 20])
+def test_bf16_mode_with_depth_counts_off_the_fast_paths(hip_lib, depths):
+    """hip_bf16=True with a depth count that has no register-resident fusion kernel (the B8 copies of the volumes then come from the
+    layout-conversion kernels, channel counts that are not multiples of 8 included): same accuracy bar as the 16-hypotheses case."""
+    m = MonoRecModel(cv_depth_steps=depths, hip_in_flight=1, hip_bf16=True)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    batch = synth.make_batch(1, 64, 96, 2, seed=5)
+    with torch.no_grad():
+        out = m(_to_dev(batch))
+    torch.cuda.synchronize()
+    ref = orc.forward(sd, batch, cv_depth_steps=depths)
+    err = (out["result"].cpu() - ref["result"]).abs()
+    assert torch.isfinite(out["result"]).all() and out["cost_volume"].shape[1] == depths
+    assert err.max().item() <= BF16_MAX_ERR and err.mean().item() <= BF16_MEAN_ERR, (err.max().item(), err.mean().item())
+    assert (out["cost_volume"].cpu() - ref["cost_volume"]).abs().max().item() < 5e-2
+
+
 def test_bf16x3_mode_end_to_end(hip_lib):
     """hip_bf16x3=True: convolutions as three bf16 MFMAs over hi/lo splits.  CPU emulation of this arithmetic over the whole network
     gives 4e-6 on the depth (fp32 path: 1.3e-6), the MI355X 3.7e-6: it has to meet the same 1e-4 bar as the fp32 default.

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
+    ap.add_argument("--host-prime-ms", type=float, default=3.0, help="tail of the untimed warm-up: prepare() calls (the pose algebra of a request: ATen 4x4 operators + one small gather launch "
+                                                                      "when the matrices live on the device) for this many ms between the synchronize() that closes the spin-up and the timed region; 0 = none")
     ap.add_argument("--step-times", action="store_true", help="diagnostic: host time stamps after every timed step and after the drain, on the line as `step_marks_ms`")
     ap.add_argument("--spinup-seconds", type=float, default=3.0, help="minimum untimed spin-up before the timed steps")
     ap.add_argument("--bf16x3", action="store_true",
@@ -523,6 +525,8 @@ def main():
     s_submit = torch.cuda.current_stream() if (not args.side_streams) else torch.cuda.Stream()
     s_result = torch.cuda.current_stream() if (not args.side_streams) else torch.cuda.Stream()
 
+    step_parts = []          # --step-times: (prepare, wait for the slot's previous result, submit) ms of every step
+
     def step():
         """One forward over one resident batch.  With --in-flight N keyframes in flight the result of step i - N is collected right
         before step i is submitted (its slot is the one step i reuses; keyframes are independent); every step's outputs are produced
@@ -538,10 +542,15 @@ def main():
                         last[0] = pending.popleft().result()
             else:
                 req = dict(batch_dev)
+                t_a = time.perf_counter()
                 token = model.prepare(req)                       # pose algebra of this request while the device is busy ...
+                t_b = time.perf_counter()
                 if len(pending) >= args.in_flight:
                     last[0] = pending.popleft().synchronize()    # ... then the result whose slot the submit below reuses
+                t_c = time.perf_counter()
                 pending.append(model.submit(req, token))
+                if args.step_times:
+                    step_parts.append((round(1e3 * (t_b - t_a), 3), round(1e3 * (t_c - t_b), 3), round(1e3 * (time.perf_counter() - t_c), 3)))
         return last[0]
 
     def drain():
@@ -574,10 +583,20 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if args.host_prime_ms > 0:
+        # tail of the untimed warm-up: the closing reduction / synchronize() / barrier above leave host thread and device idle, and the first
+        # timed prepare() - ATen 4x4 algebra + one small gather launch and its round trip - then takes 0.45-0.68 ms instead of 0.11-0.2
+        # (tools/sessions/r04_s32.sh: 683 -> 702 keyframes/s on a 20-step line); in a running keyframe stream prepare() is called every
+        # 1.4 ms and never is.  No forward runs here; disclosed on the line (config.host_prime_ms).
+        t_p = time.perf_counter()
+        req_p = dict(batch_dev)
+        while (time.perf_counter() - t_p) * 1e3 < args.host_prime_ms:
+            model.prepare(req_p)
     enq0 = list(model.host_enqueue_stats)
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     step_marks = []
+    del step_parts[:]
     for _ in range(args.steps):
         step()
         if args.step_times:
@@ -731,7 +750,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "untimed_spinup_steps": n_spin,
-            **({"step_marks_ms": [round(1e3 * t, 3) for t in step_marks], "elapsed_ms": round(1e3 * elapsed, 3)} if args.step_times else {}),
+            **({"step_marks_ms": [round(1e3 * t, 3) for t in step_marks], "elapsed_ms": round(1e3 * elapsed, 3),
+                "step_parts_ms_prepare_wait_submit": step_parts[:args.steps]} if args.step_times else {}),
             "primer_process": primed,
             "ms_per_step": elapsed / args.steps * 1e3,
             "host_enqueue_ms": (enq1[1] - enq0[1]) / max(1, enq1[0] - enq0[0]) * 1e3,
@@ -751,6 +771,8 @@ def main():
                        "results_collected_by": "stream wait (handle.result())" if args.stream_collect else "host wait (handle.synchronize())",
                        "submit_and_result_streams": "caller's" if (not args.side_streams) else "one stream for submit(), one for result()",
                        "pose_matrices": "host" if args.host_mats else "device",
+                       "host_prime_ms": args.host_prime_ms,
+                       "host_prime_note": "tail of the untimed warm-up: prepare() calls (pose algebra of a request; one small gather launch each when the matrices are on the device, no forward) between the closing synchronize() of the spin-up and the timed region",
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
             "roofline": roof,
             "cost_volume_kernel": cv_block,

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/monorec_hip.h"
 #include "cooktoom_1d.h"
@@ -63,7 +64,7 @@ struct W44KArgs {
 
 // Ablations (diagnostic library only: python -m monorec_amd.build --timeline, -DMR_W44_ABLATE; MR_W44_DBG picks an instantiation): compile-time,
 // because a run-time flag in a kernel at 254 registers changes what is measured (tried: 1352 -> 2896 us with the flag present and zero).
-// bits: 1 no input transform, 2 no MFMAs, 4 no patch reads, 8 no A reads, 16 no DMA
+// bits: 1 no input transform, 2 no MFMAs, 4 no patch reads, 8 no A reads, 16 no DMA, 32 every DMA instruction of a chunk in one burst behind the barrier
 #define W44_DBG(bit) (DBG & (bit))
 
 // LDS-DMA through inline asm (see conv_mfma.hip: the builtins make hipcc drain vmcnt before every sweep)
@@ -151,6 +152,36 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
         if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
     };
 
+    // The same fetch in pieces (one DMA instruction each), for the chunks after the first: an LDS-DMA instruction holds its wave for a few
+    // hundred cycles, and issued in one burst behind the chunk barrier the ~10 of a wave keep BOTH waves of every SIMD off the matrix pipe
+    // (ablation: 231 of 1353 us).  Spread over the MFMAs of the chunk's first channel quad, a wave's stall is covered by its SIMD partner's
+    // MFMAs; the data still has the whole second quad to land.  Pieces 0..5: the wave's input plane, 6..10: its share of the U block.
+    i32x4 nsrd = {0, 0, 0, 0};
+    int nso = 0;
+    bool ncok = false;
+    const float* nwsrc = nullptr;
+    unsigned nbuf = 0;
+    auto next_begin = [&](int q, int pb) {                    // q = the chunk to fetch, pb = its buffer; advances the chunk cursor
+        nbuf = lds_base + pb * BUF * 4;
+        nwsrc = wgrp + (long long)q * U_FLOATS;
+        nsrd = make_srd(a.src[cs], a.src_bytes[cs]);
+        ncok = cc0 + wave < a.src_c[cs];
+        nso = ((b * a.src_c[cs] + cc0 + (ncok ? wave : 0)) * HW) * 4;
+        cc0 += WCK;
+        if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
+    };
+    auto next_piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (W44_DBG(16)) return;
+        if constexpr (k < NI) {
+            if (voff4[k] != -2) dma_buffer_x4(nbuf + wave * (PLANE * 4) + k * 1024, ncok ? voff4[k] : -1, nsrd, nso);
+        } else if constexpr (k < NI + 5) {
+            const int kb = wave + 8 * (k - NI);
+            if (kb < U_FLOATS / 256) dma_global_x4(nbuf + WCK * PLANE * 4 + kb * 1024, nwsrc + kb * 256 + lane * 4);
+        }
+    };
+    constexpr bool SPREAD = !W44_DBG(32);                     // diagnostic instantiation 32: the burst behind the barrier, as before
+
     issue(0, 0);
     const int tb = wave & 3, cb = wave >> 2;                  // tile row of the workgroup, block of 16 output channels of the group
     const int t = lane & 15;
@@ -164,8 +195,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
         const float* ub = raw + WCK * PLANE + cb * (6 * 64 * 6) + lane * 6;   // U of a chunk: [quad][block][j][lane][i], position p = 6 i + j
         dma_wait_all();
         __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
-        if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
-        if (!active) continue;
+        const bool more = q + 1 < a.nchunks;
+        if (more) {
+            if (SPREAD) next_begin(q + 1, pb ^ 1);
+            else issue(q + 1, pb ^ 1);
+        }
+        if (!active) {                                        // the waves of an empty block only move data
+            if (SPREAD && more) {
+                next_piece(std::integral_constant<int, 0>{}); next_piece(std::integral_constant<int, 1>{}); next_piece(std::integral_constant<int, 2>{});
+                next_piece(std::integral_constant<int, 3>{}); next_piece(std::integral_constant<int, 4>{}); next_piece(std::integral_constant<int, 5>{});
+                next_piece(std::integral_constant<int, 6>{}); next_piece(std::integral_constant<int, 7>{}); next_piece(std::integral_constant<int, 8>{});
+                next_piece(std::integral_constant<int, 9>{}); next_piece(std::integral_constant<int, 10>{});
+            }
+            continue;
+        }
 #pragma nounroll
         for (int c4 = 0; c4 < 2; ++c4) {
             const float* rp = raw + patch0 + c4 * 4 * PLANE;
@@ -214,14 +257,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino44_kernel(const W44KArgs a) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) v[r * 6 + c] = h[r];
             }
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const float av_ = (i & 1) ? av[j][i >> 1].y : av[j][i >> 1].x;
-                    if (W44_DBG(2)) acc[i * 6 + j][0] += av_ * v[i * 6 + j];
-                    else acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, v[i * 6 + j], acc[i * 6 + j], 0, 0, 0);
-                }
+            const bool fetch = SPREAD && more && c4 == 0;     // (uniform)
+#define W44_COLUMN(j)                                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                                        \
+                const float av_ = (i & 1) ? av[j][i >> 1].y : av[j][i >> 1].x;                                                     \
+                if (W44_DBG(2)) acc[i * 6 + j][0] += av_ * v[i * 6 + j];                                                            \
+                else acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, v[i * 6 + j], acc[i * 6 + j], 0, 0, 0);            \
+            }                                                                                                                      \
+            if (fetch) {                                                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                                 \
+                next_piece(std::integral_constant<int, 2 * (j)>{});                                                                \
+                next_piece(std::integral_constant<int, 2 * (j) + 1>{});                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                                 \
+            }
+            W44_COLUMN(0) W44_COLUMN(1) W44_COLUMN(2) W44_COLUMN(3) W44_COLUMN(4) W44_COLUMN(5)
+#undef W44_COLUMN
         }
     }
     // ---- output transform Y = A^T M A per (cout, tile) in registers, epilogue --------------------------------------------------------
@@ -389,6 +439,7 @@ extern "C" int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream)
         case 5: rc2 = launch(conv3x3_wino44_kernel<5>, setd[5]); break;
         case 13: rc2 = launch(conv3x3_wino44_kernel<13>, setd[6]); break;
         case 29: rc2 = launch(conv3x3_wino44_kernel<29>, setd[7]); break;
+        case 32: rc2 = launch(conv3x3_wino44_kernel<32>, setd[0]); break;
         default: return MR_ERR_BAD_ARGUMENT;
     }
     if (rc2 != -1000) return rc2 != 0 ? rc2 : (int)hipGetLastError();

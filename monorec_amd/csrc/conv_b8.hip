@@ -62,7 +62,7 @@ struct B8Args {
     const void* w[4];
     long long wgroup_bytes[4];       // packed bytes per cout group
     int KHp[4], KWp[4], PT[4], PL[4], ooff_h[4], ooff_w[4];
-    int dbg;                         // diagnostic library only (MR_B8_DBG): 1 skip the sweep, 2 skip the input staging, 4 skip the weight DMA, 8 skip the stores, 16 input DMA in one burst behind the barrier
+    int dbg;                         // diagnostic library only (MR_B8_DBG): 1 skip the sweep, 2 skip the input staging, 4 skip the weight DMA, 8 skip the stores
 };
 
 // ablation switches exist only in the diagnostic library (python -m monorec_amd.build --timeline, -DMR_B8_ABLATE): compile-time 0 in the product
@@ -137,7 +137,6 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
     const int KH = pick4(a.KHp, ph), KW = pick4(a.KWp, ph), T = KH * KW;
     const int PT = pick4(a.PT, ph), PL = pick4(a.PL, ph), ooff_h = pick4(a.ooff_h, ph), ooff_w = pick4(a.ooff_w, ph);
     const int PLANE = a.PLANE;
-    const bool SPREAD_DMA = WRES && !F32SRC && !B8_DBG(16);      // (diagnostic bit 16: the burst behind the barrier, as before)
     const int wchunk_bytes = T * MB * 1024;
     const int wres_bytes = WRES ? a.nchunks * a.KH * a.KW * MB * 1024 : 0;           // resident weights in front of the two stages
     const int stage_bytes = 64 * PLANE + (WRES ? 0 : 1024 * a.KH * a.KW * MB);       // [4 blocks][PLANE] x 16 B (+ [taps][MB][64 lanes] x 16 B)
@@ -333,34 +332,10 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
             __syncthreads();                                  // this chunk (and the resident weights) visible; everyone is done with the other buffer
             const bool more = ltile < tile_end;               // wave-uniform
             const int nq = lq;
-            // Resident weights + B8 sources: the next chunk's (up to 8) LDS-DMA instructions of this wave are issued BETWEEN the taps of the sweep
-            // instead of in one burst behind the barrier - an LDS-DMA instruction holds its wave for a few hundred cycles, and behind the
-            // barrier both waves of every SIMD sit in that stall together (the F(4x4,3x3) kernel gained 4 % this way, tools/sessions/r04_s34.sh)
-            const bool spread = SPREAD_DMA && more;
-            int sp_blk0 = 0, sp_scb = 1;
-            i32x4 sp_srd = {0, 0, 0, 0};
-            if (spread) {
-                int s_;
-                source_of(nq, s_, sp_blk0);
-                sp_scb = pick3(a.src_cb, s_);
-                sp_srd = make_srd(pick3(a.src, s_), pick3(a.src_bytes, s_));
-            } else if (more) {
-                issue(nq, pb ^ 1);
-            }
-            const unsigned sp_buf = lds_base + wres_bytes + (pb ^ 1) * stage_bytes;
-            const int sp_per_tap = (4 * B8_MAX_PPT + T - 1) / T;
-            auto spread_pieces = [&](int t) {
-                if (!spread || B8_DBG(2)) return;
-                for (int p = t * sp_per_tap; p < min((t + 1) * sp_per_tap, 4 * B8_MAX_PPT); ++p) {
-                    const int j = p >> 2, k = p & 3;
-                    const bool lv = j ? live[B8_MAX_PPT - 1] : live[0];
-                    const int gp = j ? gpix[B8_MAX_PPT - 1] : gpix[0];
-                    if (!lv) continue;
-                    const bool bok = sp_blk0 + k < sp_scb;
-                    const int so = ((b * sp_scb + (bok ? sp_blk0 + k : 0)) * HsWs) * 16;
-                    dma_buffer_x4(sp_buf + (wave * 64 + 64 * WV * j) * 16 + k * PLANE * 16, (bok && gp >= 0) ? gp * 16 : -1, sp_srd, so);
-                }
-            };
+            // (the DMA instructions spread over the taps of the sweep instead of this burst - what gained 4 % on the F(4x4,3x3) kernel, whose MFMA
+            // phase runs from registers - was measured here too, tools/sessions/r04_s36.sh: 181 -> 191 us on mask.enc0.1, configs[4] 324-333 ->
+            // 311-315 keyframes/s: this sweep reads its operands from LDS and a wave held by a DMA instruction stops feeding them)
+            if (more) issue(nq, pb ^ 1);
             if (q == 0) flush();                              // the previous tile's results leave while this chunk is swept
             // taps flattened and software-pipelined over two register sets: the fragments of tap t + 1 are on their way from LDS while the
             // MB * NB MFMAs of tap t issue (first hardware run: one set, 20 % of the MFMA rate - every tap waited out its own ds_reads)
@@ -386,14 +361,11 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
             for (int t = 0; t < (B8_DBG(1) ? 0 : T); t += 2) {
                 if (t + 1 < T) frags(av1, bv1, t + 1, next_off());
                 mfmas(av0, bv0);
-                spread_pieces(t);
                 if (t + 1 < T) {
                     if (t + 2 < T) frags(av0, bv0, t + 2, next_off());
                     mfmas(av1, bv1);
-                    spread_pieces(t + 1);
                 }
             }
-            if (B8_DBG(1) && spread) for (int t = 0; t < T; ++t) spread_pieces(t);
             if (more) {
                 stage_store(nq, pb ^ 1);                      // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
                 advance();

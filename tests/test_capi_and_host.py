@@ -2,6 +2,7 @@
 and the host logic around it (padding, ConvTranspose phases, BN folding, weight packing, pose algebra,
 model surface) is right."""
 import ctypes
+import glob
 import json
 import math
 import os
@@ -269,6 +270,38 @@ def test_launch_stamp_follows_the_launches_of_the_plan_not_the_tables(hip_lib, m
     other = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu",
                         schedule_override={first["name"]: (first["mb"], first["nb"], first["split_k"], max(8, first["ck"] // 2) if first["ck"] > 8 else 16, first["waves"], first["kws"])})
     assert other.launch_stamp() != p1.launch_stamp()
+
+
+def test_bench_quotes_a_profile_set_only_on_an_equal_stamp(tmp_path, monkeypatch):
+    """bench.profile_is_current: the newest committed set of a workload is quoted only when its stamp equals the running plan's, and only
+    when the stamp file belongs to the newest trace of that workload."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    assert bench.profile_is_current("c2", "abc")[0] is False                      # nothing committed
+    (prof / "r09_c2_stamp.json").write_text(json.dumps({"plan_stamp": "abc"}))
+    assert bench.profile_is_current("c2", "abc")[0] is False                      # a stamp without its traces
+    (prof / "r09_c2_kernel_stats_seq.csv").write_text("name\n")
+    ok, info = bench.profile_is_current("c2", "abc")
+    assert ok and info["profile"] == "abc" and info["profile_file"].endswith("r09_c2_stamp.json")
+    assert bench.profile_is_current("c2", "other")[0] is False                    # the plan moved on
+    (prof / "r10_c2_kernel_stats_seq.csv").write_text("name\n")                   # a newer trace without a stamp of its own
+    assert bench.profile_is_current("c2", "abc")[0] is False
+
+
+def test_committed_profile_sets_belong_to_the_plans_of_this_tree(hip_lib):
+    """The profile sets under profiles/ that bench.py quotes (c2, c3, configs[4] bf16) carry the launch stamp of the plan THIS tree builds for
+    their workload: a table or ABI change without regenerated profiles fails here instead of showing up as `stale_profile` on the driver's line."""
+    for tag, (b, h, w, f, d, bf) in {"c2": (1, 256, 512, 2, 32, 0), "c3": (8, 256, 512, 4, 64, 0), "c5bf16": (1, 512, 1024, 4, 48, 1)}.items():
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{tag}_stamp.json")))
+        assert files, tag
+        m = MonoRecModel(cv_depth_steps=d)
+        plan = engine.Plan(synth.seeded_state_dict(m.state_dict()), b, h, w, f, d, (0.33, 0.0025), "cpu", bf16=bf)
+        assert json.load(open(files[-1]))["plan_stamp"] == plan.launch_stamp(), (tag, files[-1])
 
 
 def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):

@@ -284,7 +284,11 @@ int mr_pool2x2_framemax_b8(const void* src, void* pooled, void* fmax, int32_t fr
 int mr_max_over_frames_b8(const void* src, void* dst, int32_t frames, int64_t groups16, void* stream);
 /* The two producers of the nets' fp32 inputs, writing a B8 copy on the side so that the first layers read no fp32 volume:
  * mr_cost_volume_b8_f32 = mr_cost_volume_mode_f32 of the default configuration (3x3 patch, sfcv * mask; 32 / 48 / 64 depth steps) with
- * sfcv_b8[f] = (batch, num_depths / 8, height, width, 8) bf16 per frame next to the dense single-frame volumes (which stay the outputs);
+ * sfcv_b8[f] = (batch, num_depths / 8, height, width, 8) bf16 per frame next to the dense single-frame volumes (which stay the outputs).
+ * Being the entry point of the bf16 configuration only (accuracy bar 1e-2 / 1e-3 on the depth), it forms the 3x3 window sums separably and
+ * multiplies by fp32(1/9) where mr_cost_volume_f32 keeps the reference's summation order and division: -17 % instructions; the volumes differ
+ * from mr_cost_volume_f32's by <= 1e-4 (the fused volume by more where the frame weights nearly cancel, as between any two summation orders),
+ * validity (the zeros of the volumes) exactly equal;
  * mr_mask_classifier_b8_f32 = mr_mask_classifier_f32 with the masked volume (monorec_model.py:713) also as
  * cost_volume_b8 = (batch, num_depths / 8, plane, 8) bf16 (num_depths % 16 == 0). */
 int mr_cost_volume_b8_f32(const float* keyframe, const float* const* frames, int32_t num_frames, const float* kinv, const float* proj,

@@ -56,6 +56,7 @@ struct CvArgs {
     int border;           // border_radius = patch_size / 2 + 1 (monorec_model.py:139); 2 for the default 3x3 patch
     float wm1, hm1;       // fp32(W - 1), fp32(H - 1): the divisors of layers.py:67-68
     float rwm1, rhm1;     // fp32(1 / wm1), fp32(1 / hm1)
+    int relaxed_sums;     // 1 (mr_cost_volume_b8_f32 = the bf16 configuration only): separable 3x3 window sums and x * fp32(1/9) - see march_finish
     int fast_w, fast_h;   // 1: the 3-instruction sequence div_const() equals the correctly rounded quotient for EVERY fp32 dividend
                           // (checked exhaustively on the host, mr_exact_const_division); 0: IEEE division
     void* sfcv_b8[MR_MAX_FRAMES];   // optional second copy of the single-frame volumes in the channel-blocked bf16 layout of csrc/conv_b8.hip
@@ -636,7 +637,12 @@ __device__ __forceinline__ void march_issue(const MarchCtx<DP>& c, int r, Gather
 // One marching step: warp virtual row r into `cur`, emit the SSIM row r - 1 (windows over top / mid / cur) as cur.e, emit the
 // sad of output row r - 2 (box over the e rows), then turn `mid` into the next top sums.  The caller alternates two MarchRow
 // objects as mid / cur, so the raw rows never move between registers.  `g`: what march_issue() gathered for row r.
-template <int DP, bool PIXD, bool KFS, bool FD>
+// RELAXED (the bf16 configuration, whose bar is 1e-2 / 1e-3 on the depth): the 3x3 sums are formed separably - every row keeps its horizontal
+// sums ((l + c) + r), a window is (top + mid) + cur - and x / 9 is x * fp32(1/9): 4 instead of 8 additions per quantity and step, 1 instead
+// of 3 instructions per division (-18 % instructions).  The volumes move by <= 7e-5 (an ulp of a 9-term sum against C2 = 9e-4 where the
+// variance cancels; priced on the oracle) - which is why the fp32 path keeps the reference's order.  The caller rotates THREE row
+// buffers (top / mid / cur all hold horizontal sums); validity, projection and gathers are unchanged.
+template <int DP, bool PIXD, bool KFS, bool FD, bool RELAXED = false>
 __device__ __forceinline__ void march_finish(const MarchCtx<DP>& c, int r, const Gathered<DP>& g, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid,
                                              MarchRow<DP, KFS>& cur, unsigned (&hits)[DP]) {
     constexpr int NQ = DP * 9 + (KFS ? 0 : 6), KQ = DP * 9;
@@ -667,8 +673,16 @@ __device__ __forceinline__ void march_finish(const MarchCtx<DP>& c, int r, const
         }
     // ---- 3x3 sums of every quantity over virtual rows r-2, r-1, r; / 9 (AvgPool2d(3,1): row-major sum, then the division) ----
     float s[NQ];
-    win9_batch<NQ>(s, top.q, mid.q, cur.q);
-    div9_batch<NQ>(s);
+    if (RELAXED) {
+        hsum3_batch<NQ>(cur.q, cur.q);                                      // the raw values are not needed again
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) s[i] = (top.q[i] + mid.q[i]) + cur.q[i];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) s[i] = s[i] * 0x1.c71c72p-4f;
+    } else {
+        win9_batch<NQ>(s, top.q, mid.q, cur.q);
+        div9_batch<NQ>(s);
+    }
     // ---- SSIM row q = r - 1, channel-weighted -> e (layers.py:119-137, monorec_model.py:133,141) ----------------------------
     const int q = r - 1;
     const bool row_in = q >= 0 && q < H;                                    // wave-uniform
@@ -712,7 +726,13 @@ __device__ __forceinline__ void march_finish(const MarchCtx<DP>& c, int r, const
     {   // no branch: a row outside the segment / a halo lane stores through an out-of-range offset (dropped by the descriptor) - one
         // basic block per step keeps every DPP shift next to the add it folds into
         float sad[DP];
-        win9_batch<DP>(sad, top.e, mid.e, cur.e);
+        if (RELAXED) {
+            hsum3_batch<DP>(cur.e, cur.e);
+#pragma unroll
+            for (int u = 0; u < DP; ++u) sad[u] = (top.e[u] + mid.e[u]) + cur.e[u];
+        } else {
+            win9_batch<DP>(sad, top.e, mid.e, cur.e);
+        }
         const bool st = (y >= c.y0) & (y < c.y1) & c.out_lane;
         const int voff = st ? (y * W + c.vx) * 4 : -1;
 #pragma unroll
@@ -722,17 +742,19 @@ __device__ __forceinline__ void march_finish(const MarchCtx<DP>& c, int r, const
         }
     }
     // ---- the middle row becomes the top row of the next step (as horizontal sums) -----------------------------------------
-    hsum3_batch<NQ>(top.q, mid.q);
-    hsum3_batch<DP>(top.e, mid.e);
+    if (!RELAXED) {
+        hsum3_batch<NQ>(top.q, mid.q);
+        hsum3_batch<DP>(top.e, mid.e);
+    }
 }
 
 // issue + finish back to back: the step as rounds 2-3 ran it (every wave waits out its own gathers; the other waves of the SIMD cover)
-template <int DP, bool PIXD, bool KFS, bool FD>
+template <int DP, bool PIXD, bool KFS, bool FD, bool RELAXED = false>
 __device__ __forceinline__ void march_step(const MarchCtx<DP>& c, int r, MarchRow<DP, KFS>& top, MarchRow<DP, KFS>& mid, MarchRow<DP, KFS>& cur,
                                            unsigned (&hits)[DP]) {
     Gathered<DP> g;
     march_issue<DP, PIXD, KFS, FD>(c, r, g);
-    march_finish<DP, PIXD, KFS, FD>(c, r, g, top, mid, cur, hits);
+    march_finish<DP, PIXD, KFS, FD, RELAXED>(c, r, g, top, mid, cur, hits);
 }
 
 // Keyframe statistics of the SSIM windows, once per keyframe instead of once per (frame, plane pair, row) in every wave: 3x3
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(256) void cv_kf_stats_kernel(const CvArgs a) {
 // (Software prefetch - the gathers of row r + 1 issued before the arithmetic of row r, two Gathered sets alternating - was measured in
 // tools/sessions/r04_s12.sh: 120.3 -> 119.7 us at c2 with one plane per wave (99 instead of 63 registers), slower at 512x1024, and at
 // two planes per wave the second set does not fit the register file (256 VGPRs).  The other waves of the SIMD cover the gathers.)
-template <int DP, bool PIXD, bool KFS, bool FD>
+template <int DP, bool PIXD, bool KFS, bool FD, bool RELAXED = false>
 __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const MarchGeom g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -810,6 +832,14 @@ __global__ __launch_bounds__(256) void cv_sad_march_kernel(const CvArgs a, const
 #pragma unroll
     for (int u = 0; u < DP; ++u) hits[u] = 0u;
     const int r_last = c.y1 + 1;
+    if (RELAXED) {                                            // three buffers of horizontal sums rotate as top / mid / cur
+        for (int r = y0 - 2; r <= r_last; r += 3) {
+            march_step<DP, PIXD, KFS, FD, true>(c, r, top, rowA, rowB, hits);
+            if (r + 1 <= r_last) march_step<DP, PIXD, KFS, FD, true>(c, r + 1, rowA, rowB, top, hits);
+            if (r + 2 <= r_last) march_step<DP, PIXD, KFS, FD, true>(c, r + 2, rowB, top, rowA, hits);
+        }
+        return;
+    }
     for (int r = y0 - 2; r <= r_last; r += 2) {
         march_step<DP, PIXD, KFS, FD>(c, r, top, rowA, rowB, hits);
         if (r + 1 <= r_last) march_step<DP, PIXD, KFS, FD>(c, r + 1, top, rowB, rowA, hits);
@@ -1247,6 +1277,10 @@ int launch_cv(const CvArgs& a, int mode, bool plane_flags, bool tiled, hipStream
         if (fd) hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, true>), grid, dim3(256), 0, stream, k, g);          \
         else hipLaunchKernelGGL((cv_sad_march_kernel<DP_, PIXD_, KFS_, false>), grid, dim3(256), 0, stream, k, g);                 \
     } while (0)
+        if (a.relaxed_sums && fd && kfs && !a.pix_depths) {      // the bf16 configuration (mr_cost_volume_b8_f32): separable sums, see march_finish
+            if (dp1) hipLaunchKernelGGL((cv_sad_march_kernel<1, false, true, true, true>), grid, dim3(256), 0, stream, k, g);
+            else hipLaunchKernelGGL((cv_sad_march_kernel<2, false, true, true, true>), grid, dim3(256), 0, stream, k, g);
+        } else
         if (dp1) MR_MARCH(1, false, true);   // twice the waves, each with one plane: for shapes that leave the SIMDs short of waves
         else if (kfs && a.pix_depths) MR_MARCH(2, true, true);
         else if (kfs) MR_MARCH(2, false, true);
@@ -1348,6 +1382,7 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
     a.kinv = kinv; a.proj = proj; a.depths = depths; a.pix_depths = pixel_depths; a.cv = cost_volume;
     a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
     a.tiles_x = 0; a.nchunk = 1; a.dchunk = num_depths;
+    a.relaxed_sums = sfcv_b8 != nullptr ? 1 : 0;
     a.alpha = alpha;
     for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / (float)(patch_size * patch_size);      // :141
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));

@@ -610,13 +610,16 @@ def test_marching_cost_volume_kernel_codegen():
         subprocess.run([_build._hipcc(), f"--offload-arch={_build.ARCH}", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj", "-c", src,
                         "-o", os.path.join(d, "cv.o")] + flags, check=True, cwd=d, capture_output=True)
         asm = open(os.path.join(d, "cost_volume-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-    for variant in ("ILi2ELb0ELb1ELb1E", "ILi2ELb0ELb0ELb1E", "ILi1ELb0ELb1ELb1E"):   # <DP, shared depths, keyframe prepass on / off, exact constant division>
+    # <DP, shared depths, keyframe prepass on / off, exact constant division, relaxed (separable) window sums: the bf16 configuration's variants>
+    for variant in ("ILi2ELb0ELb1ELb1ELb0E", "ILi2ELb0ELb0ELb1ELb0E", "ILi1ELb0ELb1ELb1ELb0E", "ILi2ELb0ELb1ELb1ELb1E", "ILi1ELb0ELb1ELb1ELb1E"):
         m = re.search(r"_ZN12_GLOBAL__N_119cv_sad_march_kernel" + variant + r"EEvNS_6CvArgsENS_9MarchGeomE:(.*?)\.Lfunc_end", asm, re.S)
         assert m, variant
         body = m.group(1)
         folded, unfolded = body.count("v_add_f32_dpp"), body.count("v_mov_b32_dpp")
         dp = 2 if variant.startswith("ILi2") else 1
-        assert folded >= 100 * dp and unfolded <= 8 * dp, (variant, folded, unfolded)
+        relaxed = variant.endswith("Lb1E")
+        # exact: 6 folded shifts per quantity and step, two steps unrolled; relaxed: 2 per quantity, three steps unrolled
+        assert folded >= (55 if relaxed else 100) * dp and unfolded <= 8 * dp, (variant, folded, unfolded)
         meta = asm[asm.index("amdhsa.kernels"):]
         k = re.search(r"cv_sad_march_kernel" + variant + r".*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", meta, re.S)
         assert k and int(k.group(1)) == 0 and int(k.group(2)) <= (128 if dp == 2 else 64), (variant, k and k.groups())   # 4 / 8 waves per SIMD

@@ -207,8 +207,9 @@ def test_b8_bad_arguments_are_rejected_without_a_launch(hip_lib):
 
 
 def test_cost_volume_and_classifier_write_their_b8_copies(hip_lib):
-    """mr_cost_volume_b8_f32 / mr_mask_classifier_b8_f32: the dense fp32 outputs are bit-identical to the plain entry points', and the B8
-    copies are those values rounded to bf16 (nearest even) in the (batch, D / 8, H, W, 8) layout."""
+    """mr_cost_volume_b8_f32 / mr_mask_classifier_b8_f32: the dense fp32 outputs next to the plain entry points' (classifier: bit-identical; cost
+    volume: single-frame volumes within 1e-4, relaxed window sums), and the B8 copies are the entry point's fp32 values rounded to bf16 (nearest even) in the
+    (batch, D / 8, H, W, 8) layout."""
     from monorec_amd import synth
     from monorec_amd.model import MonoRecModel, host_geometry, depth_hypotheses
     lib = hip_lib
@@ -236,9 +237,17 @@ def test_cost_volume_and_classifier_write_their_b8_copies(hip_lib):
                                                  cv.data_ptr(), sptr, bptr, _stream()), "cv b8")
         torch.cuda.synchronize()
         outs[tag] = (cv.cpu(), sf.cpu())
-    assert torch.equal(outs["plain"][0], outs["b8"][0]) and torch.equal(outs["plain"][1], outs["b8"][1])
-    want = outs["plain"][1].view(nf * b, d, h, w)
-    assert torch.equal(from_b8(sfb.cpu(), d), bf(want))
+    # the bf16 configuration's entry point forms its 3x3 sums separably and multiplies by fp32(1/9) (csrc/cost_volume.hip, march_finish RELAXED):
+    # the volumes move by an ulp of a 9-term sum against the SSIM constants - <= 1e-4, no validity flip - instead of being bit-identical
+    dcv, dsf = (outs["plain"][0] - outs["b8"][0]).abs(), (outs["plain"][1] - outs["b8"][1]).abs()
+    assert float(dsf.max()) <= 1e-4 and torch.equal(outs["plain"][1] == 0, outs["b8"][1] == 0)        # single-frame volumes, validity
+    # the fused volume divides by the sum of the frame weights: where that sum is small the difference of the sads is amplified (as between
+    # the reference and any other summation order) - a small outlier budget, like the use_ssim fixtures of test_gpu_kernels.py
+    assert float((dcv > 1e-4).float().mean()) <= 2e-3 and float(dcv.max()) <= 5e-3 and torch.equal(outs["plain"][0] == 0, outs["b8"][0] == 0), \
+        (float(dcv.max()), float((dcv > 1e-4).float().mean()))
+    assert float((outs["plain"][1] - outs["b8"][1]).abs().max()) > 0            # (it IS the relaxed variant that ran)
+    want = outs["b8"][1].view(nf * b, d, h, w)
+    assert torch.equal(from_b8(sfb.cpu(), d), bf(want))                           # the B8 copy = the entry point's own fp32 values, rounded to bf16
     # classifier + mask multiply
     g = torch.Generator().manual_seed(9)
     feat = torch.randn(b, 48, h, w, generator=g).to(DEV)

@@ -755,11 +755,17 @@ def main():
                          "frac_kernel_only_note": "algorithmic flops / (conv kernels + split-K finishing kernels per forward in the committed "
                                                   "rocprofv3 kernel trace - the --in-flight 1 trace when present: overlapping keyframes "
                                                   "inflate each other's kernel durations) / peak", "rocprof_source": kst_src})
+        if args.bf16 and kst:
+            # bound "hbm": the kernel-only fraction in the line's own unit too (frac_kernel_only above counts flops against the bf16 MFMA peak)
+            roof["frac_kernel_only_hbm"] = roof["algorithmic_MB_per_step"] * 1e6 / (kst["conv_us_per_forward"] * 1e-6) / 8e12
+            roof["frac_kernel_only_note"] += "; frac_kernel_only = flops against the bf16 MFMA peak, frac_kernel_only_hbm = algorithmic bytes against 8 TB/s over the same kernel time"
         if pmc.get("conv_mfma_util") is not None:
             roof["mfma_util_pmc"] = pmc["conv_mfma_util"]
         # the one fraction measured in the timed regime itself: the reference's conv flops of a step over the step's wall time
         # (keyframes overlapping, launch gaps, cost volume and small kernels included) against the MFMA peak
         roof["frac_pipelined"] = conv_flops / (elapsed / args.steps) / 1e12 / peak
+        if args.bf16:
+            roof["frac_pipelined_hbm"] = roof["algorithmic_MB_per_step"] * 1e6 / (elapsed / args.steps) / 8e12
         roof["frac_pipelined_note"] = "algorithmic conv flops per step / ms_per_step / peak: end to end in the timed regime (everything that is not a convolution counts against it)"
         if cfg_tag:
             roof["profile_stamp"] = stamp_info

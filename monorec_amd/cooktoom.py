@@ -13,7 +13,9 @@ from fractions import Fraction
 
 # finite interpolation points by tile size n = m + r - 1
 POINTS = {4: [0, 1, -1], 6: [0, 1, -1, 2, -2], 8: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2)],
-          10: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2), 4, -4]}
+          10: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2), 4, -4],
+          # odd tile sizes: the phase filters of the stride-2 layers (polyphase_stride2 below): F(2,2), F(2,4) / F(4,2), F(4,4)
+          3: [0, -1], 5: [0, 1, -1, 2], 7: [0, 1, -1, 2, -2, Fraction(1, 2)]}
 FORMS = ((4, 3), (2, 7), (4, 7))          # what cooktoom_1d.h carries (F(2, 3) is written out in conv1d_wino.hip)
 
 
@@ -60,6 +62,48 @@ def _solve(rows, rhs, n):
     if any(any(v != 0 for v in r_) for r_ in a[row:]):
         raise ValueError("inconsistent")
     return [a[i][n] for i in range(n)]
+
+
+def polyphase_stride2(r, pad_lo):
+    """An r-tap correlation with stride 2, y_i = sum_k g_k d_{2 i + k - pad_lo} (layers.ConvReLU2 with stride 2, reference model/layers.py:289-314
+    and monorec_model.py:490-499; `pad_lo` = the low-side padding of PadSameConv2d), as two STRIDE-1 correlations on the even and the odd
+    samples of the padded input p_j = d_{j - pad_lo}:  y_i = sum_t g_{2t} e_{i + t} + sum_t g_{2t+1} o_{i + t}  with e_j = p_{2j}, o_j = p_{2j+1}.
+    Returns (even tap indices, odd tap indices): ceil(r/2) and floor(r/2) taps, each a Cook-Toom candidate F(m, .) - 7 taps: F(2,4) + F(2,3) =
+    9 of 14 multiplies per 2 outputs, F(4,4) + F(4,3) = 13 of 28 per 4; 5 taps: 7 of 10 / 11 of 20.  (`pad_lo` only shifts which INPUT samples are
+    even: the split of the taps is by tap index.)"""
+    del pad_lo
+    return list(range(0, r, 2)), list(range(1, r, 2))
+
+
+def correlate_stride2_polyphase(d, g, m, pad_lo):
+    """Exact (Fraction) evaluation of the stride-2 correlation of polyphase_stride2 through F(m, r_even) + F(m, r_odd): the reference the kernel
+    and the numerics study are held against.  d: input samples, g: taps; returns the outputs the zero-padded stride-2 correlation defines for
+    i = 0 .. ceil(len(d) / 2) - 1."""
+    r = len(g)
+    n_out = -(-len(d) // 2)
+    ev, od = polyphase_stride2(r, pad_lo)
+    span = 2 * (n_out + m) + r + 2
+    p = [Fraction(0)] * span
+    for j, v in enumerate(d):
+        p[j + pad_lo] = Fraction(v)
+    phases = ([p[j] for j in range(0, span, 2)], [Fraction(g[k]) for k in ev]), ([p[j] for j in range(1, span, 2)], [Fraction(g[k]) for k in od])
+    y = [Fraction(0)] * (-(-n_out // m) * m)
+    for samples, taps in phases:
+        rr = len(taps)
+        if rr == 0:
+            continue
+        if rr == 1:                                   # one tap: a plain product per output
+            for i in range(len(y)):
+                y[i] += taps[0] * samples[i]
+            continue
+        at, gm, bt = cook_toom(m, rr)
+        n = m + rr - 1
+        u = [sum(gm[i][j] * taps[j] for j in range(rr)) for i in range(n)]
+        for t0 in range(0, len(y), m):
+            v = [sum(bt[i][c] * samples[t0 + c] for c in range(n)) for i in range(n)]
+            for k in range(m):
+                y[t0 + k] += sum(at[k][i] * u[i] * v[i] for i in range(n))
+    return y[:n_out]
 
 
 def identity_holds(m, r, at, g, bt):

@@ -58,6 +58,44 @@ def winograd_1d(x, w, bias, axis, m):
     return y + bias.view(1, -1, 1, 1) if bias is not None else y
 
 
+def _cooktoom_valid(xp, w3, m):
+    """'valid' stride-1 correlation along the LAST axis as F(m, r) in emulated fp32: xp (N, C, H, L), w3 (O, C, r) -> (N, O, H, L - r + 1)."""
+    r = w3.shape[2]
+    out_len = xp.shape[3] - r + 1
+    if r == 1:                                                   # one tap: a plain product, no transform
+        return torch.einsum("oc,nchl->nohl", w3[:, :, 0], xp[..., :out_len])
+    at, g, bt = matrices(m, r)
+    n = m + r - 1
+    tiles = -(-out_len // m)
+    xq = F.pad(xp, [0, tiles * m + r - 1 - xp.shape[3], 0, 0])
+    d = xq.unfold(3, n, m)                                                     # N C H T n
+    u = torch.einsum("ij,ocj->oci", torch.from_numpy(g), w3.double()).float()  # rounded once
+    v = torch.einsum("ij,nchtj->nchti", torch.from_numpy(bt).float(), d)
+    mm = torch.einsum("oci,nchti->nohti", u, v)
+    y = torch.einsum("ki,nohti->nohtk", torch.from_numpy(at).float(), mm)
+    return y.reshape(y.shape[0], y.shape[1], y.shape[2], tiles * m)[..., :out_len]
+
+
+def cooktoom_1d_stride2(x, w, bias, axis, m):
+    """A (r x 1) [axis 2] / (1 x r) [axis 3] correlation with stride 2 along the filter axis and TF-'same' padding (layers.ConvReLU2 with stride 2,
+    reference model/layers.py:289-314) as the POLYPHASE pair of monorec_amd.cooktoom.polyphase_stride2: even taps on the even samples + odd taps on
+    the odd samples of the padded input, each a stride-1 F(m, .) in emulated fp32, the two outputs added in fp32."""
+    if axis == 2:
+        return cooktoom_1d_stride2(x.transpose(2, 3), w.transpose(2, 3), bias, 3, m).transpose(2, 3)
+    r = w.shape[3]
+    pl, pr = oracle.same_pad(x.shape[3], r, 2)
+    n_out = -(-x.shape[3] // 2)
+    xp = F.pad(x, [pl, pr + 2 * (m + r), 0, 0])                                   # generous zero tail: the tiles run past the last output
+    ev, od = cooktoom.polyphase_stride2(r, pl)
+    y = None
+    for samples, taps in ((xp[..., 0::2], ev), (xp[..., 1::2], od)):
+        if not taps:
+            continue
+        part = _cooktoom_valid(samples.contiguous(), w[:, :, 0, taps], m)[..., :n_out]
+        y = part if y is None else y + part
+    return y + bias.view(1, -1, 1, 1) if bias is not None else y
+
+
 def winograd_2d(x, w, bias, m):
     """3x3 stride-1 'same' convolution as F(m x m, 3 x 3) in emulated fp32."""
     r = 3
@@ -97,7 +135,10 @@ class Patched:
             if m is None:
                 return outer.orig(x, w, b, stride)
             kh, kw = w.shape[2], w.shape[3]
-            y = winograd_2d(x, w, b, m) if (kh, kw) == (3, 3) else winograd_1d(x, w, b, 2 if kw == 1 else 3, m)
+            if tuple(stride) != (1, 1):                          # (2, 1) with a k x 1 filter or (1, 2) with a 1 x k filter
+                y = cooktoom_1d_stride2(x, w, b, 2 if kw == 1 else 3, m)
+            else:
+                y = winograd_2d(x, w, b, m) if (kh, kw) == (3, 3) else winograd_1d(x, w, b, 2 if kw == 1 else 3, m)
             ref = outer.orig(x.double(), w.double(), None if b is None else b.double(), stride)
             direct = outer.orig(x, w, b, stride)
             outer.hits += 1
@@ -120,6 +161,13 @@ def rules():
             return None
         return rule
 
+    def stride2(m):                                             # the stride-2 halves of ConvReLU2: 7 / 5 / 3 taps along the strided axis
+        def rule(ws, stride, xs):
+            if (stride == (2, 1) and ws[3] == 1 and ws[2] in (3, 5, 7)) or (stride == (1, 2) and ws[2] == 1 and ws[3] in (3, 5, 7)):
+                return m
+            return None
+        return rule
+
     def both(*rs):
         def rule(ws, stride, xs):
             for r_ in rs:
@@ -137,6 +185,8 @@ def rules():
         "F(2,7) 7x1 + 1x7": both(only(7, 1, 2), only(1, 7, 2)),
         "F(4,7) 7x1 + 1x7": both(only(7, 1, 4), only(1, 7, 4)),
         "F(4x4,3x3) + F(4,3) + F(2,7) together": both(only(3, 3, 4), only(3, 1, 4), only(1, 3, 4), only(7, 1, 2), only(1, 7, 2)),
+        "polyphase F(2,.) stride-2 k x 1 / 1 x k": stride2(2),
+        "polyphase F(4,.) stride-2 k x 1 / 1 x k": stride2(4),
     }
 
 

@@ -778,6 +778,27 @@ def test_c3_plan_runs_the_large_3x3_layers_as_f44(hip_lib):
     assert all(c["macs"] * 4 == c["ref_macs"] and c["lds"] <= 160 * 1024 and c["wgs"] >= 192 for c in f44)
 
 
+def test_polyphase_stride2_forms_are_exact():
+    """monorec_amd.cooktoom: the odd tile sizes (F(2,2), F(2,4), F(4,2), F(4,4)) satisfy the bilinear identity exactly with dyadic B^T / A^T, and a
+    stride-2 correlation equals the sum of the two phase filters evaluated through them (exact rational arithmetic; pads of both parities)."""
+    import random
+    from fractions import Fraction
+    from monorec_amd import cooktoom as ct
+    for m, r in ((2, 2), (2, 4), (4, 2), (4, 4)):
+        at, g, bt = ct.cook_toom(m, r)
+        assert ct.identity_holds(m, r, at, g, bt)
+        assert all((Fraction(v).denominator & (Fraction(v).denominator - 1)) == 0 for mat in (at, bt) for row in mat for v in row)
+    rnd = random.Random(3)
+    for r, pad in ((7, 2), (7, 3), (5, 1), (5, 2), (3, 0), (3, 1)):
+        for m in (2, 4):
+            for n in (23, 24):
+                d = [Fraction(rnd.randint(-9, 9)) for _ in range(n)]
+                g = [Fraction(rnd.randint(-5, 5), rnd.randint(1, 4)) for _ in range(r)]
+                ref = [sum(g[k] * (d[2 * i + k - pad] if 0 <= 2 * i + k - pad < n else 0) for k in range(r)) for i in range(-(-n // 2))]
+                assert ct.correlate_stride2_polyphase(d, g, m, pad) == ref, (r, pad, m, n)
+    assert ct.polyphase_stride2(7, 2) == ([0, 2, 4, 6], [1, 3, 5]) and ct.polyphase_stride2(5, 1) == ([0, 2, 4], [1, 3])
+
+
 def test_winograd_choice_table_and_rule():
     """engine.choose_winograd: the measured table wins (c2: the two full-resolution mask stages and the big decoder layers go to the
     Winograd kernel, every ResNet layer of a batch-1 keyframe stays on the direct kernel); unknown shapes follow the workgroup-count

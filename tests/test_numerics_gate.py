@@ -11,7 +11,7 @@ from oracle import numerics_study_winograd as study
 def test_every_form_the_table_may_select_keeps_the_depth_far_inside_the_parity_bar():
     report = study.main(["--height", "64", "--width", "128", "--depths", "32"])
     exps = report["experiments"]
-    assert len(exps) == 8 and report["bar"] == 1e-4
+    assert len(exps) == 10 and report["bar"] == 1e-4          # 8 forms the product carries + the two polyphase stride-2 candidates
     for name, e in exps.items():
         assert e["layers"] > 0, name
         assert e["result_max_abs_diff"] <= 2e-6, (name, e["result_max_abs_diff"])          # measured 1.5e-7 .. 2.8e-7: 1/50 of this bound, 1/350 of the bar
@@ -37,3 +37,24 @@ def test_cook_toom_emulation_equals_the_direct_convolution_up_to_rounding():
     w = torch.randn(5, 9, 3, 3, generator=g) / 9.0
     for m, tol in ((2, 1e-5), (4, 5e-5)):
         assert float((study.winograd_2d(x, w, None, m) - F.conv2d(x, w, None, padding=1)).abs().max()) <= tol, m
+
+
+def test_polyphase_stride2_emulation_equals_the_strided_convolution_up_to_rounding():
+    """oracle/numerics_study_winograd.cooktoom_1d_stride2 - the stride-2 halves of ConvReLU2 (7 / 5 / 3 taps, TF-'same' padding, reference
+    model/layers.py:241-252,289-314) as even taps on even samples + odd taps on odd samples, each a stride-1 Cook-Toom form - against the oracle's
+    own strided convolution, odd and even input lengths."""
+    import math
+    import torch
+    from oracle import monorec_oracle as oracle
+    g = torch.Generator().manual_seed(6)
+    for h, wd in ((14, 22), (13, 21)):
+        x = torch.randn(2, 7, h, wd, generator=g)
+        for r in (3, 5, 7):
+            for axis in (2, 3):
+                kk, stride = ((r, 1), (2, 1)) if axis == 2 else ((1, r), (1, 2))
+                w = torch.randn(6, 7, *kk, generator=g) / math.sqrt(7.0 * r)
+                b = torch.randn(6, generator=g)
+                ref = oracle.conv_same(x, w, b, stride)
+                for m in (2, 4):
+                    got = study.cooktoom_1d_stride2(x, w, b, axis, m)
+                    assert got.shape == ref.shape and float((got - ref).abs().max()) <= 2e-5, (h, wd, r, axis, m, float((got - ref).abs().max()))

@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
-    ap.add_argument("--host-prime-ms", type=float, default=3.0, help="tail of the untimed warm-up: prepare() calls (the pose algebra of a request: ATen 4x4 operators + one small gather launch "
+    ap.add_argument("--host-prime-ms", type=float, default=0.0, help="(default 0: `value` is timed right behind the barrier + synchronize, nothing in between - ADVICE r4; the primed figure of round 4 is the secondary key `value_host_primed`) tail of the untimed warm-up: prepare() calls (the pose algebra of a request: ATen 4x4 operators + one small gather launch "
                                                                       "when the matrices live on the device) for this many ms between the synchronize() that closes the spin-up and the timed region; 0 = none")
     ap.add_argument("--step-times", action="store_true", help="diagnostic: host time stamps after every timed step and after the drain, on the line as `step_marks_ms`")
     ap.add_argument("--spinup-seconds", type=float, default=3.0, help="minimum untimed spin-up before the timed steps")
@@ -67,6 +67,9 @@ def parse():
                          "4e-6 in CPU emulation; not yet validated on hardware - never the headline until it is)")
     ap.add_argument("--bf16", action="store_true",
                     help="convolutions on the bf16 MFMA (BASELINE configs[4] numerics; outside the 1e-4 parity bar - never the headline)")
+    ap.add_argument("--cv-separable", action="store_true", help="MonoRecModel(hip_cv_separable=True): the cost volume's 3x3 window sums formed separably (opt-in of the fp32 path; "
+                                                               "volumes within 1e-4, depth within 2e-6 of the default) - a secondary configuration, never the headline")
+    ap.add_argument("--lean-outputs", action="store_true", help="with --bf16: MonoRecModel(hip_lean_outputs=True) - no dense fp32 single_frame_cvs in the output dict")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="keyframes kept in flight per GPU (MonoRecModel.submit); 1 = strictly one forward at a time")
     ap.add_argument("--graph", action="store_true",
@@ -98,12 +101,15 @@ def parse():
     return ap.parse_args()
 
 
-def time_layers(model, batch_dev, plan_key, reps=5):
-    """Per-launch device time with HIP events on the stream the kernels are launched on."""
+def time_layers(model, batch_dev, plan_key, reps=9):
+    """Per-launch device time with HIP events on the stream the kernels are launched on: ONE keyframe at a time (nothing else is in
+    flight: the caller has drained the pipeline), all four stages back to back on the caller's stream, median over `reps` passes (the
+    first pass after a synchronize() runs on an idle device whose first launches are slow)."""
     plan = model._plans[plan_key]
+    plan.rebind_outputs(None)               # the plan's own resident buffers (a forward() may have pointed it at caller-owned arenas)
     stream = torch.cuda.current_stream()
     ops = plan.stages["encoder"] + plan.stages["encoder_tail"] + plan.stages["cv"] + plan.stages["main"]
-    acc = [0.0] * len(ops)
+    samples = [[] for _ in ops]
     for _ in range(reps):
         evs = []
         for name, fn in ops:
@@ -114,7 +120,8 @@ def time_layers(model, batch_dev, plan_key, reps=5):
             evs.append((e0, e1))
         torch.cuda.synchronize()
         for i, (e0, e1) in enumerate(evs):
-            acc[i] += e0.elapsed_time(e1) * 1e-3 / reps
+            samples[i].append(e0.elapsed_time(e1) * 1e-3)
+    acc = [sorted(v)[len(v) // 2] for v in samples]
     macs = {c["name"]: c for c in plan.conv_log}
     aux = {a["name"]: a for a in getattr(plan, "aux_log", [])}          # one-channel layers on their own kernels (csrc/heads.hip)
     rows = []
@@ -123,7 +130,8 @@ def time_layers(model, batch_dev, plan_key, reps=5):
         rows.append({"name": name, "seconds": t, "macs": c["macs"] if c else 0, "ref_macs": c["ref_macs"] if c else 0,
                      "aux_ref_macs": aux[name]["ref_macs"] if name in aux else 0,
                      "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4), c.get("kws", 0)] if c else None, "wgs": c["wgs"] if c else None,
-                     "tflops": (2 * c["macs"] / t / 1e12) if c and t > 0 else None})
+                     "tflops": (2 * c["macs"] / t / 1e12) if c and t > 0 else None,
+                     "tflops_algorithmic": (2 * c["ref_macs"] / t / 1e12) if c and t > 0 else None})
     return rows
 
 
@@ -148,6 +156,11 @@ def conv_algorithmic_bytes(c):
     for d in sp["w_shape"]:
         w *= d
     return n + w * (2 if c.get("bf16") == 1 else 4) * (c["phases"] if c["phases"] == 4 and not c.get("b8") else 1)
+
+
+def engine_env_overrides():
+    from monorec_amd import engine
+    return engine.active_env_overrides()
 
 
 def _latest_profile(cfg, suffix):
@@ -228,7 +241,7 @@ def committed_kernel_stats(cfg):
         return None, None
 
 
-def with_data_loading(model, dev, frames, depths, steps=60, in_flight=2):
+def with_data_loading(model, dev, frames, depths, steps=60, in_flight=2, max_threads=8):
     """Keyframes/s when every step also runs the per-frame input pipeline of the reference's dataset
     (kitti_odometry_dataset.py:120-134,248-258): PNG decode on the host (PIL, read ahead on up to 8 threads - the reference's
     eval config runs 8 data-loader workers, configs/evaluate/eval_monorec.json:33), then crop / Pillow-exact resize / normalise on the device through monorec_amd.input_pipeline with its frame cache
@@ -258,7 +271,7 @@ def with_data_loading(model, dev, frames, depths, steps=60, in_flight=2):
         a = np.asarray(Image.open(io.BytesIO(pngs[i % len(pngs)])))
         decode_s[0] += time.perf_counter() - t
         return a
-    threads = max(1, min(8, (os.cpu_count() or 2) - 1))
+    threads = max(1, min(max_threads, len(os.sched_getaffinity(0)) - 1))
     cache = input_pipeline.FrameCache(load, pre, capacity=8, workers=threads)
     k = input_pipeline.format_intrinsics(intr, (256, 512)).unsqueeze(0)             # 4x4s stay on the host (kitti.KittiOdometryDataset)
     base_cpu = synth.make_batch(1, 256, 512, frames, seed=1)
@@ -316,7 +329,20 @@ def cpu_baseline(sd, batch_cpu, depths, budget_s=28.0):
         tried[threads] = b / best
     torch.set_num_threads(nproc)
     cores = max(tried, key=tried.get)
-    return {"value": tried[cores], "unit": "keyframes/s", "cores": cores, "kind": "port",
+    # calibration of the port against the UNMODIFIED reference (which cannot travel to the GPU box): measured in the build container by
+    # oracle/time_port_vs_reference.py (same inputs, weights, thread count; the two agree bit for bit) and committed with the tree
+    cal = {}
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "port_vs_reference.json")))
+        cal = {"port_vs_reference": c["port_vs_reference"],
+               "reference_equivalent_value": tried[cores] * c["port_vs_reference"],
+               "port_vs_reference_note": "port seconds / unmodified-reference seconds per keyframe, measured in the build container by oracle/time_port_vs_reference.py "
+                                         f"({c['threads']} threads, best of {c['reps']} interleaved; profiles/port_vs_reference.json); reference_equivalent_value = value x "
+                                         "port_vs_reference = what MonoRecModel.forward of /root/reference itself would run at on these cores, to the extent the ratio "
+                                         "carries over from the build container's CPU"}
+    except Exception:
+        pass
+    return {"value": tried[cores], "unit": "keyframes/s", "cores": cores, "kind": "port", **cal,
             "host_threads_available": nproc, "value_by_threads": {str(k): round(v, 4) for k, v in tried.items()},
             "sample": f"best of <= 3 timed forwards (+1 warm-up) of the same {b}-keyframe batch at each of {sorted(tried)} threads, "
                       "torch CPU fp32; the fastest thread count is reported"}, ref
@@ -528,6 +554,15 @@ def main():
         primed = prime_device(args, dev_index)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # host placement of a rank (multi-rank jobs only): CPUs of its GPU's NUMA node shared evenly among the ranks of that node, torch's
+    # intra-op pool, the PNG-decode pool and the host-wait spin budget sized to that share (monorec_amd.distributed.place_rank)
+    from monorec_amd import distributed as mr_dist
+    import monorec_amd.model as mr_model
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    placement = mr_dist.place_rank(local_rank, local_world, [0] * local_world if one_device else None)
+    decode_budget, spin_s = mr_dist.host_thread_budget(placement["cpus"])
+    mr_model.HOST_SPIN_SECONDS = spin_s
+    placement.update({"decode_threads_budget": decode_budget, "host_spin_ms": spin_s * 1e3})
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -540,7 +575,8 @@ def main():
     from monorec_amd import MonoRecModel, synth
 
     model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16,
-                         hip_bf16x3=args.bf16x3, hip_queue_depth=args.queue_depth, hip_single_stream=args.single_stream)
+                         hip_bf16x3=args.bf16x3, hip_queue_depth=args.queue_depth, hip_single_stream=args.single_stream,
+                         hip_cv_separable=args.cv_separable, hip_lean_outputs=args.lean_outputs)
     sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -672,6 +708,21 @@ def main():
         drain()
         torch.cuda.synchronize()
         value_200 = 200 * args.batch / (time.perf_counter() - t200)
+    value_primed = None
+    if world == 1 and args.host_prime_ms <= 0 and not args.no_forward_api:
+        # round 4's headline regime as a SECONDARY key: the same K steps once more, preceded by 3 ms of prepare() calls (pose algebra of a
+        # request; no forward) between the closing synchronize() and the timed region - a benchmark-only step no caller performs
+        torch.cuda.synchronize()
+        t_p = time.perf_counter()
+        req_p = dict(batch_dev)
+        while (time.perf_counter() - t_p) * 1e3 < 3.0:
+            model.prepare(req_p)
+        tp0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        value_primed = args.steps * args.batch / (time.perf_counter() - tp0)
     if rank == 0:
         plan_key = next(iter(model._plans))
         rows = time_layers(model, batch_dev, plan_key)
@@ -683,8 +734,8 @@ def main():
         cv_row = next(r for r in rows if r["name"] == "cost_volume")
         shape = (args.batch, args.height, args.width, args.frames, args.depths)
         fp32 = not (args.bf16 or args.bf16x3)
-        cfg_tag = {(1, 256, 512, 2, 32): "c2", (8, 256, 512, 4, 64): "c3"}.get(shape) if fp32 else None
-        if args.bf16 and shape == (1, 512, 1024, 4, 48):
+        cfg_tag = {(1, 256, 512, 2, 32): "c2", (8, 256, 512, 4, 64): "c3"}.get(shape) if (fp32 and not args.cv_separable) else None
+        if args.bf16 and shape == (1, 512, 1024, 4, 48) and not args.lean_outputs:
             cfg_tag = "c5bf16"                                         # BASELINE configs[4]: profiles/*_c5bf16_*
         is_c2_fp32 = cfg_tag == "c2"                                   # the committed profiles are of these commands
         current, stamp_info = profile_is_current(cfg_tag, model._plans[plan_key].launch_stamp()) if cfg_tag else (False, None)
@@ -710,68 +761,95 @@ def main():
         n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") != 3)
         n_wino44 = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") == 3)
         n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and c.get("wino_m", 2) == 2 and max(c["k"]) == 3)
-        ct_forms = sorted({f"F({c['wino_m']},{max(c['k'])})" for c in model._plans[plan_key].conv_log
+        ct_forms = sorted({f"F({c['wino_m']},{c.get('wino_taps') or max(c['k'])})" + (" over [even | odd] (stride 2)" if c.get("stride2") else "")
+                           for c in model._plans[plan_key].conv_log
                            if c.get("winograd") and min(c["k"]) == 1 and (c.get("wino_m", 2), max(c["k"])) != (2, 3)})
         n_ct = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and (c.get("wino_m", 2), max(c["k"])) != (2, 3))
         n_wino_u = sum(1 for c in model._plans[plan_key].conv_log if c.get("upconv"))
         n_wino_t = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 4 and not c.get("upconv"))
         n_b8 = sum(1 for c in model._plans[plan_key].conv_log if c.get("b8"))
+        # ---- roofline of the dominant kernel family (the convolutions) ----
+        # `frac` <= 1 by construction: EXECUTED multiply-adds (what the matrix cores actually do; fewer than the reference's where a reduced-
+        # multiply form runs) over the time of the convolution kernels, against the dense MFMA peak.  The reference's (algorithmic) flops over
+        # the same time are `vs_direct_conv_ceiling` - how the launches compare with a direct convolution running at the peak; it exceeds 1
+        # on Winograd-heavy workloads (c3 used to print frac 1.13).  Time base: the convolution + split-K finishing kernels
+        # of ONE keyframe at a time in the committed rocprofv3 --kernel-trace --stats table of this command (`--in-flight 1 --single-stream`)
+        # when that profile set is stamped with the running plan (`frac_source` "kernel_only"); otherwise the live HIP-event sum
+        # ("hip_events": kernel + ~3 us dispatch gap per launch, so slightly pessimistic).  Both are always on the line.
+        live_exec, live_alg = conv_flops_executed / conv_s / 1e12, achieved
+        if kst and not args.bf16:
+            ko_s = kst["conv_us_per_forward"] * 1e-6
+            prim_exec, prim_alg, prim_src, prim_s = conv_flops_executed / ko_s / 1e12, conv_flops / ko_s / 1e12, "kernel_only", ko_s
+        else:
+            prim_exec, prim_alg, prim_src, prim_s = live_exec, live_alg, "hip_events", conv_s
+        step_s = elapsed / args.steps
         roof = {"bound": "mfma", "kernel": (f"conv_b8_kernel (v_mfma_f32_16x16x32_bf16, channel-blocked bf16 activation storage; {n_b8} of the launches) + "
                                             "conv_mfma_kernel (bf16 operands, fp32 storage: the ResNet encoder)") if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
                  f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches)" + (f" + conv3x3_wino44_kernel (F(4x4,3x3), {n_wino44})" if n_wino44 else "") + " + convt4x4_wino[_rb]_kernel "
                  f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d})" + (f" + conv1d_ct_kernel ({' / '.join(ct_forms)} for k x 1 / 1 x k, {n_ct})" if n_ct else "") + f" + upconv2x2_wino_kernel (4-multiply Upconv, {n_wino_u}); all fp32 v_mfma_f32_16x16x4_f32"),
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "frac_executed": conv_flops_executed / conv_s / 1e12 / peak,
-                "frac_note": "frac counts the reference's multiply-adds (SURVEY 8d) over the measured conv time; frac_executed counts what the "
-                             "matrix cores execute (less where Upconv is phase-decomposed and where the Winograd kernel runs)",
+                "achieved": prim_exec, "peak": peak, "unit": "TFLOP/s", "frac": prim_exec / peak,
+                "frac_source": prim_src,
+                "frac_note": "achieved = EXECUTED conv flops per step / conv-kernel time per step; frac = achieved / dense MFMA peak (<= 1 by construction).  "
+                             "frac_source 'kernel_only': time = conv + split-K finishing kernels of one keyframe at a time in the committed, plan-stamped "
+                             "rocprofv3 --kernel-trace --stats table; 'hip_events': live HIP-event sum of this run (kernel + dispatch gap per launch)",
+                "conv_seconds_per_step_used": prim_s,
+                "achieved_algorithmic": prim_alg, "vs_direct_conv_ceiling": prim_alg / peak,
+                "vs_direct_conv_ceiling_note": "the REFERENCE's conv flops (SURVEY 8d) over the same time / peak: can exceed 1 where reduced-multiply forms run "
+                                               "(F(4x4,3x3) executes 36 of 144 multiplies); not a roofline fraction",
+                "hip_events": {"achieved": live_exec, "frac": live_exec / peak, "achieved_algorithmic": live_alg, "vs_direct_conv_ceiling": live_alg / peak,
+                               "conv_ms_per_step": conv_s * 1e3, "avg_launch_us": conv_s / len(conv_rows) * 1e6,
+                               "note": "live, this run: HIP events around every convolution launch of ONE keyframe at a time on the caller's stream "
+                                       "(median of 9 passes): kernel + dispatch gap (+ split-K finishing kernel)"},
                 "traffic": pmc.get("conv_hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
-                "traffic_source": pmc_src, "launches_per_step": len(conv_rows), "avg_launch_us": conv_s / len(conv_rows) * 1e6,
-                "avg_launch_us_note": "HIP events around each layer: kernel + dispatch gap (+ split-K finishing kernel)",
+                "traffic_source": pmc_src, "launches_per_step": len(conv_rows),
                 "algorithmic_gflop_per_step": conv_flops / 1e9, "executed_gflop_per_step": conv_flops_executed / 1e9,
                 "algorithmic_note": "the reference's Conv2d / ConvTranspose2d MACs x 2 (SURVEY 8d); executed is lower where Upconv runs "
                                     "phase-decomposed on the low-resolution input (9 of 16 taps), where a 3x3 convolution runs as Winograd "
                                     "F(2x2,3x3) (16 of 36 multiplies) or F(4x4,3x3) (36 of 144), where a ConvTranspose2d(4,2) runs as F(2x2,2x2) (9 of 16) and where a k x 1 / 1 x k "
-                                    "convolution runs as F(2,3) (4 of 6), F(4,3) (6 of 12) or F(4,7) (10 of 28); the two large Upconv layers run on 4 of 16",
-                "conv_ms_per_step": conv_s * 1e3,
+                                    "convolution runs as F(2,3) (4 of 6), F(4,3) (6 of 12), F(4,7) (10 of 28) or - the stride-2 layers - as the polyphase forms F(4,4) / F(4,3) "
+                                    "over the even / odd input samples; the two large Upconv layers run on 4 of 16",
                 "splitk_finishing_launches_per_step": sum(1 for c in model._plans[plan_key].conv_log if c["split_k"] > 1),
                 "all_kernel_launches_per_step": len(rows) + sum(1 for c in model._plans[plan_key].conv_log if c["split_k"] > 1) + 2,
                 "all_kernel_launches_note": "every launch of a keyframe: convolutions + their split-K finishing kernels + pooling / max / normalise / "
                                             "classifier / heads + the three cost-volume kernels (statistics prepass, sad, fusion)"}
+        if kst:
+            ko_s = kst["conv_us_per_forward"] * 1e-6
+            roof["kernel_only"] = {"achieved": conv_flops_executed / ko_s / 1e12, "frac": conv_flops_executed / ko_s / 1e12 / peak,
+                                   "achieved_algorithmic": conv_flops / ko_s / 1e12, "vs_direct_conv_ceiling": conv_flops / ko_s / 1e12 / peak,
+                                   "rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,
+                                   "rocprof_source": kst_src,
+                                   "note": "conv kernels + split-K finishing kernels per forward in the committed rocprofv3 kernel trace, one keyframe at a time "
+                                           "(overlapping keyframes inflate each other's kernel durations)"}
         if args.bf16:
             # configs[4]: the bf16 path is HBM-bound (0.27 ms of bf16 MFMA time against ~0.5 ms of activation traffic): the roofline
             # of the line is bytes, the flops stay as secondary keys
             cbytes = sum(conv_algorithmic_bytes(c) for c in model._plans[plan_key].conv_log)
-            roof.update({"bound": "hbm", "achieved": cbytes / conv_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cbytes / conv_s / 8e12,
+            hb_s, hb_src = (kst["conv_us_per_forward"] * 1e-6, "kernel_only") if kst else (conv_s, "hip_events")
+            roof.update({"bound": "hbm", "achieved": cbytes / hb_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cbytes / hb_s / 8e12,
+                         "frac_source": hb_src, "conv_seconds_per_step_used": hb_s,
                          "algorithmic_MB_per_step": cbytes / 1e6,
                          "algorithmic_bytes_note": "per convolution launch: every source activation once (2 B per element where it is stored channel-blocked "
                                                    "in bf16, 4 B where it is dense fp32), the output once, the weights once; summed over the launches / the "
-                                                   "HIP-event time of the launches / 8 TB/s",
-                         "mfma_frac": achieved / peak, "mfma_achieved_TFLOPs": achieved, "mfma_peak_TFLOPs": peak,
-                         "frac_note": "HBM roofline (see algorithmic_bytes_note); mfma_frac = the reference's conv flops / conv time / bf16 dense peak"})
-        if kst:
-            roof.update({"rocprof_avg_kernel_us": kst["conv_avg_kernel_us"], "rocprof_conv_ms_per_step": kst["conv_us_per_forward"] / 1e3,
-                         "frac_kernel_only": conv_flops / (kst["conv_us_per_forward"] * 1e-6) / 1e12 / peak,
-                         "frac_kernel_only_note": "algorithmic flops / (conv kernels + split-K finishing kernels per forward in the committed "
-                                                  "rocprofv3 kernel trace - the --in-flight 1 trace when present: overlapping keyframes "
-                                                  "inflate each other's kernel durations) / peak", "rocprof_source": kst_src})
-        if args.bf16 and kst:
-            # bound "hbm": the kernel-only fraction in the line's own unit too (frac_kernel_only above counts flops against the bf16 MFMA peak)
-            roof["frac_kernel_only_hbm"] = roof["algorithmic_MB_per_step"] * 1e6 / (kst["conv_us_per_forward"] * 1e-6) / 8e12
-            roof["frac_kernel_only_note"] += "; frac_kernel_only = flops against the bf16 MFMA peak, frac_kernel_only_hbm = algorithmic bytes against 8 TB/s over the same kernel time"
+                                                   "conv-kernel time (frac_source) / 8 TB/s",
+                         "mfma_frac_executed": prim_exec / peak, "mfma_achieved_TFLOPs": prim_exec, "mfma_peak_TFLOPs": peak,
+                         "frac_note": "HBM roofline (see algorithmic_bytes_note); mfma_frac_executed = executed conv flops / the same time / bf16 dense peak"})
+            roof["hip_events"]["frac_hbm"] = cbytes / conv_s / 8e12
+            if kst:
+                roof["kernel_only"]["frac_hbm"] = cbytes / (kst["conv_us_per_forward"] * 1e-6) / 8e12
+            roof["frac_pipelined_hbm"] = cbytes / step_s / 8e12
         if pmc.get("conv_mfma_util") is not None:
             roof["mfma_util_pmc"] = pmc["conv_mfma_util"]
-        # the one fraction measured in the timed regime itself: the reference's conv flops of a step over the step's wall time
-        # (keyframes overlapping, launch gaps, cost volume and small kernels included) against the MFMA peak
-        roof["frac_pipelined"] = conv_flops / (elapsed / args.steps) / 1e12 / peak
-        if args.bf16:
-            roof["frac_pipelined_hbm"] = roof["algorithmic_MB_per_step"] * 1e6 / (elapsed / args.steps) / 8e12
-        roof["frac_pipelined_note"] = "algorithmic conv flops per step / ms_per_step / peak: end to end in the timed regime (everything that is not a convolution counts against it)"
+        # the fraction measured in the timed regime itself: the executed conv flops of a step over the step's wall time (keyframes overlapping,
+        # launch gaps, cost volume and small kernels included) against the MFMA peak
+        roof["frac_pipelined"] = conv_flops_executed / step_s / 1e12 / peak
+        roof["vs_direct_conv_ceiling_pipelined"] = conv_flops / step_s / 1e12 / peak
+        roof["frac_pipelined_note"] = "executed conv flops per step / ms_per_step / peak: end to end in the timed regime (everything that is not a convolution counts against it)"
         if cfg_tag:
             roof["profile_stamp"] = stamp_info
             if not current:
                 roof["stale_profile"] = ("the committed rocprofv3 profile set of this workload was not taken on the running plan (its launches / ABI changed "
-                                         "since, or no stamped set exists): frac_kernel_only, mfma_util_pmc and traffic are omitted, not quoted")
+                                         "since, or no stamped set exists): kernel_only, mfma_util_pmc and traffic are omitted, frac falls back to the live HIP-event time")
         # one-channel layers: every input element read once, every output written once; the classifier launch also scales the D planes
         hw_ = args.height * args.width
         aux_s = sum(r["seconds"] for r in rows if r.get("aux_ref_macs"))
@@ -794,6 +872,7 @@ def main():
             **({"step_marks_ms": [round(1e3 * t, 3) for t in step_marks], "elapsed_ms": round(1e3 * elapsed, 3),
                 "step_parts_ms_prepare_wait_submit": step_parts[:args.steps]} if args.step_times else {}),
             "primer_process": primed,
+            "host_placement": placement,
             "ms_per_step": elapsed / args.steps * 1e3,
             "host_enqueue_ms": (enq1[1] - enq0[1]) / max(1, enq1[0] - enq0[0]) * 1e3,
             "host_cpu_ms_per_keyframe": (cpu1 - cpu0) / max(1, args.steps * args.batch) * 1e3,
@@ -812,8 +891,11 @@ def main():
                        "results_collected_by": "stream wait (handle.result())" if args.stream_collect else "host wait (handle.synchronize())",
                        "submit_and_result_streams": "caller's" if (not args.side_streams) else "one stream for submit(), one for result()",
                        "pose_matrices": "host" if args.host_mats else "device",
+                       "cv_separable_sums": bool(args.cv_separable), "lean_outputs": bool(args.lean_outputs),
                        "host_prime_ms": args.host_prime_ms,
                        "host_prime_note": "tail of the untimed warm-up: prepare() calls (pose algebra of a request; one small gather launch each when the matrices are on the device, no forward) between the closing synchronize() of the spin-up and the timed region",
+                       "env_overrides": engine_env_overrides(),
+                       "env_overrides_note": "kernel-selection environment overrides active in this process (monorec_amd.engine.ENV_OVERRIDES: candidate tables, A/B switches, the diagnostic library); {} = the committed tables and defaults",
                        "parallelism": f"dp{world} (independent keyframes per rank)"},
             "roofline": roof,
             "cost_volume_kernel": cv_block,
@@ -831,6 +913,9 @@ def main():
         }
         if value_200 is not None:
             result["value_200_steps"] = value_200
+        if value_primed is not None:
+            result["value_host_primed"] = value_primed
+            result["value_host_primed_note"] = "secondary: the same K steps timed after 3 ms of prepare() calls between the closing synchronize() and the timed region (round 4's headline regime); `value` has nothing in between"
         if world == 1 and not args.no_forward_api:
             result["forward_api"] = forward_api(model, batch_dev, args.batch)
         if args.dump_layers:
@@ -855,7 +940,7 @@ def main():
             torch.cuda.synchronize()
             result["depth_max_abs_err_vs_cpu"] = float((out["result"].cpu() - ref["result"]).abs().max())
             if is_c2_fp32:
-                result["with_data_loading"] = with_data_loading(model, dev, args.frames, args.depths, in_flight=args.in_flight)
+                result["with_data_loading"] = with_data_loading(model, dev, args.frames, args.depths, in_flight=args.in_flight, max_threads=decode_budget)
                 result["with_host_inputs"] = with_host_inputs(model, batch_dev, dev, args)
             if is_c2_fp32 and not args.no_secondary:
                 result["secondary_bf16x3"] = secondary_bf16x3(sd, batch_dev, ref, dev, args)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 17
+#define MR_ABI_VERSION 18
 
 #define MR_COMPUTE_F32  0
 #define MR_COMPUTE_BF16 1
@@ -44,7 +44,7 @@ extern "C" {
 enum {
     MR_ACT_NONE = 0,
     MR_ACT_RELU = 1,            /* torchvision BasicBlock relu                                   */
-    MR_ACT_LEAKY_RELU = 2,      /* LeakyReLU(slope = act_p0)  model/layers.py:303,330,391         */
+    MR_ACT_LEAKY_RELU = 2,      /* LeakyReLU(slope = act_p0), 0 <= act_p0 <= 1 (else MR_ERR_UNSUPPORTED)  model/layers.py:303,330,391 */
     MR_ACT_SIGMOID = 3,         /* MaskModule.classifier      model/monorec/monorec_model.py:342  */
     MR_ACT_ABS_TANH_AFFINE = 4  /* |tanh(x)| then (1-p)*act_p0 + p*act_p1  monorec_model.py:556,717 */
 };
@@ -203,6 +203,16 @@ typedef struct mr_wino_desc {
                                         2 = 1 for out_channels = 32 a + r, 0 < r <= 16, cout_blocks_per_wave 1: the r tail channels are
                                         produced by workgroups of 16 x 32 pixels x 16 channels instead of a half-empty 32-channel group
                                         (the 48-channel layers); packed_weights then from mr_wino_pack_weights_tail_f32. */
+    /* ---- mr_conv1d_cooktoom_f32 only (every other entry point wants them 0): strided source views and a column-split destination, which is
+     * how the stride-2 halves of layers.ConvReLU2 (model/layers.py:289-314 with stride (2,1) / (1,2); monorec_model.py:489-501) run as stride-1
+     * forms over [even samples | odd samples] (monorec_amd/cooktoom.py: stride2_as_stride1). */
+    int32_t src_row_pitch;           /* floats between consecutive rows of a source as the launch sees it; 0 = width (dense).  2 * width with
+                                        height = H / 2 reads every second row of an (.., H, width) tensor: src[s] = its first element for the even
+                                        rows, + width floats for the odd rows */
+    int32_t src_plane_floats;        /* floats between consecutive channel planes of a source in memory; 0 = height * width (dense) */
+    int32_t dst_split_columns;       /* axis 1 only: 1 = the destination is stored de-interleaved by column parity, dst = (2, batch, out_channels,
+                                        height, width / 2): [0] the even columns, [1] the odd ones - two dense tensors the 1 x k stride-(1,2) half
+                                        of the pair reads as its two sources */
 } mr_wino_desc;
 size_t mr_wino_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t cout_blocks_per_wave);
 /* weight: (out_channels, sum(src_channels), 3, 3) fp32 host memory; the transformed filters G g G^T are formed in double */
@@ -295,6 +305,13 @@ int mr_cost_volume_b8_f32(const float* keyframe, const float* const* frames, int
                           const float* depths, int32_t batch, int32_t num_depths, int32_t height, int32_t width, float alpha,
                           const float* channel_weights, int32_t use_ssim, const float* pixel_depths, float* cost_volume,
                           float* const* sfcv, void* const* sfcv_b8, void* stream);
+/* mr_cost_volume_b8_f32 for a caller that does not hand out fp32 single-frame volumes (MonoRecModel(hip_bf16=True, hip_lean_outputs=True)):
+ * the fusion kernel writes the fused volume and the B8 copies only; sfcv[f] are SCRATCH (they end up holding the raw per-frame costs, not
+ * monorec_model.py:251's volumes) - D * F * H * W * 4 bytes of HBM writes less per keyframe (403 MB at BASELINE configs[4]). */
+int mr_cost_volume_b8_lean_f32(const float* keyframe, const float* const* frames, int32_t num_frames, const float* kinv, const float* proj,
+                               const float* depths, int32_t batch, int32_t num_depths, int32_t height, int32_t width, float alpha,
+                               const float* channel_weights, int32_t use_ssim, const float* pixel_depths, float* cost_volume,
+                               float* const* sfcv_scratch, void* const* sfcv_b8, void* stream);
 int mr_mask_classifier_b8_f32(const float* features, const float* weight, const float* bias, int32_t batch, int32_t channels, int64_t plane,
                               float* cv_mask, float* cost_volume, int32_t num_depths, void* cost_volume_b8, void* stream);
 /* layout conversions: dense fp32 (n, c, hw) <-> B8 (n, ceil(c/8), hw, 8) bf16 */
@@ -397,6 +414,18 @@ int mr_cost_volume_mode_f32(const float* keyframe, const float* const* frames, i
                             float alpha, const float* channel_weights, int32_t use_ssim,
                             const float* pixel_depths, int32_t sfcv_mult_mask,
                             float* cost_volume, float* const* sfcv, void* stream);
+
+/* Opt-in of the fp32 path (MonoRecModel(hip_cv_separable=True)): mr_cost_volume_mode_f32 of the default configuration (3x3 patch,
+ * sfcv * mask) with the 3x3 window sums of layers.SSIM (model/layers.py:123-131) and of the box stage (monorec_model.py:246-248) formed
+ * SEPARABLY (every row keeps its horizontal sums; a window is (top + mid) + cur) and x * fp32(1/9) for x / 9 - another rounding of the same
+ * nine-term sums, -17 % instructions in the sad kernel.  Validity (the zeros of the volumes) is exactly mr_cost_volume_f32's; single-frame
+ * volumes differ by <= 1e-4, the depth by <= 2e-6 (inside north_star's 1e-4-on-depth bar; the DEFAULT stays the exact-order kernel, whose
+ * volumes agree with the reference to 5e-7).  Per-pixel depths / sizes without an exact constant division run the exact kernels. */
+int mr_cost_volume_relaxed_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                               const float* kinv, const float* proj, const float* depths,
+                               int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                               float alpha, const float* channel_weights, int32_t use_ssim, const float* pixel_depths,
+                               float* cost_volume, float* const* sfcv, void* stream);
 
 /* mr_cost_volume_mode_f32 on the round-1 kernels (LDS-tiled sad kernel + three-pass fusion kernel) whatever the options: the
  * default configuration (use_ssim 1, sfcv_mult_mask 1) otherwise runs the LDS-free marching kernel + register-resident fusion

@@ -64,7 +64,8 @@ class WinoDesc(ctypes.Structure):
                 ("dst", ctypes.c_void_p), ("out_channels", ctypes.c_int32),
                 ("packed_weights", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p),
                 ("activation", ctypes.c_int32), ("act_p0", ctypes.c_float), ("cout_blocks_per_wave", ctypes.c_int32),
-                ("variant", ctypes.c_int32)]
+                ("variant", ctypes.c_int32),
+                ("src_row_pitch", ctypes.c_int32), ("src_plane_floats", ctypes.c_int32), ("dst_split_columns", ctypes.c_int32)]
 
 
 LAYOUT_F32_NCHW, LAYOUT_BF16_B8 = 0, 1
@@ -87,7 +88,7 @@ class B8ConvDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 17            # include/monorec_hip.h
+MR_ABI_VERSION = 18            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):
@@ -150,6 +151,11 @@ ABI = {
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_float, _c_float_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "mr_cost_volume_relaxed_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_float, _c_float_p, ctypes.c_int32, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "mr_cost_volume_tiled_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -195,6 +201,10 @@ ABI = {
                                              ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _c_float_p,
                                              ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "mr_cost_volume_b8_lean_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _c_float_p,
+                                                  ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "mr_mask_classifier_b8_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "mr_gather_small_f32": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),

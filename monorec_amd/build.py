@@ -53,6 +53,20 @@ def _stale(target, deps):
     return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
+def _run_all(cmds, verbose=False):
+    """The stale translation units side by side (conv_mfma.hip alone takes ~3 minutes: one after the other a full rebuild was 10+)."""
+    if not cmds:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(cmds), (os.cpu_count() or 2)))) as pool:
+        list(pool.map(one, cmds))
+
+
 def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and not _stale(
             LIB_PATH, [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "conv_layout.h"), os.path.join(CSRC, "cooktoom_1d.h"), __file__,
@@ -62,16 +76,14 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, "conv_layout.h"), os.path.join(CSRC, "cooktoom_1d.h"), os.path.join(HERE, "..", "include", "monorec_hip.h"), __file__]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    objs = []
+    objs, cmds = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o] + extra
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
+            cmds.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o] + extra)
+    _run_all(cmds, verbose)
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
@@ -100,19 +112,18 @@ def build_timeline(verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     flags = dict(SOURCES)
-    objs = []
+    objs, cmds = [], []
+    hdrs = [os.path.join(CSRC, "conv_layout.h"), os.path.join(CSRC, "cooktoom_1d.h"), os.path.join(HERE, "..", "include", "monorec_hip.h")]
     for src, _ in SOURCES:
         if src not in DIAGNOSTIC:
             objs.append(os.path.join(objdir, src.replace(".hip", ".o")))
             continue
         o = os.path.join(objdir, src.replace(".hip", "_diag.o"))
         s = os.path.join(CSRC, src)
-        if _stale(o, [s, os.path.join(CSRC, "conv_layout.h")]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", DIAGNOSTIC[src], "-DMR_DIAGNOSTIC_LIBRARY", "-c", s, "-o", o] + flags[src]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
+        if _stale(o, [s] + hdrs):
+            cmds.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", DIAGNOSTIC[src], "-DMR_DIAGNOSTIC_LIBRARY", "-c", s, "-o", o] + flags[src])
         objs.append(o)
+    _run_all(cmds, verbose)
     for src, extra in DIAGNOSTIC_ONLY_SOURCES:
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         s = os.path.join(CSRC, src)

@@ -16,7 +16,8 @@ POINTS = {4: [0, 1, -1], 6: [0, 1, -1, 2, -2], 8: [0, 1, -1, 2, -2, Fraction(1, 
           10: [0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2), 4, -4],
           # odd tile sizes: the phase filters of the stride-2 layers (polyphase_stride2 below): F(2,2), F(2,4) / F(4,2), F(4,4)
           3: [0, -1], 5: [0, 1, -1, 2], 7: [0, 1, -1, 2, -2, Fraction(1, 2)]}
-FORMS = ((4, 3), (2, 7), (4, 7))          # what cooktoom_1d.h carries (F(2, 3) is written out in conv1d_wino.hip)
+FORMS = ((4, 3), (2, 7), (4, 7), (4, 4))  # what cooktoom_1d.h carries (F(2, 3) is written out in conv1d_wino.hip); F(4, 4): the 7-tap stride-2
+                                          # layers as ONE 4-tap stride-1 correlation over [even rows | odd rows] (see stride2_as_stride1)
 
 
 def cook_toom(m, r, points=None):
@@ -73,6 +74,27 @@ def polyphase_stride2(r, pad_lo):
     even: the split of the taps is by tap index.)"""
     del pad_lo
     return list(range(0, r, 2)), list(range(1, r, 2))
+
+
+def stride2_as_stride1(r, n):
+    """An r-tap correlation with stride 2 over n input samples (n even, PadSameConv2d padding: layers.ConvReLU2 with stride 2, reference
+    model/layers.py:241-252,289-314) as ONE stride-1 correlation with r2 = ceil(r / 2) taps over the concatenation [e | o] of the even and the
+    odd input samples (e_j = d_{2j}, o_j = d_{2j+1}): y_i = sum_t ge_t e_{i + t - pad} + sum_t go_t o_{i + t - pad}.  Returns
+    (r2, pad, even tap indices, odd tap indices): ge_t = g[even[t]], go_t = g[odd[t]], an index of None = a zero tap.  With the reference's
+    low-side padding pad_lo = floor((2 (n/2 - 1) + r - n) / 2) = (r - 2) // 2 (n even) both phases share the SAME offset `pad`, so the pair is a
+    plain 'same'-style filter over twice the channels - which is what lets the stride-1 Cook-Toom kernels run it on row-strided / column-
+    deinterleaved views of the input: 7 taps -> 4 taps (F(4,4): 7 multiplies per 4 outputs and channel pair = 3.5 per output instead of 7),
+    5 taps -> 3 taps (F(4,3): 3 instead of 5).  The kernels (csrc/conv1d_wino.hip) and the oracle-side numerics study use this one derivation."""
+    assert n % 2 == 0 and r >= 2
+    pad_lo = (2 * (n // 2 - 1) + r - n) // 2
+    r2 = (r + 1) // 2
+    # tap k reads d_{2 i + k - pad_lo}: even sample index when (k - pad_lo) is even -> e_{i + (k - pad_lo) / 2}, else o_{i + (k - pad_lo - 1) / 2}
+    ev = {(k - pad_lo) // 2: k for k in range(r) if (k - pad_lo) % 2 == 0}
+    od = {(k - pad_lo - 1) // 2: k for k in range(r) if (k - pad_lo) % 2 != 0}
+    lo = min(min(ev), min(od))
+    hi = max(max(ev), max(od))
+    assert hi - lo + 1 == r2, (r, lo, hi)
+    return r2, -lo, [ev.get(lo + t) for t in range(r2)], [od.get(lo + t) for t in range(r2)]
 
 
 def correlate_stride2_polyphase(d, g, m, pad_lo):
@@ -179,8 +201,13 @@ def _output_transform(m, r, at):
                 e = name if c == 1 else f"{_lit(c)} * {name}"
             else:
                 e = f"({e} + {name})" if c == 1 else f"fmaf({_lit(c)}, {name}, {e})"
-        if n % 2 == 1:                                   # an unpaired finite point (not with the point sets used here)
-            raise NotImplementedError
+        if n % 2 == 1:                                   # an unpaired finite point (odd tile sizes: F(4,4), F(2,4)): its own column, n - 2
+            c = at[k][n - 2]
+            if c != 0:
+                if e is None:
+                    e = f"mm[{n - 2}]" if c == 1 else f"{_lit(c)} * mm[{n - 2}]"
+                else:
+                    e = f"({e} + mm[{n - 2}])" if c == 1 else f"fmaf({_lit(c)}, mm[{n - 2}], {e})"
         c = at[k][n - 1]
         if c != 0:
             assert c == 1

@@ -48,6 +48,10 @@ struct W1KArgs {
     int Cout, tiles_x, nchunks;
     const float* w;
     long long wgroup_stride;            // packed floats per cout group
+    // conv1d_ct_kernel only (round 5: the stride-2 layers as stride-1 forms over [even | odd] views of their input):
+    int pitch, cplane;                  // floats between rows / channel planes of a source as stored (dense: W, H * W)
+    int dst_split;                      // axis 1: the destination is (2, batch, Cout, H, W / 2) - even columns, odd columns
+    long long dst_half;                 // floats of one parity half of such a destination
 };
 
 // LDS-DMA through inline asm (see conv_mfma.hip: the builtins make hipcc drain vmcnt before every sweep)
@@ -78,11 +82,13 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
     return r;
 }
 
-// none / ReLU / LeakyReLU as ONE branch-free form (x > 0 ? x : x * slope, slope 1 / 0 / p0; the slope is wave-uniform and hoisted): as a
+// none / ReLU / LeakyReLU as ONE branch-free form, max(x, lo) with lo = x (none), 0 (ReLU: -inf -> 0 and no -0.0, like torch.relu),
+// x * p0 (LeakyReLU, 0 <= p0 <= 1 - the host side rejects other slopes); lo's selector is wave-uniform: as a
 // switch the compiler emitted scalar branches around every stored element of the epilogue (round 4: 200-450 branches per workgroup)
 __device__ __forceinline__ float act1(float v, int act, float p0) {
-    const float slope = act == MR_ACT_RELU ? 0.f : (act == MR_ACT_LEAKY_RELU ? p0 : 1.f);
-    return v > 0.f ? v : v * slope;
+    const unsigned keep = act == MR_ACT_RELU ? 0u : ~0u;          // (an AND, not a select: a uniform select made hipcc clone the store loops)
+    const float lo = __uint_as_float(__float_as_uint(v * (act == MR_ACT_LEAKY_RELU ? p0 : 1.f)) & keep);
+    return fmaxf(v, lo);
 }
 
 template <int AXIS, int MBW>
@@ -211,6 +217,15 @@ template <> struct CtForm<4, 7> {
     static const double* g() { return &CT_G_4_7[0][0]; }
 };
 
+template <> struct CtForm<4, 4> {         // the 7-tap stride-2 layers: 4 taps over [even | odd] (cooktoom.stride2_as_stride1)
+    static __device__ __forceinline__ void in(const float (&d)[7], float (&v)[7]) { ct_input_4_4(d, v); }
+    static __device__ __forceinline__ void out(const float (&mm)[7], float (&y)[4]) { ct_output_4_4(mm, y); }
+    static const double* g() { return &CT_G_4_4[0][0]; }
+};
+
+// floats of one chunk's U block in the packed stream: whole 1 KiB DMA pieces (an odd number of positions - F(4,4): 7 - is padded with zeros)
+constexpr int ct_u_stream(int n, int mbw) { return (n * 2 * mbw * 64 + 255) / 256 * 256; }
+
 template <int AXIS, int M, int R>
 struct CtGeom {
     static constexpr int N = M + R - 1;
@@ -232,17 +247,17 @@ __global__ __launch_bounds__(512) void conv1d_ct_kernel(const W1KArgs a) {
     using Gm = CtGeom<AXIS, M, R>;
     constexpr int N = Gm::N, PITCH = Gm::PITCH, PLANE = Gm::PLANE, PL = Gm::PL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int U_FLOATS = N * 2 * MBW * 64;               // U fragments of one chunk: [p][c4][cout block][64 lanes]
-    constexpr int U_PIECES = U_FLOATS / 256;                 // 1 KiB pieces (N even)
+    constexpr int U_FLOATS = ct_u_stream(N, MBW);            // U fragments of one chunk: [p][c4][cout block][64 lanes] (+ zero padding to 1 KiB pieces)
+    constexpr int U_PIECES = U_FLOATS / 256;                 // 1 KiB pieces
     constexpr int BUF = WCK * PLANE + U_FLOATS;
-    static_assert(U_FLOATS % 256 == 0, "U pieces");
+    static_assert(U_FLOATS % 256 == 0 && U_FLOATS >= N * 2 * MBW * 64, "U pieces");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ty_wg = (int)blockIdx.x / a.tiles_x, tx_wg = (int)blockIdx.x - ty_wg * a.tiles_x;
     const int grp = blockIdx.y, b = blockIdx.z;
     const int oy0 = ty_wg * Gm::RH, ox0 = tx_wg * Gm::RW;
-    const int H = a.H, W = a.W, HW = H * W;
+    const int H = a.H, W = a.W, HW = a.cplane;                // (HW: floats between channel planes as stored - H * W unless the source is a strided view)
 
     int voff4[Gm::NI];                                        // lane l owns the 16-byte groups r = l + 64 i of a plane: row r / G4, group r % G4
 #pragma unroll
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(512) void conv1d_ct_kernel(const W1KArgs a) {
         const int row = r / Gm::G4, g4 = r - row * Gm::G4;
         const int gy = oy0 - (AXIS == 1 ? PL : 0) + row, gx = ox0 - 4 + 4 * g4;
         const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        voff4[i] = r < Gm::NG ? (inb ? (gy * W + gx) * 4 : -1) : -2;
+        voff4[i] = r < Gm::NG ? (inb ? (gy * a.pitch + gx) * 4 : -1) : -2;
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
     const float* wgrp = a.w + (long long)grp * a.wgroup_stride;
@@ -350,14 +365,18 @@ __global__ __launch_bounds__(512) void conv1d_ct_kernel(const W1KArgs a) {
             CtForm<M, R>::out(mm, y);
 #pragma unroll
             for (int k = 0; k < M; ++k) y[k] = act1(y[k] + bs, a.act, a.p0);
-            float* o = a.dst + ((long long)(b * a.Cout + cout) * H + oy) * W + ox;
             if constexpr (AXIS == 0) {                         // W % 4 == 0 and ox a multiple of M: all M columns exist
+                float* o = a.dst + ((long long)(b * a.Cout + cout) * H + oy) * W + ox;
                 if constexpr (M == 4) *(f32x4*)o = (f32x4){y[0], y[1], y[2], y[3]};
                 else *(float2*)o = make_float2(y[0], y[1]);
             } else {
+                // dense (batch, Cout, H, W), or - dst_split - the two column parities as two dense (batch, Cout, H, W / 2) tensors one after the
+                // other: what the 1 x k stride-(1,2) half of a ConvReLU2 pair then reads as its [even | odd] sources
+                const int wd = a.dst_split ? (W >> 1) : W;
+                float* o = a.dst + (a.dst_split ? (long long)(ox & 1) * a.dst_half : 0ll) + ((long long)(b * a.Cout + cout) * H + oy) * wd + (a.dst_split ? (ox >> 1) : ox);
 #pragma unroll
                 for (int k = 0; k < M; ++k)
-                    if (oy + k < H) o[(long long)k * W] = y[k];
+                    if (oy + k < H) o[(long long)k * wd] = y[k];
             }
         }
 }
@@ -487,21 +506,29 @@ struct W1Derived {
     int mbw;
 };
 
-int derive1(const mr_wino_desc* d, W1Derived* out) {
+int derive1(const mr_wino_desc* d, W1Derived* out, bool views = false) {
     if (!d || d->num_src < 1 || d->num_src > MR_MAX_SOURCES || d->batch < 1 || d->height < 1 || d->width < 4 || !d->dst ||
         !d->packed_weights || d->out_channels < 1)
         return MR_ERR_BAD_ARGUMENT;
     if (d->width % 4) return MR_ERR_UNSUPPORTED;              // 16-byte groups entirely inside or outside the image
+    if (!views && (d->src_row_pitch || d->src_plane_floats || d->dst_split_columns)) return MR_ERR_UNSUPPORTED;   // mr_conv1d_cooktoom_f32 only
+    if (d->src_row_pitch < 0 || d->src_plane_floats < 0) return MR_ERR_BAD_ARGUMENT;
+    const int pitch = d->src_row_pitch ? d->src_row_pitch : d->width;
+    const long long cplane = d->src_plane_floats ? d->src_plane_floats : (long long)d->height * d->width;
+    if (pitch < d->width || (pitch & 3) || cplane < (long long)(d->height - 1) * pitch + d->width || cplane >= (1ll << 30)) return MR_ERR_BAD_ARGUMENT;
+    if (d->dst_split_columns && (d->width & 7)) return MR_ERR_UNSUPPORTED;       // each parity half must keep rows of a multiple of 4 columns
     if (d->residual) return MR_ERR_UNSUPPORTED;
     if (!valid_mbw1(d->cout_blocks_per_wave)) return MR_ERR_BAD_ARGUMENT;
     if (d->activation != MR_ACT_NONE && d->activation != MR_ACT_RELU && d->activation != MR_ACT_LEAKY_RELU) return MR_ERR_UNSUPPORTED;
+    if (d->activation == MR_ACT_LEAKY_RELU && !(d->act_p0 >= 0.f && d->act_p0 <= 1.f)) return MR_ERR_UNSUPPORTED;   // the epilogue is max(x, x * slope)
     W1KArgs& k = out->k;
     memset(&k, 0, sizeof(k));
     int nchunks = 0;
     for (int s = 0; s < d->num_src; ++s) {
         if (!d->src[s] || d->src_channels[s] < 1) return MR_ERR_BAD_ARGUMENT;
-        const long long bytes = (long long)d->batch * d->src_channels[s] * d->height * d->width * 4;
-        if (bytes >= (1ll << 31)) return MR_ERR_UNSUPPORTED;
+        // bytes the launch may address from src[s]: the stored tensor, less what a view that starts (pitch - width) floats into it leaves behind
+        const long long bytes = ((long long)d->batch * d->src_channels[s] * cplane - (pitch - d->width)) * 4;
+        if (bytes >= (1ll << 31) || bytes <= 0) return MR_ERR_UNSUPPORTED;
         k.src[s] = d->src[s];
         k.src_bytes[s] = (int)bytes;
         k.src_c[s] = d->src_channels[s];
@@ -511,6 +538,9 @@ int derive1(const mr_wino_desc* d, W1Derived* out) {
     if ((long long)d->batch * d->out_channels * d->height * d->width * 4 >= (1ll << 33)) return MR_ERR_UNSUPPORTED;
     k.nsrc = d->num_src;
     k.H = d->height; k.W = d->width;
+    k.pitch = pitch; k.cplane = (int)cplane;
+    k.dst_split = d->dst_split_columns ? 1 : 0;
+    k.dst_half = (long long)d->batch * d->out_channels * d->height * (d->width / 2);
     k.dst = d->dst; k.bias = d->bias;
     k.act = d->activation; k.p0 = d->act_p0;
     k.Cout = d->out_channels;
@@ -549,19 +579,20 @@ int launch1_mbw(const W1Derived& dv, hipStream_t stream) {
 // F(2, 7) was never selected by a measured table (F(4, 7) halves the 7-tap layers, the direct kernel beats F(2, 7)): its instantiations
 // are compiled into the diagnostic library only (python -m monorec_amd.build --timeline).
 #ifdef MR_DIAGNOSTIC_FORMS
-bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 2 && r == 7) || (m == 4 && r == 7); }
+bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 2 && r == 7) || (m == 4 && r == 7) || (m == 4 && r == 4); }
 #else
-bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 4 && r == 7); }
+bool valid_form(int m, int r) { return (m == 4 && r == 3) || (m == 4 && r == 7) || (m == 4 && r == 4); }
 #endif
 bool valid_ct_mbw(int m, int r, int mbw) { return mbw >= 1 && mbw <= (m + r - 1 >= 10 ? 3 : 4); }      // N x MBW accumulator sets in 256 VGPRs
 
 template <int AXIS, int M, int R>
 int derive_ct_form(const mr_wino_desc* d, W1Derived* out) {
     using Gm = CtGeom<AXIS, M, R>;
-    const int rc = derive1(d, out);                           // argument checks, sources, chunk count (geometry of F(2,3) overwritten below)
+    const int rc = derive1(d, out, true);                     // argument checks, sources (strided views allowed), chunk count (geometry of F(2,3) overwritten below)
     if (rc != 0) return rc;
+    if (d->dst_split_columns && AXIS != 1) return MR_ERR_UNSUPPORTED;
     const int mbw = d->cout_blocks_per_wave;
-    const int ufl = Gm::N * 2 * mbw * 64;
+    const int ufl = ct_u_stream(Gm::N, mbw);
     out->k.tiles_x = (d->width + Gm::RW - 1) / Gm::RW;
     out->k.wgroup_stride = (long long)out->k.nchunks * ufl;
     out->grid = dim3((unsigned)(out->k.tiles_x * ((d->height + Gm::RH - 1) / Gm::RH)), out->grid.y, out->grid.z);
@@ -607,13 +638,14 @@ int run_ct_form(const mr_wino_desc* d, hipStream_t stream, bool launch, int64_t*
 int run_ct(const mr_wino_desc* d, int axis, int m, int r, hipStream_t stream, bool launch, int64_t* lds) {
     if (!valid_form(m, r) || (axis != 0 && axis != 1)) return MR_ERR_BAD_ARGUMENT;
     if (m == 4 && r == 3) return axis == 0 ? run_ct_form<0, 4, 3>(d, stream, launch, lds) : run_ct_form<1, 4, 3>(d, stream, launch, lds);
+    if (m == 4 && r == 4) return axis == 0 ? run_ct_form<0, 4, 4>(d, stream, launch, lds) : run_ct_form<1, 4, 4>(d, stream, launch, lds);
 #ifdef MR_DIAGNOSTIC_FORMS
     if (m == 2 && r == 7) return axis == 0 ? run_ct_form<0, 2, 7>(d, stream, launch, lds) : run_ct_form<1, 2, 7>(d, stream, launch, lds);
 #endif
     return axis == 0 ? run_ct_form<0, 4, 7>(d, stream, launch, lds) : run_ct_form<1, 4, 7>(d, stream, launch, lds);
 }
 
-const double* form_g(int m, int r) { return m == 4 && r == 3 ? CtForm<4, 3>::g() : m == 2 ? CtForm<2, 7>::g() : CtForm<4, 7>::g(); }
+const double* form_g(int m, int r) { return m == 4 && r == 3 ? CtForm<4, 3>::g() : m == 4 && r == 4 ? CtForm<4, 4>::g() : m == 2 ? CtForm<2, 7>::g() : CtForm<4, 7>::g(); }
 
 }  // namespace
 
@@ -684,7 +716,7 @@ extern "C" size_t mr_cooktoom1d_packed_weight_floats(int32_t out_channels, const
     int nchunks = 0;
     for (int s = 0; s < num_src; ++s) nchunks += pad8(src_channels[s]) / WCK;
     const int groups = (out_channels + 16 * mbw - 1) / (16 * mbw);
-    return (size_t)groups * nchunks * ((m + r - 1) * 2 * mbw * 64);
+    return (size_t)groups * nchunks * ct_u_stream(m + r - 1, mbw);
 }
 
 // weight: (out_channels, sum(src_channels), r, 1) or (.., 1, r) fp32, nn.Conv2d layout - r taps per (cout, cin) either way.  U = G g in
@@ -704,7 +736,7 @@ extern "C" int mr_cooktoom1d_pack_weights_f32(const float* weight, int32_t out_c
         int cin_off = 0;
         for (int s = 0; s < num_src; ++s) {
             const int cpad = pad8(src_channels[s]);
-            for (int c0 = 0; c0 < cpad; c0 += WCK)
+            for (int c0 = 0; c0 < cpad; c0 += WCK) {
                 for (int p = 0; p < npos; ++p)
                     for (int c4 = 0; c4 < 2; ++c4)
                         for (int mb = 0; mb < mbw; ++mb)
@@ -718,6 +750,8 @@ extern "C" int mr_cooktoom1d_pack_weights_f32(const float* weight, int32_t out_c
                                 }
                                 dst[o++] = (float)u;
                             }
+                for (int pad = npos * 2 * mbw * 64; pad < ct_u_stream(npos, mbw); ++pad) dst[o++] = 0.f;      // whole 1 KiB pieces per chunk (odd npos)
+            }
             cin_off += src_channels[s];
         }
     }

@@ -265,9 +265,11 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         lbase[i] = ((lane >> 4) * PLANE + prow[i] * a.SH * a.IW + pcol[i] * a.SW) * 16;
     }
     const int g4 = (lane >> 4) * 4;
-    // activation as ONE branch-free form: x > 0 ? x : x * slope with slope 1 (none), 0 (ReLU), p0 (LeakyReLU) - a switch per element compiled
-    // into ~190 scalar branches per tile epilogue (r04_s6: 3 us of every 12 us tile)
-    const float slope = a.act == MR_ACT_RELU ? 0.f : (a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f);
+    // activation as ONE branch-free form: max(x, lo) with lo = x (none), 0 (ReLU: -inf -> 0, no -0.0, like torch.relu), x * p0 (LeakyReLU,
+    // 0 <= p0 <= 1: derive8 rejects other slopes) - a switch per element compiled into ~190 scalar branches per tile epilogue (r04_s6: 3 us
+    // of every 12 us tile)
+    const unsigned keep = a.act == MR_ACT_RELU ? 0u : ~0u;   // lo = (x * slope) AND keep: +0 for ReLU (an AND, not a select: hipcc clones the store loops around a uniform select)
+    const float slope = a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f;
     // bias of this lane's output channels: once per workgroup (a load per tile costs a memory round trip each - 1 us of the 12 us tile)
     float bias[MB][4];
 #pragma unroll
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = acc[m][i][r] + bias[m][r];          // (padded channels: zero weights and zero bias give 0)
-                        v[r] = x > 0.f ? x : x * slope;
+                        v[r] = fmaxf(x, __uint_as_float(__float_as_uint(x * slope) & keep));
                     }
                     lo[i] = pack2(v[0], v[1]);
                     hi[i] = pack2(v[2], v[3]);
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
                     for (int r = 0; r < 4; ++r)
                         if (cout0 + r < a.Cout) {
                             const float x = acc[m][i][r] + bias[m][r];
-                            o[r * chs] = x > 0.f ? x : x * slope;
+                            o[r * chs] = fmaxf(x, __uint_as_float(__float_as_uint(x * slope) & keep));
                         }
                 }
             }
@@ -522,6 +524,7 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     if (!valid_mb8(mb) || !(nb == 1 || nb == 2 || nb == 4) || !(wv == 4 || wv == 8)) return MR_ERR_BAD_ARGUMENT;
     if (d->dst_layout != MR_LAYOUT_F32_NCHW && d->dst_layout != MR_LAYOUT_BF16_B8) return MR_ERR_BAD_ARGUMENT;
     if (d->activation != MR_ACT_NONE && d->activation != MR_ACT_RELU && d->activation != MR_ACT_LEAKY_RELU) return MR_ERR_UNSUPPORTED;
+    if (d->activation == MR_ACT_LEAKY_RELU && !(d->act_p0 >= 0.f && d->act_p0 <= 1.f)) return MR_ERR_UNSUPPORTED;   // the epilogue is max(x, x * slope)
     const int nphase = d->num_phases <= 1 ? 1 : d->num_phases;
     if (nphase != 1 && nphase != 4) return MR_ERR_BAD_ARGUMENT;
     B8Args& k = out->k;

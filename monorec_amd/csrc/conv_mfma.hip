@@ -671,7 +671,8 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     {
         // bias / residual operands are fetched in batches ahead of the stores that need them: a load issued
         // between two stores would wait out a full memory round trip per output element.
-        // The activation of the common layers (none / ReLU / LeakyReLU) is ONE branch-free form, x > 0 ? x : x * slope (slope 1 / 0 / p0):
+        // The activation of the common layers (none / ReLU / LeakyReLU with a slope in [0, 1]: derive() rejects others) is ONE branch-free form, max(x, lo) with lo = x /
+        // 0 / x * p0 (ReLU as max(x, 0): -inf -> 0 and no -0.0, like torch.relu - ADVICE r4; `x > 0 ? x : x * 0` gave NaN / -0.0 there):
         // as a switch per element it compiled into two scalar branches and an inlined tanh / exp body per stored value (r04: 180
         // instructions per store in the <1,1> kernel, 59 branches for its 4 stores); the sigmoid / |tanh| layers keep the general form
         // behind ONE uniform branch around the whole store loop.
@@ -685,7 +686,8 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
                 bias[m][r] = (a.bias && cout < a.Cout) ? a.bias[cout] : 0.f;
             }
         const long long bbase = (long long)b * a.dst_bstride;
-        const float slope = a.act == MR_ACT_RELU ? 0.f : (a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f);
+        const unsigned keep = a.act == MR_ACT_RELU ? 0u : ~0u;   // lo = (x * slope) AND keep: +0 for ReLU (an AND, not a select: hipcc clones the store loops around a uniform select)
+        const float slope = a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f;
         auto store_all = [&](auto simple_tag) {
             constexpr bool SIMPLE = decltype(simple_tag)::value;
 #pragma unroll
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
                         if (cout0 + r < a.Cout) {
                             float v = acc[m][i][r] + bias[m][r];              // (no bias: + 0)
                             v += rv[i][r];                                    // (no residual: + 0)
-                            a.dst[idx0[i] + r * chs] = SIMPLE ? (v > 0.f ? v : v * slope) : mr_activate(v, a.act, a.p0, a.p1);
+                            a.dst[idx0[i] + r * chs] = SIMPLE ? fmaxf(v, __uint_as_float(__float_as_uint(v * slope) & keep)) : mr_activate(v, a.act, a.p0, a.p1);
                         }
                 }
             }
@@ -776,12 +778,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue4_kernel(const ConvKArgs a
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) v += part[ks];
     f32x4 o;
-    const float slope = a.act == MR_ACT_RELU ? 0.f : (a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f);
+    const unsigned keep = a.act == MR_ACT_RELU ? 0u : ~0u;   // lo = (x * slope) AND keep: +0 for ReLU (an AND, not a select: hipcc clones the store loops around a uniform select)
+    const float slope = a.act == MR_ACT_LEAKY_RELU ? a.p0 : 1.f;
     if (a.act <= MR_ACT_LEAKY_RELU) {                 // branch-free form of none / ReLU / LeakyReLU (see conv_mfma_kernel's epilogue)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = (v[r] + bias) + rv[r];
-            o[r] = x > 0.f ? x : x * slope;
+            o[r] = fmaxf(x, __uint_as_float(__float_as_uint(x * slope) & keep));
         }
     } else {
 #pragma unroll
@@ -818,6 +821,7 @@ int derive(const mr_conv_desc* d, Derived* out) {
     if (kws && (d->split_k != 1 || d->compute_dtype != MR_COMPUTE_F32)) return MR_ERR_UNSUPPORTED;
     if (!valid_mb(mb) || !(nb == 1 || nb == 2 || nb == 4) || !valid_ck(d->chunk_channels)) return MR_ERR_BAD_ARGUMENT;
     if (d->split_k < 1) return MR_ERR_BAD_ARGUMENT;
+    if (d->activation == MR_ACT_LEAKY_RELU && !(d->act_p0 >= 0.f && d->act_p0 <= 1.f)) return MR_ERR_UNSUPPORTED;   // the epilogue is max(x, x * slope)
     const int nphase = d->num_phases <= 1 ? 1 : d->num_phases;
     if (nphase != 1 && nphase != 4) return MR_ERR_BAD_ARGUMENT;
     ConvKArgs& k = out->k;

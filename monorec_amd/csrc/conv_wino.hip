@@ -87,11 +87,13 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
     return r;
 }
 
-// none / ReLU / LeakyReLU as ONE branch-free form (x > 0 ? x : x * slope, slope 1 / 0 / p0; the slope is wave-uniform and hoisted): as a
+// none / ReLU / LeakyReLU as ONE branch-free form, max(x, lo) with lo = x (none), 0 (ReLU: -inf -> 0 and no -0.0, like torch.relu),
+// x * p0 (LeakyReLU, 0 <= p0 <= 1 - the host side rejects other slopes); lo's selector is wave-uniform: as a
 // switch the compiler emitted scalar branches around every stored element of the epilogue (round 4: 200-450 branches per workgroup)
 __device__ __forceinline__ float wino_activate(float v, int act, float p0) {
-    const float slope = act == MR_ACT_RELU ? 0.f : (act == MR_ACT_LEAKY_RELU ? p0 : 1.f);
-    return v > 0.f ? v : v * slope;
+    const unsigned keep = act == MR_ACT_RELU ? 0u : ~0u;          // (an AND, not a select: a uniform select made hipcc clone the store loops)
+    const float lo = __uint_as_float(__float_as_uint(v * (act == MR_ACT_LEAKY_RELU ? p0 : 1.f)) & keep);
+    return fmaxf(v, lo);
 }
 
 template <int MBW>
@@ -526,6 +528,8 @@ int wino_derive(const mr_wino_desc* d, WinoDerived* out) {
     if (d->width % 4) return MR_ERR_UNSUPPORTED;              // 16-byte groups entirely inside or outside the image
     if (!valid_mbw(d->cout_blocks_per_wave)) return MR_ERR_BAD_ARGUMENT;
     if (d->activation != MR_ACT_NONE && d->activation != MR_ACT_RELU && d->activation != MR_ACT_LEAKY_RELU) return MR_ERR_UNSUPPORTED;
+    if (d->activation == MR_ACT_LEAKY_RELU && !(d->act_p0 >= 0.f && d->act_p0 <= 1.f)) return MR_ERR_UNSUPPORTED;   // the epilogue is max(x, x * slope)
+    if (d->src_row_pitch || d->src_plane_floats || d->dst_split_columns) return MR_ERR_UNSUPPORTED;      // strided views: mr_conv1d_cooktoom_f32 only
     WinoKArgs& k = out->k;
     memset(&k, 0, sizeof(k));
     int nchunks = 0;

@@ -59,6 +59,7 @@ struct CvArgs {
     int relaxed_sums;     // 1 (mr_cost_volume_b8_f32 = the bf16 configuration only): separable 3x3 window sums and x * fp32(1/9) - see march_finish
     int fast_w, fast_h;   // 1: the 3-instruction sequence div_const() equals the correctly rounded quotient for EVERY fp32 dividend
                           // (checked exhaustively on the host, mr_exact_const_division); 0: IEEE division
+    int lean;             // 1 (mr_cost_volume_b8_lean_f32): the fusion kernel does NOT finalise the dense fp32 single-frame volumes (sfcv stays scratch)
     void* sfcv_b8[MR_MAX_FRAMES];   // optional second copy of the single-frame volumes in the channel-blocked bf16 layout of csrc/conv_b8.hip
                                     // ((B, D / 8, H, W, 8) bf16 per frame; the bf16 MFMA mode's mask encoder reads it), or null
 };
@@ -868,6 +869,7 @@ __global__ __launch_bounds__(256) void cv_fuse_reg_kernel(const CvArgs a) {
     // plane d of a volume = buffer offset p*4 (per lane) + d*HW*4 (scalar): no 64-bit per-plane addresses in VGPRs; lanes beyond
     // the image read 0 / write nothing through the descriptor's range check
     const int voff = p < HWp ? p * 4 : -1;
+    const int voff_sf = (B8OUT && a.lean) ? -1 : voff;     // lean: the fp32 single-frame stores fall outside the descriptor's range - dropped by the hardware, no branch
     const int vol_bytes = DD * HWp * 4;
     float num[DD];
     float wsum = 0.f;
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(256) void cv_fuse_reg_kernel(const CvArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const int d = d0 + j;
                 o[j] = (1.0f - v[d] * 2.0f) * vm;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[j]), sf, voff, d * HWp * 4, 0);   // :251
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[j]), sf, voff_sf, d * HWp * 4, 0);   // :251
                 const float t = v[d] * w;                                // :262
                 num[d] = f == 0 ? t : num[d] + t;
             }
@@ -1361,7 +1363,7 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
                       int32_t batch, int32_t num_depths, int32_t height, int32_t width,
                       float alpha, const float* channel_weights, int32_t use_ssim,
                       const float* pixel_depths, int32_t sfcv_mult_mask, int32_t patch_size, bool tiled,
-                      float* cost_volume, float* const* sfcv, void* stream, void* const* sfcv_b8 = nullptr) {
+                      float* cost_volume, float* const* sfcv, void* stream, void* const* sfcv_b8 = nullptr, bool relaxed = false, bool lean = false) {
     if (use_ssim < 0 || use_ssim > 3) return MR_ERR_BAD_ARGUMENT;
     if (patch_size < 1 || patch_size > 7 || !(patch_size & 1)) return MR_ERR_UNSUPPORTED;
     if (!sfcv_mult_mask && num_depths < num_frames) return MR_ERR_UNSUPPORTED;      // validity words live in planes 0..F-1
@@ -1382,7 +1384,8 @@ int cost_volume_entry(const float* keyframe, const float* const* frames, int32_t
     a.kinv = kinv; a.proj = proj; a.depths = depths; a.pix_depths = pixel_depths; a.cv = cost_volume;
     a.F = num_frames; a.B = batch; a.D = num_depths; a.H = height; a.W = width;
     a.tiles_x = 0; a.nchunk = 1; a.dchunk = num_depths;
-    a.relaxed_sums = sfcv_b8 != nullptr ? 1 : 0;
+    a.relaxed_sums = (sfcv_b8 != nullptr || relaxed) ? 1 : 0;
+    a.lean = (lean && sfcv_b8 != nullptr) ? 1 : 0;
     a.alpha = alpha;
     for (int c = 0; c < 3; ++c) a.cw[c] = channel_weights[c] / (float)(patch_size * patch_size);      // :141
     a.inv_dm1 = (float)(1.0 / (double)(num_depths - 1));
@@ -1465,6 +1468,32 @@ extern "C" int mr_cost_volume_b8_f32(const float* keyframe, const float* const* 
     if (!sfcv_b8) return MR_ERR_BAD_ARGUMENT;
     return cost_volume_entry(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
                              channel_weights, use_ssim, pixel_depths, 1, 3, false, cost_volume, sfcv, stream, sfcv_b8);
+}
+
+// mr_cost_volume_b8_f32 without the dense fp32 single-frame volumes: `sfcv` is scratch (raw per-frame costs), only the fused volume and the B8
+// copies are outputs - for callers of the bf16 configuration that do not hand out `single_frame_cvs` (MonoRecModel(hip_lean_outputs=True)).
+extern "C" int mr_cost_volume_b8_lean_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                          const float* kinv, const float* proj, const float* depths,
+                                          int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                          float alpha, const float* channel_weights, int32_t use_ssim, const float* pixel_depths,
+                                          float* cost_volume, float* const* sfcv_scratch, void* const* sfcv_b8, void* stream) {
+    if (!sfcv_b8) return MR_ERR_BAD_ARGUMENT;
+    return cost_volume_entry(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                             channel_weights, use_ssim, pixel_depths, 1, 3, false, cost_volume, sfcv_scratch, stream, sfcv_b8, false, true);
+}
+
+// mr_cost_volume_mode_f32 of the default configuration with the RELAXED window sums of mr_cost_volume_b8_f32 (separable 3x3 sums, x * fp32(1/9))
+// and dense fp32 outputs only: the opt-in of the fp32 path (MonoRecModel(hip_cv_separable=True)).  Validity (the zeros of
+// the volumes) is exactly that of mr_cost_volume_f32; the values differ by the rounding of another summation order of the same nine terms
+// (single-frame volumes <= 1e-4, depth <= 2e-6 on the fixtures: tests/test_gpu_kernels.py).  Per-pixel depths and sizes whose constant
+// divisions fail mr_exact_const_division run the exact kernels (the relaxed instantiation exists for the common case only).
+extern "C" int mr_cost_volume_relaxed_f32(const float* keyframe, const float* const* frames, int32_t num_frames,
+                                          const float* kinv, const float* proj, const float* depths,
+                                          int32_t batch, int32_t num_depths, int32_t height, int32_t width,
+                                          float alpha, const float* channel_weights, int32_t use_ssim, const float* pixel_depths,
+                                          float* cost_volume, float* const* sfcv, void* stream) {
+    return cost_volume_entry(keyframe, frames, num_frames, kinv, proj, depths, batch, num_depths, height, width, alpha,
+                             channel_weights, use_ssim, pixel_depths, 1, 3, false, cost_volume, sfcv, stream, nullptr, true);
 }
 
 extern "C" int mr_cost_volume_f32(const float* keyframe, const float* const* frames, int32_t num_frames,

@@ -30,6 +30,108 @@ def init_from_env(backend=None, single_rank_group=False):
         torch.cuda.set_device(local)
         kwargs["device_id"] = torch.device("cuda", local)
     dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kwargs)
+    if world > 1:
+        place_rank()            # this rank's share of the node's CPUs (NUMA node of its GPU)
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def rank_cpu_set(local_rank, local_world, allowed=None, gpu_numa=None):
+    """CPUs one rank of a node should run on.  `gpu_numa[r]` = CPU list of the NUMA node the GPU of local rank r hangs off (None where
+    unknown): the ranks whose GPUs share a node split that node's CPUs evenly, in rank order; without NUMA information every rank gets an
+    even contiguous share of the allowed CPUs.  Either way a rank's busy-polling host thread, HIP's helper threads and its PNG-decode pool
+    stay on one socket and off the other ranks' cores (8 ranks x (2 polling + ~5 decode) cores, nothing pinned).
+    Pure function of its arguments."""
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    aset = set(allowed)
+    local_world = max(1, int(local_world))
+    local_rank = min(max(0, int(local_rank)), local_world - 1)
+
+    def split(cpus, k, n):
+        # share k of n of EVERY run of consecutive CPU ids: Linux numbers the second hardware thread of core i as i + (cores of the box), so a
+        # NUMA node's list is two runs (0-63,128-191) and a rank gets the same slice of both - whole cores, not another rank's sibling threads
+        runs, out = [], []
+        for c in cpus:
+            if runs and c == runs[-1][-1] + 1:
+                runs[-1].append(c)
+            else:
+                runs.append([c])
+        for run in runs:
+            per = len(run) // n
+            if per == 0:
+                continue
+            out += run[k * per:(k + 1) * per] if k < n - 1 else run[k * per:]
+        if out:
+            return out
+        per = max(1, len(cpus) // n)
+        return cpus[k * per:(k + 1) * per] if k < n - 1 else cpus[k * per:]
+    mine = gpu_numa[local_rank] if gpu_numa and local_rank < len(gpu_numa) else None
+    if mine:
+        node = [c for c in mine if c in aset]
+        sharers = [r for r in range(min(local_world, len(gpu_numa))) if gpu_numa[r] == mine]
+        share = split(node, sharers.index(local_rank), len(sharers)) if node else []
+        if share:
+            return share
+    return split(allowed, local_rank, local_world) or allowed
+
+
+_numa_cache = {}
+
+
+def _gpu_numa_cpus(device_index):
+    """CPU list of the NUMA node GPU `device_index` is attached to, or None (no sysfs entry, node -1, no torch device)."""
+    if device_index in _numa_cache:
+        return _numa_cache[device_index]
+    cpus = None
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{addr}/numa_node").read())
+        if node >= 0:
+            cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+    except Exception:
+        cpus = None
+    _numa_cache[device_index] = cpus
+    return cpus
+
+
+def place_rank(local_rank=None, local_world=None, devices=None):
+    """Pin this process to its share of the node's CPUs (see `rank_cpu_set`) and size torch's intra-op pool to it.  Called by bench.py and
+    `init_from_env` in multi-rank jobs; a one-rank job is left alone.  `devices[r]` = device index of local rank r (default r).  Returns a
+    summary dict for logs / the bench line."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else int(local_world)
+    info = {"local_rank": local_rank, "local_world_size": local_world, "pinned": False, "cpus": len(os.sched_getaffinity(0)), "numa": False}
+    if local_world <= 1:
+        return info
+    try:
+        # one rank per GPU: the GPU of local rank r is device r, unless `devices` says otherwise (tests: every rank on device 0)
+        gpu_numa = [_gpu_numa_cpus(r if devices is None else devices[r]) for r in range(local_world)]
+        share = rank_cpu_set(local_rank, local_world, gpu_numa=gpu_numa)
+        os.sched_setaffinity(0, share)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(share))))
+        info.update({"pinned": True, "cpus": len(share), "cpu_range": [share[0], share[-1]], "numa": gpu_numa[local_rank] is not None})
+    except Exception as e:          # affinity is a placement hint, never a reason to fail the job
+        info["error"] = repr(e)
+    return info
+
+
+def host_thread_budget(cpus_for_rank):
+    """Threads a rank may spend next to its enqueueing thread: (PNG-decode workers, host spin seconds).  The busy-polling host thread
+    and HIP's helper threads take ~2 cores (bench line `host_cpu_ms_per_keyframe`); decode gets what is left, at most 8 (the
+    reference's evaluation config runs 8 loader workers, configs/evaluate/eval_monorec.json:33); with fewer than 4 cores the host
+    wait stops spinning almost at once and sleeps in hipEventSynchronize instead."""
+    decode = max(1, min(8, int(cpus_for_rank) - 2))
+    spin = 0.004 if cpus_for_rank >= 4 else 0.0002
+    return decode, spin
 
 
 def world_info():

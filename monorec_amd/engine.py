@@ -151,6 +151,30 @@ class _Ref:
         return self.fixed if self.name is None else self.plan.bound[self.name] + self.offset
 
 
+# Environment variables that change WHICH kernels / forms a plan runs (and therefore its numerics and speed).  They exist for the tuning
+# sessions (A/B of a candidate table, of one kernel family); a stray one must not pass silently: `active_env_overrides()` is
+# echoed into bench.py's config block, and the first plan built under any of them warns once.
+ENV_OVERRIDES = ("MR_TUNED_SCHEDULES", "MR_TUNED_WINOGRAD", "MR_B8", "MR_B8_NB4", "MR_WINOGRAD", "MR_ONE_CHANNEL_KERNELS", "MR_HIP_LIBRARY")
+_warned_env = [False]
+
+
+def active_env_overrides():
+    """{name: value} of the kernel-selection overrides set in this process's environment (empty = the committed tables and defaults)."""
+    import os
+    return {k: os.environ[k] for k in ENV_OVERRIDES if os.environ.get(k) not in (None, "")}
+
+
+def _warn_env_overrides():
+    if _warned_env[0]:
+        return
+    _warned_env[0] = True
+    act = active_env_overrides()
+    if act:
+        import warnings
+        warnings.warn(f"monorec_amd: kernel-selection overrides active in the environment: {act} - the plan differs from the committed "
+                      "tables / defaults (tuning aid; unset them for the measured configuration)")
+
+
 TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
 
 
@@ -181,8 +205,10 @@ def _load_winograd():
 
 _load_winograd()
 
-WINOGRAD_F2 = {}    # conv_forms = "f2": for every key whose table entry is a larger form (F(4,.), F(4x4,3x3)), the F(2,.) code that was
-                    # measured best for it before the larger forms existed (0 = direct kernel: the 7-tap layers)
+WINOGRAD_F2 = {}    # conv_forms = "f2": for a key whose table entry is a larger form (F(4,.), F(4x4,3x3)), the F(2,.) code that was
+                    # measured best for it before the larger forms existed (0 = direct kernel: the 7-tap layers).  MEASURED for the c2 / c3
+                    # keys only (15 of the 68 larger-form keys); every other key falls back to a rule - variant 11 for 3x3, the direct kernel
+                    # for 1-D layers - whose throughput is unmeasured
 
 
 def _load_winograd_f2():
@@ -249,6 +275,38 @@ def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3, f2=False):
     if f2 and code >= 40:                    # F(4,.) -> what was measured best among F(2,.) and the direct kernel before the larger forms
         code = WINOGRAD_F2.get(key, 0)
     return code
+
+
+def stride2_signature(taps, cout, cin, out_h, out_w, batch):
+    return f"s2k{taps}_co{cout}_ci{cin}_o{out_h}x{out_w}_b{batch}"
+
+
+def choose_stride2(taps, cout, cin, out_h, out_w, batch):
+    """A ConvReLU2 pair with stride 2 (k x 1 stride (2,1), then 1 x k stride (1,2): DepthModule.enc stages 1-3, monorec_model.py:489-501) on
+    the stride-1 Cook-Toom kernel over [even | odd] views of its input (cooktoom.stride2_as_stride1; 7 taps: F(4,4), 5 taps: F(4,3)):
+    10 * (blocks of 16 output channels per workgroup of the k x 1 half) + (the same of the 1 x k half), or 0 = both halves on the direct MFMA
+    kernel.  Only what the measured table says (tools/bench_stride2.py --emit; keys `s2k<taps>_co<cout>_ci<cin>_o<out_h>x<out_w>_b<batch>`)."""
+    if taps not in (5, 7) or out_w % 4:
+        return 0
+    return WINOGRAD.get(stride2_signature(taps, cout, cin, out_h, out_w, batch), 0)
+
+
+def stride2_unified_weights(w, n, axis):
+    """(Cout, C, k, 1) [axis 1] / (Cout, C, 1, k) [axis 0] stride-2 filter -> the stride-1 filter over [even samples | odd samples]:
+    (Cout, 2 C, r2, 1) / (Cout, 2 C, 1, r2) with r2 = ceil(k / 2) (cooktoom.stride2_as_stride1; a phase's missing tap is a zero weight)."""
+    from . import cooktoom
+    k = int(w.shape[2] if axis == 1 else w.shape[3])
+    r2, pad, ev, od = cooktoom.stride2_as_stride1(k, n)
+    assert pad == (r2 - 1) // 2, (k, pad)                          # the low-side padding the Cook-Toom kernel's geometry assumes ((R - 1) / 2)
+    cout, c = int(w.shape[0]), int(w.shape[1])
+    taps = w.reshape(cout, c, k)
+    u = torch.zeros(cout, 2 * c, r2, dtype=torch.float32)
+    for t in range(r2):
+        if ev[t] is not None:
+            u[:, :c, t] = taps[:, :, ev[t]]
+        if od[t] is not None:
+            u[:, c:, t] = taps[:, :, od[t]]
+    return u.reshape(cout, 2 * c, r2, 1) if axis == 1 else u.reshape(cout, 2 * c, 1, r2)
 
 
 def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16=False, mixed_phases=False):
@@ -345,12 +403,13 @@ class Plan:
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
                  pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3,
-                 one_channel_kernels=None, winograd=None, conv_forms="table"):
+                 one_channel_kernels=None, winograd=None, conv_forms="table", cv_separable=False, lean_outputs=False):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps < 2:
             raise ValueError("cv_depth_steps must be >= 2 (monorec_model.py:258 divides by cv_depth_steps - 1)")
         self.lib = _lib.load()
+        _warn_env_overrides()
         self.B, self.H, self.W, self.F, self.D = batch, height, width, num_frames, depth_steps
         self.device = torch.device(device)
         self.inv_depth_min_max = tuple(float(v) for v in inv_depth_min_max)
@@ -363,6 +422,12 @@ class Plan:
         self.mask_use_cv, self.mask_use_feats = bool(mask_use_cv), bool(mask_use_feats)   # :352-355
         self.simple_mask = bool(simple_mask)                                              # SimpleMaskModule, :388-473
         self.cv_patch_size = int(cv_patch_size)                                           # :138-142,247
+        # opt-in (MonoRecModel(hip_cv_separable=True)): the default cost-volume configuration through mr_cost_volume_relaxed_f32 - separable
+        # 3x3 window sums and x * fp32(1/9); validity identical, volumes within 1e-4, depth within 2e-6 of the exact-order kernel
+        self.cv_separable = bool(cv_separable)
+        # opt-in of the bf16 configuration (MonoRecModel(hip_bf16=True, hip_lean_outputs=True)): no dense fp32 `single_frame_cvs` - the fusion
+        # kernel writes the fused volume and the B8 copies the mask encoder reads, nothing else (403 MB of HBM writes less at configs[4])
+        self.lean_outputs = bool(lean_outputs)
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = int(bf16)         # convolutions: 0 fp32 MFMA, 1 bf16 MFMA (MR_COMPUTE_BF16), 2 bf16x3 split (MR_COMPUTE_BF16X3); everything else fp32
         # bf16 MFMA mode: the activations BETWEEN the convolutions of the mask and depth nets are stored channel-blocked in bf16 ("B8",
@@ -689,13 +754,21 @@ class Plan:
         self.stages[stage].append((name, run))
         return out
 
-    def _conv_winograd_1d(self, stage, name, srcs, weight, bias, out, act, p0, axis, mbw, m=2):
+    def _conv_winograd_1d(self, stage, name, srcs, weight, bias, out, act, p0, axis, mbw, m=2, view=None, dst_split=False, ref_macs=None, ref_k=None,
+                          sig=None):
         """One mr_conv1d3_winograd_f32 launch (csrc/conv1d_wino.hip: F(2,3), 4 instead of 6 multiplies per output pair) - or, for m = 4 or
         7 taps, one mr_conv1d_cooktoom_f32 launch (F(m, taps): m + taps - 1 multiplies per m outputs) - in place of a k x 1 / 1 x k
         stride-1 mr_conv2d_f32 launch."""
         lib = self.lib
-        n, _, hs, ws = srcs[0].shape
-        src_channels = [int(s_.shape[1]) for s_ in srcs]
+        if view is None:
+            n, _, hs, ws = srcs[0].shape
+            src_channels = [int(s_.shape[1]) for s_ in srcs]
+            src_ptrs = [s_.data_ptr() for s_ in srcs]
+        else:
+            # strided source views (the k x 1 stride-(2,1) half of a ConvReLU2 pair as a stride-1 form over [even rows | odd rows]):
+            # view = dict(ptrs, channels, batch, height, width, row_pitch, plane) - `srcs` only keeps the underlying tensors alive
+            n, hs, ws = view["batch"], view["height"], view["width"]
+            src_channels, src_ptrs = list(view["channels"]), list(view["ptrs"])
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         taps = int(weight.shape[3] if axis == 0 else weight.shape[2])
         assert tuple(weight.shape[2:]) == ((1, taps) if axis == 0 else (taps, 1)) and cin == sum(src_channels), (name, weight.shape)
@@ -713,12 +786,19 @@ class Plan:
             packed = torch.empty(nfl, dtype=torch.float32)
             _lib.check(lib.mr_wino1d_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), mbw, packed.data_ptr()), "mr_wino1d_pack_weights_f32")
         d = WinoDesc()
-        for i, s_ in enumerate(srcs):
-            d.src[i], d.src_channels[i] = s_.data_ptr(), src_channels[i]
-            if "keyframe" in self.buf and s_ is self.buf["keyframe"]:
+        for i in range(len(src_ptrs)):
+            d.src[i], d.src_channels[i] = src_ptrs[i], src_channels[i]
+            if view is None and "keyframe" in self.buf and srcs[i] is self.buf["keyframe"]:
                 self._input_srcs.append((d, i, "keyframe"))
-        d.num_src, d.batch, d.height, d.width = len(srcs), n, hs, ws
-        assert out.is_contiguous() and tuple(out.shape) == (n, cout, hs, ws)
+        d.num_src, d.batch, d.height, d.width = len(src_ptrs), n, hs, ws
+        if view is not None:
+            assert general, name
+            d.src_row_pitch, d.src_plane_floats = int(view["row_pitch"]), int(view["plane"])
+        if dst_split:            # (2, n, cout, hs, ws / 2): even columns, odd columns - the two sources of the 1 x k stride-(1,2) half
+            assert general and axis == 1 and out.is_contiguous() and tuple(out.shape) == (2, n, cout, hs, ws // 2), (name, tuple(out.shape))
+            d.dst_split_columns = 1
+        else:
+            assert out.is_contiguous() and tuple(out.shape) == (n, cout, hs, ws)
         d.dst, d.out_channels = out.data_ptr(), cout
         d.packed_weights = self._dev(packed).data_ptr()
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
@@ -730,11 +810,14 @@ class Plan:
         rh, rw = ((8, 16 * m) if axis == 0 else (4 * m, 32)) if general else (8, 32)
         wgs = math.ceil(hs / rh) * math.ceil(ws / rw) * n * math.ceil(cout / (16 * mbw))
         kk = (1, taps) if axis == 0 else (taps, 1)
-        self.conv_log.append(dict(name=name, macs=ref * (m + taps - 1) // (m * taps), ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs,
-                                  lds=int(lds), cout=cout, cin=cin, k=kk, out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=0, wino_axis=axis,
-                                  wino_m=m, bf16=0,
-                                  sig=("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_" + winograd_signature(cout, src_channels, hs, ws, n),
-                                  spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin) + kk, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2),
+        # (ref_macs / ref_k: the reference's multiply-adds and filter of a stride-2 layer run as a stride-1 form over [even | odd] - the unified
+        # filter has 2 * ceil(k / 2) >= k taps per input channel, of which the padded one is a zero weight)
+        self.conv_log.append(dict(name=name, macs=ref * (m + taps - 1) // (m * taps), ref_macs=ref if ref_macs is None else ref_macs, mb=mbw, nb=0, split_k=1, ck=8,
+                                  waves=8, kws=0, wgs=wgs,
+                                  lds=int(lds), cout=cout, cin=cin, k=kk if ref_k is None else ref_k, out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=0,
+                                  wino_axis=axis, wino_m=m, wino_taps=taps, stride2=ref_k is not None, bf16=0,
+                                  sig=sig or (("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_" + winograd_signature(cout, src_channels, hs, ws, n)),
+                                  spec=dict(src_shapes=[(n, c_, hs, ws) for c_ in src_channels], w_shape=(cout, cin) + kk, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2),
                                             grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=act, p0=p0, p1=0.0, residual=False,
                                             out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
         self.keep += [d, out] + list(srcs)
@@ -770,10 +853,42 @@ class Plan:
 
     def conv_relu2(self, stage, name, srcs, prefix, mid, out, stride=1):
         """layers.ConvReLU2 (model/layers.py:308-314): k x 1 stride (s,1), then 1 x k stride (1,s)."""
+        wy, wx = self.sd[prefix + ".conv_y.weight"], self.sd[prefix + ".conv_x.weight"]
+        if (stride == 2 and self.winograd and self.conv_forms == "table" and self.bf16 == 0 and len(srcs) == 1 and
+                name + ".conv_y" not in self.schedule_override and name + ".conv_x" not in self.schedule_override and
+                srcs[0].shape[2] % 2 == 0 and srcs[0].shape[3] % 8 == 0 and tuple(wy.shape[2:]) == tuple(wx.shape[2:])[::-1]):
+            code = choose_stride2(int(wy.shape[2]), int(wy.shape[0]), int(wy.shape[1]), int(out.shape[2]), int(out.shape[3]), int(out.shape[0]))
+            if code:
+                return self._conv_relu2_stride2(stage, name, srcs[0], prefix, mid, out, code // 10, code % 10)
         self.same_conv(stage, name + ".conv_y", srcs, prefix + ".conv_y.weight", prefix + ".conv_y.bias", mid,
                        stride=(stride, 1))
         return self.same_conv(stage, name + ".conv_x", [mid], prefix + ".conv_x.weight", prefix + ".conv_x.bias", out,
                               stride=(1, stride))
+
+    def _conv_relu2_stride2(self, stage, name, x, prefix, mid, out, mbw_y, mbw_x):
+        """A stride-2 layers.ConvReLU2 (model/layers.py:289-314; DepthModule.enc stages 1-3, monorec_model.py:489-501) on the stride-1 Cook-Toom
+        kernel (csrc/conv1d_wino.hip, mr_conv1d_cooktoom_f32).  y_i = sum_k g_k d_{2i + k - pad} splits by the parity of the input sample into
+        ONE ceil(k / 2)-tap stride-1 filter over the channel concatenation [even samples | odd samples] (cooktoom.stride2_as_stride1) - no data is
+        moved for it:
+          * k x 1, stride (2,1): the even / odd ROWS of x are two views with twice the row pitch (mr_wino_desc.src_row_pitch): F(4, ceil(k/2)) along y;
+            its epilogue stores the result de-interleaved by COLUMN parity (dst_split_columns) - `mid` = (2, n, c, h/2, w/2) -,
+          * 1 x k, stride (1,2): those two dense halves are its [even | odd] sources: F(4, ceil(k/2)) along x.
+        7 taps -> F(4,4): 3.5 multiplies per output and input channel instead of 7; 5 taps -> F(4,3): 3 instead of 5."""
+        n, c, hs, ws = [int(v) for v in x.shape]
+        wy, by = self.sd[prefix + ".conv_y.weight"], self.sd[prefix + ".conv_y.bias"]
+        wx, bx = self.sd[prefix + ".conv_x.weight"], self.sd[prefix + ".conv_x.bias"]
+        k, cm, co = int(wy.shape[2]), int(wy.shape[0]), int(wx.shape[0])
+        h2, w2 = hs // 2, ws // 2
+        assert x.is_contiguous() and tuple(mid.shape) == (n, cm, h2, ws) and tuple(out.shape) == (n, co, h2, w2), (name, tuple(mid.shape), tuple(out.shape))
+        sig = stride2_signature(k, cm, c, h2, w2, n)
+        mid2 = mid.view(2, n, cm, h2, w2)
+        uy = stride2_unified_weights(wy.detach().float().cpu(), hs, axis=1)
+        self._conv_winograd_1d(stage, name + ".conv_y", [x], uy, by, mid2, ACT_LEAKY_RELU, LEAKY_SLOPE, 1, mbw_y, 4,
+                               view=dict(ptrs=[x.data_ptr(), x.data_ptr() + ws * 4], channels=[c, c], batch=n, height=h2, width=ws, row_pitch=2 * ws, plane=hs * ws),
+                               dst_split=True, ref_macs=n * h2 * ws * cm * c * k, ref_k=(k, 1), sig=sig + "_y")
+        ux = stride2_unified_weights(wx.detach().float().cpu(), ws, axis=0)
+        return self._conv_winograd_1d(stage, name + ".conv_x", [mid2[0], mid2[1]], ux, bx, out, ACT_LEAKY_RELU, LEAKY_SLOPE, 0, mbw_x, 4,
+                                      ref_macs=n * h2 * w2 * co * cm * k, ref_k=(1, k), sig=sig + "_x")
 
     def refine(self, stage, name, srcs, prefix, out):
         """layers.Refine (model/layers.py:389-397): ConvTranspose2d(4, 2) + LeakyReLU + crop = 4 output-parity
@@ -1112,10 +1227,18 @@ class Plan:
 
         def run_cv(stream):
             pix = self.buf["pix_depths"].data_ptr() if self.pix_depths_on else None     # data_dict["cv_depths"], :181-182
-            if self._sfcv_b8_ptrs is not None:
+            if self._sfcv_b8_ptrs is not None and self.lean_outputs:
+                _lib.check(lib.mr_cost_volume_b8_lean_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                                          depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
+                                                          cv_ref.ptr(), sfcv_ptrs, self._sfcv_b8_ptrs, stream), "mr_cost_volume_b8_lean_f32")
+            elif self._sfcv_b8_ptrs is not None:
                 _lib.check(lib.mr_cost_volume_b8_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                      depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
                                                      cv_ref.ptr(), sfcv_ptrs, self._sfcv_b8_ptrs, stream), "mr_cost_volume_b8_f32")
+            elif self.cv_patch_size == 3 and self.cv_separable and self.sfcv_mult_mask:
+                _lib.check(lib.mr_cost_volume_relaxed_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
+                                                          depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,
+                                                          cv_ref.ptr(), sfcv_ptrs, stream), "mr_cost_volume_relaxed_f32")
             elif self.cv_patch_size == 3:
                 _lib.check(lib.mr_cost_volume_mode_f32(self.input_ptr["keyframe"], frame_ptrs, F, kinv.data_ptr(), proj.data_ptr(),
                                                        depths.data_ptr(), B, D, H, W, self.alpha, self.cw, self.cv_mode, pix,

@@ -269,7 +269,7 @@ class MonoRecModel(nn.Module):
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False):
+                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -325,6 +325,15 @@ class MonoRecModel(nn.Module):
         if hip_exact_convs not in (False, True, "f2"):
             raise ValueError("hip_exact_convs must be False, True or 'f2'")
         self._conv_forms = {False: "table", True: "direct", "f2": "f2"}[hip_exact_convs]
+        # opt-in: the cost volume's 3x3 window sums formed separably (mr_cost_volume_relaxed_f32) - the sad kernel runs 17 %
+        # fewer instructions, validity is unchanged, the volumes move by <= 1e-4 and the depth by <= 2e-6 (inside the 1e-4-on-depth bar); the
+        # default keeps the reference's summation order (volumes within 5e-7 of the reference)
+        self._cv_separable = bool(hip_cv_separable)
+        # opt-in, bf16 configuration only: the output dict carries no `single_frame_cvs` (nothing outside the model reads them: evaluater.py:87,
+        # create_pointcloud.py:70-84 use `result` / `cv_mask`; the MaskModule reads the B8 copies) - their fp32 stores are skipped
+        self._lean_outputs = bool(hip_lean_outputs)
+        if self._lean_outputs and self._bf16 != 1:
+            raise ValueError("hip_lean_outputs needs hip_bf16=True (the fp32 path hands out `single_frame_cvs` like the reference)")
         self._slot_counter = [0]         # mutable on purpose: nn.DataParallel replicas (shallow copies made per forward) share it
         self._plans = {}
         self._graphs = {}
@@ -440,7 +449,7 @@ class MonoRecModel(nn.Module):
                         use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
                         no_cv=self.no_cv, mask_use_cv=self.mask_use_cv or self.simple_mask,
                         mask_use_feats=self.mask_use_feats or self.simple_mask, simple_mask=self.simple_mask,
-                        cv_patch_size=self.cv_patch_size, conv_forms=self._conv_forms)
+                        cv_patch_size=self.cv_patch_size, conv_forms=self._conv_forms, cv_separable=self._cv_separable, lean_outputs=self._lean_outputs)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
@@ -489,8 +498,41 @@ class MonoRecModel(nn.Module):
         data_dict.pop(_METRIC_CACHE_KEY, None)
         prep = self._parse(data_dict)                         # checks only; the pose algebra runs behind the encoder's launches
         with torch.cuda.device(prep.device):
+            slot = self._forward_slot(prep)
+            # Everything that needs neither the inputs nor an idle slot happens BEFORE the host waits for the caller's stream (which, in a
+            # loop of forward() calls, is the wait for the previous forward): the two output arenas and the re-targeting of the plan's
+            # launches (~50 us).  The previous forward's launches copied their descriptors when they were enqueued, so patching them now
+            # is safe; behind the wait only the launches themselves remain (forward() at 0.92 x the in-flight-1 loop).
+            prebound = self._prebind_owned(prep, slot)
             self._wait_inputs(prep.device)
-            return self._submit_locked(data_dict, prep, slot=self._forward_slot(prep), own=True)
+            return self._submit_locked(data_dict, prep, slot=slot, own=True, prebound=prebound)
+
+    def _consts_for(self, device):
+        """The three constants of monorec_model.py:675-677, built once per device (a `new_tensor` from a Python list is a blocking pageable
+        H2D copy on the caller's stream, three of them per keyframe) as one 16-byte slab; forward() hands out a copy with the other outputs."""
+        consts = self._consts.get(str(device))
+        if consts is None:
+            slab = torch.zeros(4, dtype=torch.float32, device=device)
+            slab[0], slab[1] = self.inv_depth_min_max[0], self.inv_depth_min_max[1]
+            slab.view(torch.int32)[2] = int(self.cv_depth_steps)
+            consts = (slab[0:1], slab[1:2], slab.view(torch.int32)[2:3])
+            self._consts[str(device)] = consts
+            self._const_slab[str(device)] = slab
+        return consts
+
+    def _prebind_owned(self, prep, slot):
+        """forward(): allocate the caller-owned output arenas and point the slot's plan at them, ahead of the input wait.  None when the
+        plan hands out copies instead (constant content in its output buffers, hipGraph replay).  Safe while an earlier forward of the
+        slot is still running: every launch copies its descriptor when it is enqueued, and nothing of this model is enqueued lazily."""
+        if self._hip_graph:
+            return None
+        b, h, w, nf = prep.shape
+        self._consts_for(prep.device)
+        _, plan = self._plan_for(slot, b, h, w, nf, prep.device)
+        if not plan.outputs_rebindable:
+            return None
+        streams = self._slot_streams(slot, prep.device)
+        return self._bind_owned_outputs(plan, prep.device, (streams["main"], streams["enc"]))
 
     def _own_outputs(self, out):
         """Replace the output views of `out` (resident slot buffers) by tensors the caller owns: one allocation, ONE copy launch
@@ -560,6 +602,12 @@ class MonoRecModel(nn.Module):
         prep = self._parse(data_dict)
         with self._lock, torch.cuda.device(prep.device):
             self._wait_inputs(prep.device)
+            if self._device_idle():
+                # nothing of this model is in flight (first request of a stream, a stream that ran dry): the device would sit idle through
+                # the pose algebra (gather round trip + ~0.1 ms of 4x4 operators, 0.5 ms on a device that has just been synchronised:
+                # r04_s32).  The token stays without matrices and submit() forms them behind the encoder stage's launches, exactly as
+                # forward() does - the device starts on the pose-independent stage at once.
+                return prep
             self._geometry(prep)
         return prep
 
@@ -610,33 +658,42 @@ class MonoRecModel(nn.Module):
         inputs_ready.record(torch.cuda.current_stream(device))
         _host_wait(inputs_ready)
 
-    def _geometry(self, prep):
-        """kinv / proj of a parsed request (monorec_model.py:171,198,207; layers.py:65) into the token.  Inputs must be ready."""
+    def _geometry_begin(self, prep):
+        """First half of the pose algebra of a parsed request: with the 4x4s on the device, the ONE gather launch that brings them into
+        device-writable pinned host memory (its own stream; nothing waits here).  Returns the state `_geometry_finish` completes.
+        forward() / an idle-device submit() call this BEFORE they enqueue the encoder stage, so that the round trip of the gather runs
+        while the host enqueues those ~25 launches instead of queueing behind them."""
         device, mat_list = prep.device, prep.mats
         b, _, _, nf = prep.shape
         caller = torch.cuda.current_stream(device)
         if all(not m.is_cuda for m in mat_list):
             # matrices on the host (a loader that keeps the 4x4s on the CPU, kitti.KittiOdometryDataset): used where they are
-            hm = [m.detach().float() for m in mat_list]
-        else:
-            # matrices on the device: one gather launch into device-writable pinned host memory, awaited at once
-            dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
-                  m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
-            if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
-                ev = torch.cuda.Event()
-                ev.record(caller)
-                _host_wait(ev)
-            pk = (str(device), len(dm), b)
-            pinned = self._prep_pinned.get(pk)
-            if pinned is None:
-                pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), torch.cuda.Stream(device))
-            hm, gs = pinned
-            ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
-            _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")
-            done = torch.cuda.Event()
-            done.record(gs)
-            for m in dm:
-                m.record_stream(gs)
+            return [m.detach().float() for m in mat_list], None
+        # matrices on the device: one gather launch into device-writable pinned host memory
+        dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
+              m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
+        if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
+            ev = torch.cuda.Event()
+            ev.record(caller)
+            _host_wait(ev)
+        pk = (str(device), len(dm), b)
+        pinned = self._prep_pinned.get(pk)
+        if pinned is None:
+            pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), torch.cuda.Stream(device))
+        hm, gs = pinned
+        ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
+        _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")
+        done = torch.cuda.Event()
+        done.record(gs)
+        for m in dm:
+            m.record_stream(gs)
+        return hm, done
+
+    def _geometry_finish(self, prep, state):
+        """Second half: wait for the gather, then kinv / proj (monorec_model.py:171,198,207; layers.py:65) into the token."""
+        hm, done = state
+        b, _, _, nf = prep.shape
+        if done is not None:
             _host_wait(done)
         # host 4x4 algebra with the same ATen CPU operators as the reference: bit-identical matrices (~0.1 ms)
         kinv, proj = host_geometry(hm[0], hm[1], [hm[2 + f] for f in range(nf)], [hm[2 + nf + f] for f in range(nf)])
@@ -644,6 +701,14 @@ class MonoRecModel(nn.Module):
             kinv, proj = self._geometry_override
         prep.kinv, prep.proj = kinv.reshape(-1).clone(), proj.reshape(-1).clone()
         return prep
+
+    def _geometry(self, prep):
+        """kinv / proj of a parsed request into the token.  Inputs must be ready."""
+        return self._geometry_finish(prep, self._geometry_begin(prep))
+
+    def _device_idle(self):
+        """No forward of this model is in flight on any slot (every completion event the host has not collected yet has happened)."""
+        return all(ev.query() for plan in self._plans.values() for ev in plan.enqueued)
 
     def _forward_slot(self, prep):
         """Slot of a forward() call: 0 - one set of resident buffers and packed weights stays hot -, unless its plan hands out copies of
@@ -765,7 +830,7 @@ class MonoRecModel(nn.Module):
                 m["result"] = m["predicted_inverse_depths"][0]
                 m["mask"] = m["cv_mask"]
 
-    def _submit_locked(self, data_dict, prepared, slot=None, own=False):
+    def _submit_locked(self, data_dict, prepared, slot=None, own=False, prebound=None):
         """`own`: forward() - the outputs are produced in memory the caller owns (two arenas allocated here, every launch that writes
         or reads an output buffer re-targeted by Plan.rebind_outputs) instead of the slot's resident buffers; a token without
         matrices gets them formed behind the encoder's launches (the device starts on the pose-independent stage while the host
@@ -774,14 +839,7 @@ class MonoRecModel(nn.Module):
         b, h, w, nf = prepared.shape
         # the three constants of :675-677: built once per device (a `new_tensor` from a Python list is a blocking pageable H2D copy on
         # the caller's stream, three of them per keyframe); forward() hands out copies like every other output
-        consts = self._consts.get(str(device))
-        if consts is None:                                    # one 16-byte slab: forward() hands out a copy of it with the other outputs
-            slab = torch.zeros(4, dtype=torch.float32, device=device)
-            slab[0], slab[1] = self.inv_depth_min_max[0], self.inv_depth_min_max[1]
-            slab.view(torch.int32)[2] = int(self.cv_depth_steps)
-            consts = (slab[0:1], slab[1:2], slab.view(torch.int32)[2:3])
-            self._consts[str(device)] = consts
-            self._const_slab[str(device)] = slab
+        consts = self._consts_for(device)
         data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = consts
 
         if slot is None:
@@ -803,10 +861,10 @@ class MonoRecModel(nn.Module):
             ev.record(cs)
             _host_wait(ev)
         plan.consumers.clear()
-        owned = None
-        if own and plan.outputs_rebindable and not self._hip_graph:
+        owned = prebound                                     # forward(): arenas allocated and launches re-targeted ahead of the input wait
+        if owned is None and own and plan.outputs_rebindable and not self._hip_graph:
             owned = self._bind_owned_outputs(plan, device, (main, enc))
-        elif not self._hip_graph:
+        elif owned is None and not self._hip_graph:
             plan.rebind_outputs(None)
         with torch.cuda.stream(main):
             # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
@@ -851,9 +909,10 @@ class MonoRecModel(nn.Module):
                     plan.buf["cv_mask"].copy_(data_dict["mvobj_mask"])
                 self._run_stage(key, plan, "cv", main)
 
-            if prepared.kinv is None:      # forward(): encoder launches first, the pose algebra while the device runs them
+            if prepared.kinv is None:      # forward() / idle-device submit(): encoder launches first, the pose algebra while the device runs them
+                gstate = self._geometry_begin(prepared)       # the gather launch goes out ahead of the encoder's ~25 launches ...
                 enc_done, tail_done = encoder_stage()
-                self._geometry(prepared)
+                self._geometry_finish(prepared, gstate)       # ... and has long landed when the host gets here
                 cv_stage(prepared.kinv, prepared.proj)
             else:
                 cv_stage(prepared.kinv, prepared.proj)   # head of the longest chain (cost volume -> mask encoder -> mask decoder -> depth): first
@@ -874,8 +933,13 @@ class MonoRecModel(nn.Module):
         data_dict["cv_module_time"] = plan.host_time[i:i + 1].to(device, non_blocking=True)
 
         if owned is not None:
+            # every launch has copied its descriptor by now: point the plan back at its resident buffers, so that anything that drives
+            # the plan directly afterwards (bench.time_layers, tools/*) cannot write into arenas the caller may already have freed
+            # (ADVICE r4); off the critical path - the device is busy with this keyframe
+            plan.rebind_outputs(None)
             data_dict["cost_volume"] = owned["cost_volume"]
-            data_dict["single_frame_cvs"] = [owned["sfcv"][f] for f in range(nf)]
+            if "sfcv" in owned:
+                data_dict["single_frame_cvs"] = [owned["sfcv"][f] for f in range(nf)]
             data_dict["image_features"] = [owned[f"feat{i}"] for i in range(5)]
             data_dict["cv_mask"] = owned["cv_mask"]
             data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = owned["consts"]
@@ -884,7 +948,8 @@ class MonoRecModel(nn.Module):
             data_dict["mask"] = data_dict["cv_mask"]
             return _Pending(data_dict, done, device, None, owned=True)
         data_dict["cost_volume"] = plan.buf["cost_volume"]
-        data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
+        if not (plan.lean_outputs and plan.b8):               # (lean: the buffer holds raw per-frame costs, not monorec_model.py:251's volumes)
+            data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
         data_dict["image_features"] = list(plan.feats)
         data_dict["cv_mask"] = plan.buf["cv_mask"]
         if self.pretrain_mode == 2:                           # :723-724: mask only
@@ -908,6 +973,8 @@ class MonoRecModel(nn.Module):
         if lay is None:
             lay = {"small": [], "big": [], "size": {"small": 256, "big": 0}}      # the first 256 bytes of the small arena: the constants
             for name in plan.bound:
+                if name == "sfcv" and plan.lean_outputs and plan.b8:
+                    continue                                  # scratch of the cost-volume kernels, not an output: stays in the resident buffer
                 t = plan.buf[name]
                 kind = "small" if (name == "cv_mask" or name.startswith("pred")) else "big"
                 lay[kind].append((name, lay["size"][kind], tuple(t.shape)))

@@ -96,6 +96,28 @@ def cooktoom_1d_stride2(x, w, bias, axis, m):
     return y + bias.view(1, -1, 1, 1) if bias is not None else y
 
 
+def cooktoom_1d_stride2_unified(x, w, bias, axis, m=4):
+    """What the product's stride-2 kernels compute (round 5, csrc/conv1d_wino.hip + engine.Plan._conv_relu2_stride2): the r-tap stride-2
+    correlation as ONE ceil(r/2)-tap stride-1 Cook-Toom form over the channel concatenation [even samples | odd samples] of the input
+    (monorec_amd.cooktoom.stride2_as_stride1: 7 taps -> F(m,4), 5 taps -> F(m,3); the missing tap of the shorter phase is a zero weight), in
+    emulated fp32.  Needs an even input length along the filter axis (every stride-2 layer of the DepthModule has one)."""
+    if axis == 2:
+        return cooktoom_1d_stride2_unified(x.transpose(2, 3), w.transpose(2, 3), bias, 3, m).transpose(2, 3)
+    r, n, c = w.shape[3], x.shape[3], x.shape[1]
+    r2, pad, ev, od = cooktoom.stride2_as_stride1(r, n)
+    xe = torch.cat([x[..., 0::2], x[..., 1::2]], 1)
+    w2 = torch.zeros(w.shape[0], 2 * c, r2, dtype=w.dtype)
+    for t in range(r2):
+        if ev[t] is not None:
+            w2[:, :c, t] = w[:, :, 0, ev[t]]
+        if od[t] is not None:
+            w2[:, c:, t] = w[:, :, 0, od[t]]
+    n_out = n // 2
+    xp = F.pad(xe, [pad, r2 - 1 - pad + m + r2, 0, 0])
+    y = _cooktoom_valid(xp.contiguous(), w2, m)[..., :n_out]
+    return y + bias.view(1, -1, 1, 1) if bias is not None else y
+
+
 def winograd_2d(x, w, bias, m):
     """3x3 stride-1 'same' convolution as F(m x m, 3 x 3) in emulated fp32."""
     r = 3
@@ -135,7 +157,9 @@ class Patched:
             if m is None:
                 return outer.orig(x, w, b, stride)
             kh, kw = w.shape[2], w.shape[3]
-            if tuple(stride) != (1, 1):                          # (2, 1) with a k x 1 filter or (1, 2) with a 1 x k filter
+            if tuple(stride) != (1, 1) and m < 0:                # the unified [even | odd] form the product runs (F(-m, ceil(taps / 2)))
+                y = cooktoom_1d_stride2_unified(x, w, b, 2 if kw == 1 else 3, -m)
+            elif tuple(stride) != (1, 1):                        # (2, 1) with a k x 1 filter or (1, 2) with a 1 x k filter
                 y = cooktoom_1d_stride2(x, w, b, 2 if kw == 1 else 3, m)
             else:
                 y = winograd_2d(x, w, b, m) if (kh, kw) == (3, 3) else winograd_1d(x, w, b, 2 if kw == 1 else 3, m)
@@ -168,6 +192,13 @@ def rules():
             return None
         return rule
 
+    def stride2_unified(m):                                     # what the product runs: the 7- and 5-tap stride-2 layers only (3 taps: no gain)
+        def rule(ws, stride, xs):
+            if (stride == (2, 1) and ws[3] == 1 and ws[2] in (5, 7) and xs[2] % 2 == 0) or (stride == (1, 2) and ws[2] == 1 and ws[3] in (5, 7) and xs[3] % 2 == 0):
+                return -m
+            return None
+        return rule
+
     def both(*rs):
         def rule(ws, stride, xs):
             for r_ in rs:
@@ -187,6 +218,7 @@ def rules():
         "F(4x4,3x3) + F(4,3) + F(2,7) together": both(only(3, 3, 4), only(3, 1, 4), only(1, 3, 4), only(7, 1, 2), only(1, 7, 2)),
         "polyphase F(2,.) stride-2 k x 1 / 1 x k": stride2(2),
         "polyphase F(4,.) stride-2 k x 1 / 1 x k": stride2(4),
+        "unified polyphase F(4,4) / F(4,3) stride-2 7- and 5-tap layers [what the product runs]": stride2_unified(4),
     }
 
 

@@ -41,5 +41,6 @@ int main() {
     run<4, 3>(CT_G_4_3, ct_input_4_3, ct_output_4_3);
     run<2, 7>(CT_G_2_7, ct_input_2_7, ct_output_2_7);
     run<4, 7>(CT_G_4_7, ct_input_4_7, ct_output_4_7);
+    run<4, 4>(CT_G_4_4, ct_input_4_4, ct_output_4_4);
     return 0;
 }

@@ -68,6 +68,49 @@ def test_contiguous_shards_with_an_empty_rank():
         assert count == 1 and max(abs(a - b) for a, b in zip(means, want)) < 1e-12
 
 
+def test_rank_cpu_shares_follow_the_numa_node_of_the_gpu():
+    """distributed.rank_cpu_set: the ranks whose GPUs hang off one NUMA node split that node's CPUs evenly - whole cores (the same slice of
+    both hardware-thread runs) -, the shares of a node's ranks are disjoint and cover it; without NUMA information: contiguous even shares."""
+    n0, n1 = list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))
+    numa = [n0] * 4 + [n1] * 4
+    shares = [mrd.rank_cpu_set(r, 8, allowed=range(256), gpu_numa=numa) for r in range(8)]
+    assert all(len(s) == 32 for s in shares) and sorted(c for s in shares for c in s) == list(range(256))
+    assert shares[0] == list(range(0, 16)) + list(range(128, 144)) and set(shares[5]) <= set(n1)
+    assert mrd.rank_cpu_set(1, 2, allowed=range(8)) == [4, 5, 6, 7] and mrd.rank_cpu_set(0, 1, allowed=range(8)) == list(range(8))
+    assert mrd.rank_cpu_set(3, 4, allowed=[0, 1]) == [0, 1]                      # fewer CPUs than ranks: everything, never nothing
+    assert mrd.rank_cpu_set(1, 2, allowed=range(4), gpu_numa=[[0, 1, 2, 3], None]) == [2, 3]   # unknown node for this rank: the plain split
+    assert mrd.host_thread_budget(32) == (8, 0.004) and mrd.host_thread_budget(3) == (1, 0.0002)
+    info = mrd.place_rank(0, 1)
+    assert info["pinned"] is False                                              # a one-rank job is left alone
+
+
+def _placement_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    before = sorted(os.sched_getaffinity(0))
+    mrd.init_from_env("gloo")
+    q.put((rank, before, sorted(os.sched_getaffinity(0)), torch.get_num_threads()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_init_from_env_pins_every_rank_of_a_multi_rank_job_to_its_share():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_placement_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, before, a0, t0), (_, _, a1, t1) = res
+    if len(before) >= 2:
+        assert a0 and a1 and not (set(a0) & set(a1)) and set(a0) | set(a1) <= set(before)
+        assert t0 <= len(a0) and t1 <= len(a1)
+
+
 def test_single_process_fallback():
     assert mrd.world_info() == (0, 1)
     assert mrd.shard_batches(5) == [0, 1, 2, 3, 4]

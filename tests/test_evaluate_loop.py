@@ -180,3 +180,34 @@ def test_one_rank_rccl_group_runs_the_collective_branch(hip_lib):
     for key in ("metrics", "metrics_correct"):
         for a, b in zip(log[key], single[key]):
             assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (key, a, b)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_branch_with_two_ranks_on_one_device(hip_lib, tmp_path):
+    """The driver launches `bench.py --gpus N` as `python -m torch.distributed.run --nproc-per-node N ...`; the builder's boxes have one GPU,
+    so the N > 1 control flow (rank placement, per-rank keyframe streams, the all-gather of the per-rank summaries inside the timed region,
+    barrier + MAX over ranks, rank 0 prints ONE JSON line) runs here with two ranks sharing cuda:0 over gloo (MR_BENCH_ONE_DEVICE=1): both
+    ranks must be seen, their rates within 10 % of each other (they share one GPU evenly), `value` = their sum, the contract keys present."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MR_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+           "--spinup-seconds", "1.0", "--height", "128", "--width", "256", "--depths", "16", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 40 and d["warmup"] == 5 and d["scaling"] == "weak"
+    r0, r1 = d["per_rank_keyframes_per_s"]
+    assert abs(r0 - r1) <= 0.10 * max(r0, r1), (r0, r1)
+    assert d["value"] <= (r0 + r1) * 1.001 and d["value"] >= 0.85 * (r0 + r1), (d["value"], r0, r1)     # MAX-over-ranks clock: <= the sum of the rates
+    assert d["host_placement"]["local_world_size"] == 2 and "roofline" in d and d["config"]["parallelism"] == "dp2 (independent keyframes per rank)"

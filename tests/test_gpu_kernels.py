@@ -310,7 +310,9 @@ def test_bf16_conv_matches_bf16_rounded_reference(hip_lib, case):
         assert (_act_ref(full, act, p0, p1) - got).abs().max().item() > 1e-4
 
 
-def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch=3, tiled=False):
+def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch=3, tiled=False, entry=None):
+    """entry: None = the exact-order entry points; "relaxed" = mr_cost_volume_relaxed_f32 (the fp32 opt-in, separable window sums);
+    "b8" = mr_cost_volume_b8_f32 (the bf16 configuration's entry point: the same relaxed sums + B8 copies, which are dropped here)."""
     lib = _lib.load()
     kf = batch["keyframe"].to(DEV)
     b, _, h, w = kf.shape
@@ -326,7 +328,17 @@ def _hip_cost_volume(batch, d, use_ssim=1, cv_depths=None, mult_mask=True, patch
     fp = (ctypes.c_void_p * nf)(*[f.data_ptr() for f in frames])
     sp = (ctypes.c_void_p * nf)(*[s.data_ptr() for s in sf])
     cw = (ctypes.c_float * 3)(5 / 32, 16 / 32, 11 / 32)
-    if tiled:
+    if entry == "relaxed":
+        _lib.check(lib.mr_cost_volume_relaxed_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(), b, d, h, w, 10.0, cw,
+                                                  int(use_ssim), None if cv_depths is None else cv_depths.data_ptr(), cv.data_ptr(), sp, _stream()),
+                   "mr_cost_volume_relaxed_f32")
+    elif entry == "b8":
+        sfb = torch.empty(nf * b, d // 8, h, w, 8, dtype=torch.bfloat16, device=DEV)
+        bp = (ctypes.c_void_p * nf)(*[sfb.data_ptr() + f * b * (d // 8) * h * w * 16 for f in range(nf)])
+        _lib.check(lib.mr_cost_volume_b8_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(), b, d, h, w, 10.0, cw,
+                                             int(use_ssim), None if cv_depths is None else cv_depths.data_ptr(), cv.data_ptr(), sp, bp, _stream()),
+                   "mr_cost_volume_b8_f32")
+    elif tiled:
         _lib.check(lib.mr_cost_volume_tiled_f32(kf.data_ptr(), fp, nf, kinv.data_ptr(), proj.data_ptr(), depths.data_ptr(),
                                                 b, d, h, w, 10.0, cw, int(use_ssim),
                                                 None if cv_depths is None else cv_depths.data_ptr(), 1 if mult_mask else 0,
@@ -383,6 +395,59 @@ def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
         assert bad <= 1e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
     bad = ((cv - ocv).abs() > 2e-4).float().mean().item()
     assert bad <= 1e-4, (bad, (cv - ocv).abs().max().item())
+
+
+# Bars of the RELAXED window sums (separable 3x3 sums, x * fp32(1/9)): another rounding of the same nine-term sums, amplified by the SSIM ratio
+# where the variances are tiny.  Measured on the MI355X (tools/sessions/r05_s1.sh) and set to ~2x that; validity may not move at all.
+RELAXED_SFCV_ATOL = 2e-4          # single-frame volumes vs the reference fixture (exact-order kernel: 5e-7)
+RELAXED_SFCV_OUTLIERS = (1e-4, 2e-4)   # (threshold, allowed fraction of entries beyond it)
+RELAXED_CV_OUTLIERS = (2e-4, 3e-3)     # fused volume: the frame weights amplify where they nearly cancel (as between any two summation orders)
+
+
+@pytest.mark.parametrize("entry", ["relaxed", "b8"])
+@pytest.mark.parametrize("case", ["c1_256x512", "d64_f4", "small"])
+def test_relaxed_cost_volume_entry_points_against_the_reference_fixture_and_the_oracle(hip_lib, case, entry):
+    """mr_cost_volume_relaxed_f32 (fp32 opt-in, MonoRecModel(hip_cv_separable=True)) and mr_cost_volume_b8_f32 (what every hip_bf16=True plan
+    calls) had only ever been compared with the exact HIP entry point - HIP against HIP.  Their own oracle legs:
+      1. the committed outputs of the REAL reference (tests/golden): single-frame volumes inside RELAXED_SFCV_ATOL with ZERO validity flips over
+         every stored sample (a zero of the volume = an invalid pixel: the relaxed sums never touch the validity logic);
+      2. the CPU oracle on this host: validity flips within the budget the exact kernel gets (another host CPU moves the oracle itself), outlier
+         fractions inside the stated bars;
+      3. the exact entry point on the same inputs: zeros identical everywhere (no flip at all), values inside the same bars."""
+    import numpy as np
+    g = Golden(case)
+    if entry == "b8" and g.depths not in (32, 48, 64):
+        pytest.skip("mr_cost_volume_b8_f32 writes its B8 copies from the register-resident fusion kernel: 32 / 48 / 64 hypotheses")
+    batch = g.make_inputs()
+    cv, sf = _hip_cost_volume(batch, g.depths, entry=entry)
+    cv_x, sf_x = _hip_cost_volume(batch, g.depths)
+    assert not torch.isnan(cv).any() and not any(torch.isnan(t).any() for t in sf)
+    worst = 0.0
+    for f in range(len(sf)):
+        # 1. reference fixture: values and zeros of the stored samples
+        info = g.compare(f"sfcv{f}", sf[f], atol=RELAXED_SFCV_ATOL)
+        worst = max(worst, info["max_abs"])
+        stride = int(g.z[f"sfcv{f}.stride"])
+        got, want = sf[f].reshape(-1)[::stride].numpy(), g.z[f"sfcv{f}.samples"]
+        assert np.array_equal(got == 0, want == 0), (case, f, int(((got == 0) != (want == 0)).sum()))
+        # 3. the exact entry point: not one validity flip, values within the bars
+        assert torch.equal(sf[f] == 0, sf_x[f] == 0), (case, f)
+        d = (sf[f] - sf_x[f]).abs()
+        assert float(d.max()) <= RELAXED_SFCV_ATOL and float((d > RELAXED_SFCV_OUTLIERS[0]).float().mean()) <= RELAXED_SFCV_OUTLIERS[1], (float(d.max()),)
+    assert torch.equal(cv == 0, cv_x == 0)
+    dcv = (cv - cv_x).abs()
+    assert float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean()) <= RELAXED_CV_OUTLIERS[1], (float(dcv.max()), float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean()))
+    assert any(float((a - b).abs().max()) > 0 for a, b in zip(sf, sf_x)), "the relaxed instantiation did not run"
+    # 2. this host's oracle
+    ocv, osf = orc.cost_volume(batch, steps=g.depths)
+    for f in range(len(sf)):
+        flips = ((sf[f] == 0).all(1) != (osf[f] == 0).all(1)).float().mean().item()
+        assert flips <= 1e-4, (f, flips)
+        bad = ((sf[f] - osf[f]).abs() > 2e-4).float().mean().item()
+        assert bad <= 2e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
+    print(case, entry, "sfcv vs reference fixture max |diff| %.2e; vs exact entry point: sfcv %.2e, cv %.2e (beyond %.0e: %.2e of the entries)" %
+          (worst, max(float((a - b).abs().max()) for a, b in zip(sf, sf_x)), float(dcv.max()), RELAXED_CV_OUTLIERS[0],
+           float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean())))
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 72, 3, 12), (1, 64, 96, 2, 8), (2, 96, 160, 2, 32), (1, 256, 512, 2, 32),
@@ -1072,6 +1137,105 @@ def test_cooktoom_1d_conv_matches_torch_fp32(hip_lib, case, form, axis):
         assert lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, 2, 3, _stream()) == -1        # F(2,3) lives in mr_conv1d3_winograd_f32
         d.cout_blocks_per_wave = 5
         assert lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, m, r, _stream()) == -1
+
+
+# ---- round 5: the stride-2 halves of ConvReLU2 as stride-1 Cook-Toom forms over [even | odd] views (F(4,4) for 7 taps, F(4,3) for 5) -----------
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("case", [((24,), 32, (24, 64), 1, 2), ((5, 11), 40, (13, 20), 3, 1), ((48, 48), 64, (18, 72), 1, 4), ((16,), 48, (9, 40), 2, 3)])
+def test_cooktoom_f44_matches_torch_fp32(hip_lib, case, axis):
+    """mr_conv1d_cooktoom_f32 with the 4-tap form F(4,4) (7 multiplies per 4 outputs): a 1 x 4 / 4 x 1 stride-1 correlation with 1 zero in front
+    and 2 behind along the filter axis (what a 7-tap stride-2 'same' filter becomes over [even | odd] samples), odd numbers of blocks per wave
+    included (their packed U block is padded to whole 1 KiB pieces)."""
+    srcs_c, cout, (h, w), batch, mbw = case
+    lib = hip_lib
+    g = torch.Generator().manual_seed(1300 + sum(srcs_c) + axis)
+    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
+    cin = sum(srcs_c)
+    kk = (1, 4) if axis == 0 else (4, 1)
+    wt = torch.randn(cout, cin, *kk, generator=g) * (1.0 / math.sqrt(4.0 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    xin = F.pad(torch.cat(srcs, 1), (1, 2, 0, 0) if axis == 0 else (0, 0, 1, 2))
+    ref = F.leaky_relu(F.conv2d(xin, wt, bias), 0.1)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    n = lib.mr_cooktoom1d_packed_weight_floats(cout, sc, len(srcs_c), mbw, 4, 4)
+    assert n > 0 and n % 256 == 0
+    packed = torch.empty(n)
+    _lib.check(lib.mr_cooktoom1d_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), mbw, 4, 4, packed.data_ptr()))
+    d = _lib.WinoDesc()
+    dsrcs = [s_.to(DEV) for s_ in srcs]
+    for i, s_ in enumerate(dsrcs):
+        d.src[i], d.src_channels[i] = s_.data_ptr(), srcs_c[i]
+    out = torch.full((batch, cout, h, w), float("nan"), device=DEV)
+    pk, bs = packed.to(DEV), bias.to(DEV)
+    d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
+    d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), None
+    d.activation, d.act_p0, d.cout_blocks_per_wave = ACT_LEAKY_RELU, 0.1, mbw
+    assert 0 < lib.mr_conv1d_cooktoom_lds_bytes(ctypes.byref(d), axis, 4, 4) <= 160 * 1024
+    _lib.check(lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), axis, 4, 4, _stream()), "mr_conv1d_cooktoom_f32")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+    # strided views and the column-split destination are this entry point's alone
+    d.src_row_pitch = 2 * w
+    assert lib.mr_conv1d3_winograd_f32(ctypes.byref(d), axis, _stream()) == -2 and lib.mr_upconv2x2_winograd_f32(ctypes.byref(d), _stream()) == -2
+    d.src_row_pitch, d.dst_split_columns = 0, 1
+    if axis == 0:
+        assert lib.mr_conv1d_cooktoom_f32(ctypes.byref(d), 0, 4, 4, _stream()) == -2            # column split: the k x 1 (axis 1) half only
+
+
+STRIDE2_CASES = [
+    # (cin, cmid, cout, taps, (H, W), batch, (blocks per workgroup of the k x 1 half, of the 1 x k half))
+    (48, 64, 64, 7, (32, 64), 1, (2, 2)),          # depth.enc1.0 in small
+    (64, 128, 128, 5, (16, 32), 2, (4, 1)),        # depth.enc2.0 in small, batch 2
+    (12, 40, 24, 7, (18, 40), 1, (1, 3)),          # ragged channels, odd block counts (padded U stream of F(4,4)), rows that do not fill a tile
+    (128, 192, 192, 5, (8, 16), 1, (3, 2)),        # depth.enc3.0 in small
+    (35, 48, 48, 7, (64, 128), 2, (3, 3)),         # 48 = 3 blocks, a channel count that is no multiple of 8
+]
+
+
+@pytest.mark.parametrize("case", range(len(STRIDE2_CASES)))
+def test_stride2_conv_relu2_pair_on_the_cooktoom_kernel_matches_torch_fp32(hip_lib, monkeypatch, case):
+    """A stride-2 layers.ConvReLU2 (k x 1 stride (2,1) -> LeakyReLU -> 1 x k stride (1,2) -> LeakyReLU, TF-'same' padding; reference
+    model/layers.py:241-252,289-314, DepthModule.enc stages 1-3) through Plan.conv_relu2 with a table entry for its shape: both halves on
+    mr_conv1d_cooktoom_f32 over [even | odd] views (row-strided sources, column-split intermediate) - against the same pair evaluated by
+    F.conv2d on the CPU, and against the plan's own direct-kernel route (table entry 0)."""
+    cin, cmid, cout, k, (h, w), batch, (mby, mbx) = STRIDE2_CASES[case]
+    g = torch.Generator().manual_seed(1500 + case)
+    x = torch.randn(batch, cin, h, w, generator=g)
+    sd = {"p.conv_y.weight": torch.randn(cmid, cin, k, 1, generator=g) / math.sqrt(float(k) * cin), "p.conv_y.bias": torch.randn(cmid, generator=g) * 0.1,
+          "p.conv_x.weight": torch.randn(cout, cmid, 1, k, generator=g) / math.sqrt(float(k) * cmid), "p.conv_x.bias": torch.randn(cout, generator=g) * 0.1}
+    pt, pb = engine.same_pad(h, k, 2)
+    pl, pr = engine.same_pad(w, k, 2)
+    t = F.leaky_relu(F.conv2d(F.pad(x, (0, 0, pt, pb)), sd["p.conv_y.weight"], sd["p.conv_y.bias"], stride=(2, 1)), 0.1)
+    ref = F.leaky_relu(F.conv2d(F.pad(t, (pl, pr, 0, 0)), sd["p.conv_x.weight"], sd["p.conv_x.bias"], stride=(1, 2)), 0.1)
+    assert tuple(ref.shape) == (batch, cout, h // 2, w // 2)
+    sig = engine.stride2_signature(k, cmid, cin, h // 2, w // 2, batch)
+    outs = {}
+    for code in (10 * mby + mbx, 0):
+        monkeypatch.setitem(engine.WINOGRAD, sig, code)
+        plan = engine.Plan.bare(DEV, state=sd)
+        plan.winograd = True
+        xd = x.to(DEV)
+        mid = torch.full((batch, cmid, h // 2, w), float("nan"), device=DEV)
+        out = torch.full((batch, cout, h // 2, w // 2), float("nan"), device=DEV)
+        plan.conv_relu2("main", "t", [xd], "p", mid, out, stride=2)
+        plan.finalize()
+        routed = [bool(c.get("stride2")) for c in plan.conv_log]
+        assert routed == [bool(code), bool(code)], (code, routed)
+        assert [c["ref_macs"] for c in plan.conv_log] == [batch * (h // 2) * w * cmid * cin * k, batch * (h // 2) * (w // 2) * cout * cmid * k]
+        if code:
+            r2 = (k + 1) // 2
+            assert [c["macs"] for c in plan.conv_log] == [batch * (h // 2) * w * cmid * 2 * cin * (3 + r2) // 4, batch * (h // 2) * (w // 2) * cout * 2 * cmid * (3 + r2) // 4]
+        plan.run_stage("main", _stream())
+        torch.cuda.synchronize()
+        outs[code] = out.cpu()
+        assert torch.isfinite(outs[code]).all() and torch.isfinite(mid).all(), code     # every element of the (split) intermediate was written
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((outs[10 * mby + mbx] - ref).abs().max())
+    assert err <= 3e-5 * scale, (err, scale)                              # two chained layers; F(4,4) / F(4,3) per layer: 1e-5
+    assert float((outs[0] - ref).abs().max()) <= 2e-5 * scale
 
 
 def test_plan_routes_layers_to_the_cooktoom_forms(hip_lib, monkeypatch):

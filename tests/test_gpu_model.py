@@ -13,7 +13,8 @@ from oracle import monorec_oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 RESULT_ATOL = 1e-4          # BASELINE.json north_star: depths within 1e-4 abs of the reference CPU output
-BF16_MAX_ERR, BF16_MEAN_ERR = 1e-2, 1e-3   # accuracy bar of the bf16 MFMA mode (hip_bf16=True, BASELINE configs[4]); see DESIGN 4.1b
+BF16_MAX_ERR, BF16_MEAN_ERR = 4e-3, 6e-4   # accuracy bar of the bf16 MFMA mode (hip_bf16=True, BASELINE configs[4]): 2 x what the MI355X measures (2e-3 max /
+                                           # 3e-4 mean against the fp32 CPU output; round 4's self-declared 1e-2 / 1e-3 would have let a 5 x regression pass)
 
 
 def _model(depths, graph, in_flight=1, family="he", **kw):
@@ -110,6 +111,31 @@ def test_c2_config_matches_reference_fixture_and_graph_replay(hip_lib):
         r_g = graphed(_to_dev(batch2))["result"].clone()
         r_e = eager(_to_dev(batch2))["result"].clone()
     assert torch.equal(r_g, r_e)
+
+
+def test_c2_config_with_separable_cost_volume_sums(hip_lib):
+    """MonoRecModel(hip_cv_separable=True): the fp32 path's opt-in - the cost volume through mr_cost_volume_relaxed_f32 (separable
+    3x3 window sums), everything else unchanged.  Against the committed output of the reference at BASELINE configs[1]: the depth stays inside
+    north_star's 1e-4 bar (measured ~2e-6), the mask at its bar; the volumes move by <= 2e-4 (exact-order default: 5e-7) with the validity - the
+    zeros - exactly that of the default plan."""
+    g = Golden("c1_256x512")
+    batch = g.make_inputs()
+    sep, sd = _model(g.depths, graph=False, hip_cv_separable=True)
+    ref_plan, _ = _model(g.depths, graph=False)
+    with torch.no_grad():
+        out = sep(_to_dev(batch))
+        base = ref_plan(_to_dev(batch))
+    torch.cuda.synchronize()
+    info = g.compare("result", out["result"], atol=RESULT_ATOL)
+    print("c2, separable cost-volume sums: result vs reference fixture", info,
+          "vs the default plan %.2e" % (out["result"] - base["result"]).abs().max().item())
+    assert info["max_abs"] <= 2e-5                     # measured ~2e-6: far inside the 1e-4 bar, and pinned well below it
+    g.compare("cv_mask", out["cv_mask"], atol=1e-4)
+    for f in range(g.frames):
+        g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=2e-4)
+        assert torch.equal(out["single_frame_cvs"][f] == 0, base["single_frame_cvs"][f] == 0)       # not one validity flip
+        assert float((out["single_frame_cvs"][f] - base["single_frame_cvs"][f]).abs().max()) > 0    # (the relaxed kernel did run)
+    g.compare("cost_volume", out["cost_volume"], atol=2e-4, max_outlier_frac=3e-3)
 
 
 def test_reference_example_sample_with_metrics(hip_lib):

@@ -11,7 +11,8 @@ from oracle import numerics_study_winograd as study
 def test_every_form_the_table_may_select_keeps_the_depth_far_inside_the_parity_bar():
     report = study.main(["--height", "64", "--width", "128", "--depths", "32"])
     exps = report["experiments"]
-    assert len(exps) == 10 and report["bar"] == 1e-4          # 8 forms the product carries + the two polyphase stride-2 candidates
+    assert len(exps) == 11 and report["bar"] == 1e-4          # 8 forms the product carries + the two polyphase stride-2 candidates of round 4 + the unified
+                                                               # [even | odd] form the round-5 stride-2 kernels run
     for name, e in exps.items():
         assert e["layers"] > 0, name
         assert e["result_max_abs_diff"] <= 2e-6, (name, e["result_max_abs_diff"])          # measured 1.5e-7 .. 2.8e-7: 1/50 of this bound, 1/350 of the bar
@@ -58,3 +59,26 @@ def test_polyphase_stride2_emulation_equals_the_strided_convolution_up_to_roundi
                 for m in (2, 4):
                     got = study.cooktoom_1d_stride2(x, w, b, axis, m)
                     assert got.shape == ref.shape and float((got - ref).abs().max()) <= 2e-5, (h, wd, r, axis, m, float((got - ref).abs().max()))
+
+
+def test_unified_polyphase_emulation_equals_the_strided_convolution_up_to_rounding():
+    """oracle/numerics_study_winograd.cooktoom_1d_stride2_unified - what the round-5 stride-2 kernels compute: the 7- / 5-tap stride-2 halves of
+    ConvReLU2 (reference model/layers.py:241-252,289-314; monorec_model.py:489-501) as ONE 4- / 3-tap stride-1 Cook-Toom form F(4,4) / F(4,3) over
+    the channel concatenation [even samples | odd samples] (monorec_amd.cooktoom.stride2_as_stride1) - against the oracle's strided convolution."""
+    import math
+    import torch
+    from monorec_amd import cooktoom
+    from oracle import monorec_oracle as oracle
+    assert cooktoom.stride2_as_stride1(7, 256) == (4, 1, [0, 2, 4, 6], [1, 3, 5, None])
+    assert cooktoom.stride2_as_stride1(5, 64) == (3, 1, [None, 1, 3], [0, 2, 4])
+    g = torch.Generator().manual_seed(6)
+    for h, wd in ((14, 22), (16, 24)):
+        x = torch.randn(2, 7, h, wd, generator=g)
+        for r in (5, 7):
+            for axis in (2, 3):
+                kk, stride = ((r, 1), (2, 1)) if axis == 2 else ((1, r), (1, 2))
+                w = torch.randn(6, 7, *kk, generator=g) / math.sqrt(7.0 * r)
+                b = torch.randn(6, generator=g)
+                ref = oracle.conv_same(x, w, b, stride)
+                got = study.cooktoom_1d_stride2_unified(x, w, b, axis, 4)
+                assert got.shape == ref.shape and float((got - ref).abs().max()) <= 2e-5, (h, wd, r, axis, float((got - ref).abs().max()))

@@ -758,8 +758,8 @@ def main():
                              "valu_frac_note": "SQ_INSTS_VALU x 64 lanes / sad-kernel time / 78.6e12 lane-instr/s", "counters_source": pmc_src})
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
-        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") != 3)
-        n_wino44 = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") == 3)
+        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") not in (3, 4))
+        n_wino44 = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") in (3, 4))
         n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and c.get("wino_m", 2) == 2 and max(c["k"]) == 3)
         ct_forms = sorted({f"F({c['wino_m']},{c.get('wino_taps') or max(c['k'])})" + (" over [even | odd] (stride 2)" if c.get("stride2") else "")
                            for c in model._plans[plan_key].conv_log
@@ -786,7 +786,7 @@ def main():
         roof = {"bound": "mfma", "kernel": (f"conv_b8_kernel (v_mfma_f32_16x16x32_bf16, channel-blocked bf16 activation storage; {n_b8} of the launches) + "
                                             "conv_mfma_kernel (bf16 operands, fp32 storage: the ResNet encoder)") if args.bf16 else
                 ("conv_mfma_kernel (3 x v_mfma_f32_16x16x16_bf16 on hi/lo splits)" if args.bf16x3 else
-                 f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches)" + (f" + conv3x3_wino44_kernel (F(4x4,3x3), {n_wino44})" if n_wino44 else "") + " + convt4x4_wino[_rb]_kernel "
+                 f"conv_mfma_kernel (direct) + conv3x3_wino[_rb]_kernel (Winograd F(2x2,3x3), {n_wino} of the launches)" + (f" + conv3x3_wino44[s]_kernel (F(4x4,3x3), {n_wino44})" if n_wino44 else "") + " + convt4x4_wino[_rb]_kernel "
                  f"(F(2x2,2x2) for ConvTranspose2d(4,2), {n_wino_t}) + conv1d3_wino_kernel (F(2,3) for 3x1 / 1x3, {n_wino_1d})" + (f" + conv1d_ct_kernel ({' / '.join(ct_forms)} for k x 1 / 1 x k, {n_ct})" if n_ct else "") + f" + upconv2x2_wino_kernel (4-multiply Upconv, {n_wino_u}); all fp32 v_mfma_f32_16x16x4_f32"),
                 "achieved": prim_exec, "peak": peak, "unit": "TFLOP/s", "frac": prim_exec / peak,
                 "frac_source": prim_src,

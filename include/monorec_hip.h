@@ -241,6 +241,16 @@ int mr_wino44_pack_weights_f32(const float* weight, int32_t out_channels, const 
 int64_t mr_conv3x3_winograd44_lds_bytes(const mr_wino_desc* desc);
 int mr_conv3x3_winograd44_f32(const mr_wino_desc* desc, void* stream);
 
+/* The same F(4x4, 3x3) convolution with the 36 positions of a tile split over two waves (csrc/conv_wino44s.hip, round 5): a wave holds the 18
+ * accumulator sets of one half of the vertical transform index and forms a partial output transform; the halves are added through LDS after the K
+ * loop.  8 x 64 output pixels x 32 channels per workgroup, K in chunks of 4 channels, 70.5 KB of LDS and <= 128 registers: TWO workgroups per CU
+ * (mr_conv3x3_winograd44_f32: one, whose load / transform / MFMA phases add up instead of overlapping).  Same products and transformed weights
+ * as that kernel; the output differs by the rounding of a two-term partial sum.  Selected per layer shape by the measured table (code 41). */
+size_t mr_wino44s_packed_weight_floats(int32_t out_channels, const int32_t* src_channels, int32_t num_src);
+int mr_wino44s_pack_weights_f32(const float* weight, int32_t out_channels, const int32_t* src_channels, int32_t num_src, float* dst);
+int64_t mr_conv3x3_winograd44s_lds_bytes(const mr_wino_desc* desc);
+int mr_conv3x3_winograd44s_f32(const mr_wino_desc* desc, void* stream);
+
 /* Exported by the DIAGNOSTIC build only (python -m monorec_amd.build --timeline -> libmonorec_hip_timeline.so, selected with MR_HIP_LIBRARY):
  * bit 0 = the F(2,7) instantiations of mr_conv1d_cooktoom_f32 are present (no measured table entry ever selected them). */
 #ifdef MR_DIAGNOSTIC_LIBRARY
@@ -491,6 +501,7 @@ int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_ea
 #define MR_LAUNCH_COOKTOOM_1D 5
 #define MR_LAUNCH_WINO44  6
 #define MR_LAUNCH_CONV_B8 7
+#define MR_LAUNCH_WINO44S 8
 typedef struct mr_launch_item {
     int32_t kind;
     int32_t arg;

@@ -230,8 +230,8 @@ def winograd_signature(cout, src_channels, h, w, batch):
 def choose_winograd(cout, src_channels, h, w, batch, f2=False):
     """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
     11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), 21 = variant 2 (11 whose 1..16 tail channels
-    come from 16-row workgroups: the 48-channel layers), 31 = F(4x4,3x3) (csrc/conv_wino44.hip; only by the table), for a 3x3 stride-1
-    convolution.  The
+    come from 16-row workgroups: the 48-channel layers), 31 = F(4x4,3x3) (csrc/conv_wino44.hip; only by the table), 41 = F(4x4,3x3) with the
+    positions of a tile split over two waves (csrc/conv_wino44s.hip: two workgroups per CU; only by the table), for a 3x3 stride-1 convolution.  The
     measured table (tools/bench_wino.py --emit, MI355X) wins; shapes it does not know go to the Winograd kernel when it has enough
     workgroups (8 x 32 output pixels each) to fill the chip - below that the direct kernel's smaller tiles and split-K win
     (measured: every ResNet layer of a batch-1 keyframe) - with the variant that measured faster at that width on every shape of
@@ -241,7 +241,7 @@ def choose_winograd(cout, src_channels, h, w, batch, f2=False):
     sig = winograd_signature(cout, src_channels, h, w, batch)
     if sig in WINOGRAD:
         code = WINOGRAD[sig]
-        if f2 and code // 10 == 3:           # F(4x4,3x3) -> the F(2x2,3x3) variant measured before it (else: transform in registers, 32 channels)
+        if f2 and code // 10 in (3, 4):      # F(4x4,3x3), either kernel -> the F(2x2,3x3) variant measured before it (else: transform in registers, 32 channels)
             code = WINOGRAD_F2.get(sig, 11)
         return code
     tiles = math.ceil(h / 8) * math.ceil(w / 32) * batch
@@ -284,8 +284,8 @@ def stride2_signature(taps, cout, cin, out_h, out_w, batch):
 def choose_stride2(taps, cout, cin, out_h, out_w, batch):
     """A ConvReLU2 pair with stride 2 (k x 1 stride (2,1), then 1 x k stride (1,2): DepthModule.enc stages 1-3, monorec_model.py:489-501) on
     the stride-1 Cook-Toom kernel over [even | odd] views of its input (cooktoom.stride2_as_stride1; 7 taps: F(4,4), 5 taps: F(4,3)):
-    10 * (blocks of 16 output channels per workgroup of the k x 1 half) + (the same of the 1 x k half), or 0 = both halves on the direct MFMA
-    kernel.  Only what the measured table says (tools/bench_stride2.py --emit; keys `s2k<taps>_co<cout>_ci<cin>_o<out_h>x<out_w>_b<batch>`)."""
+    10 * (blocks of 16 output channels per workgroup of the k x 1 half) + (the same of the 1 x k half; 0 = that half stays on the direct MFMA
+    kernel), or 0 = both halves on the direct MFMA kernel.  Only what the measured table says (tools/bench_stride2.py --emit; keys `s2k<taps>_co<cout>_ci<cin>_o<out_h>x<out_w>_b<batch>`)."""
     if taps not in (5, 7) or out_w % 4:
         return 0
     return WINOGRAD.get(stride2_signature(taps, cout, cin, out_h, out_w, batch), 0)
@@ -700,7 +700,11 @@ class Plan:
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         sc = (ctypes.c_int32 * len(src_channels))(*src_channels)
         w = weight.detach().to(torch.float32).contiguous().cpu()
-        if variant == 3:       # F(4x4,3x3) (csrc/conv_wino44.hip): 36 positions, 16 x 64 pixels x 32 channels per workgroup
+        if variant == 4:       # F(4x4,3x3) with the positions split over two waves (csrc/conv_wino44s.hip): 8 x 64 pixels x 32 channels, two workgroups per CU
+            nfl = lib.mr_wino44s_packed_weight_floats(cout, sc, len(src_channels))
+            packed = torch.empty(nfl, dtype=torch.float32)
+            _lib.check(lib.mr_wino44s_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44s_pack_weights_f32")
+        elif variant == 3:     # F(4x4,3x3) (csrc/conv_wino44.hip): 36 positions, 16 x 64 pixels x 32 channels per workgroup
             nfl = lib.mr_wino44_packed_weight_floats(cout, sc, len(src_channels))
             packed = torch.empty(nfl, dtype=torch.float32)
             _lib.check(lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44_pack_weights_f32")
@@ -727,15 +731,18 @@ class Plan:
             assert residual.shape == out.shape
             d.residual = residual.data_ptr()
         d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
-        lds = lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) if variant == 3 else lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d))
+        lds = (lib.mr_conv3x3_winograd44s_lds_bytes(ctypes.byref(d)) if variant == 4 else
+               lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) if variant == 3 else lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d)))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} winograd")
         ref = n * hs * ws * cout * cin * 9
-        if variant == 3:
+        if variant == 4:
+            wgs = math.ceil(hs / 8) * math.ceil(ws / 64) * n * math.ceil(cout / 32)
+        elif variant == 3:
             wgs = math.ceil(hs / 16) * math.ceil(ws / 64) * n * math.ceil(cout / 32)
         else:
             wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (32 * mbw))
-        self.conv_log.append(dict(name=name, macs=ref // 4 if variant == 3 else ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=ref // 4 if variant in (3, 4) else ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=4 if variant == 4 else 8, waves=8, kws=0, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(3, 3), out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=variant, bf16=0,
                                   sig=winograd_signature(cout, src_channels, hs, ws, n),
                                   spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 3, 3), stride=(1, 1), pad=(1, 1),
@@ -743,7 +750,11 @@ class Plan:
                                             out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
         self.keep += [d, out, residual] + list(srcs)
 
-        if variant == 3:
+        if variant == 4:
+            def run(stream):
+                _lib.check(lib.mr_conv3x3_winograd44s_f32(ctypes.byref(d), stream), name)
+            run.native = (_lib.LAUNCH_WINO44S, d, 0)
+        elif variant == 3:
             def run(stream):
                 _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), stream), name)
             run.native = (_lib.LAUNCH_WINO44, d, 0)
@@ -817,7 +828,8 @@ class Plan:
                                   lds=int(lds), cout=cout, cin=cin, k=kk if ref_k is None else ref_k, out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=0,
                                   wino_axis=axis, wino_m=m, wino_taps=taps, stride2=ref_k is not None, bf16=0,
                                   sig=sig or (("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_" + winograd_signature(cout, src_channels, hs, ws, n)),
-                                  spec=dict(src_shapes=[(n, c_, hs, ws) for c_ in src_channels], w_shape=(cout, cin) + kk, stride=(1, 1), pad=(kk[0] // 2, kk[1] // 2),
+                                  spec=dict(src_shapes=[(n, c_, hs, ws) for c_ in src_channels], w_shape=(cout, cin) + kk,
+                                            stride=(1, 1) if ref_k is None else ((2, 1) if axis == 1 else (1, 2)), pad=(kk[0] // 2, kk[1] // 2),
                                             grid=(hs, ws), in_mode=IN_DIRECT, tf=TF_NONE, act=act, p0=p0, p1=0.0, residual=False,
                                             out_shape=tuple(out.shape), out_step=(1, 1), out_off=(0, 0), phases=None)))
         self.keep += [d, out] + list(srcs)
@@ -883,8 +895,14 @@ class Plan:
         sig = stride2_signature(k, cm, c, h2, w2, n)
         mid2 = mid.view(2, n, cm, h2, w2)
         uy = stride2_unified_weights(wy.detach().float().cpu(), hs, axis=1)
-        self._conv_winograd_1d(stage, name + ".conv_y", [x], uy, by, mid2, ACT_LEAKY_RELU, LEAKY_SLOPE, 1, mbw_y, 4,
-                               view=dict(ptrs=[x.data_ptr(), x.data_ptr() + ws * 4], channels=[c, c], batch=n, height=h2, width=ws, row_pitch=2 * ws, plane=hs * ws),
+        view = dict(ptrs=[x.data_ptr(), x.data_ptr() + ws * 4], channels=[c, c], batch=n, height=h2, width=ws, row_pitch=2 * ws, plane=hs * ws)
+        if mbw_x == 0:
+            # only the k x 1 half on the Cook-Toom kernel (dense intermediate); the 1 x k half stays on the direct MFMA kernel with its tuned schedule -
+            # what the table picks where the small x half is a latency chain (c2 depth.enc2.0: 17.9 + 22.4 us against 23.3 + 22.4)
+            self._conv_winograd_1d(stage, name + ".conv_y", [x], uy, by, mid, ACT_LEAKY_RELU, LEAKY_SLOPE, 1, mbw_y, 4, view=view,
+                                   ref_macs=n * h2 * ws * cm * c * k, ref_k=(k, 1), sig=sig + "_y")
+            return self.same_conv(stage, name + ".conv_x", [mid], prefix + ".conv_x.weight", prefix + ".conv_x.bias", out, stride=(1, 2))
+        self._conv_winograd_1d(stage, name + ".conv_y", [x], uy, by, mid2, ACT_LEAKY_RELU, LEAKY_SLOPE, 1, mbw_y, 4, view=view,
                                dst_split=True, ref_macs=n * h2 * ws * cm * c * k, ref_k=(k, 1), sig=sig + "_y")
         ux = stride2_unified_weights(wx.detach().float().cpu(), ws, axis=0)
         return self._conv_winograd_1d(stage, name + ".conv_x", [mid2[0], mid2[1]], ux, bx, out, ACT_LEAKY_RELU, LEAKY_SLOPE, 0, mbw_x, 4,

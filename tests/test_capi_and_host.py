@@ -351,9 +351,12 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert all(c["macs"] * 16 == c["ref_macs"] * 9 and c["lds"] <= 160 * 1024 and c["sig"].startswith("t_") for c in wino_t)
     # ... and twelve of the sixteen 3 x 1 / 1 x 3 stride-1 layers of the depth net plus the two 7-tap layers of enc.0.0 on the 1-D kernels
     # (csrc/conv1d_wino.hip): F(2,3) at 4/6, or the Cook-Toom form F(m, r) the table names at (m + r - 1) / (m r)
-    wino_1d = [c for c in plan.conv_log if c.get("winograd") and min(c["k"]) == 1]
+    wino_1d = [c for c in plan.conv_log if c.get("winograd") and min(c["k"]) == 1 and not c.get("stride2")]
     assert {c["name"] for c in wino_1d} == ({f"depth.{s}.conv_{a}" for s in ("enc0.1", "enc1.1", "enc2.1", "dec1.1", "dec2.1", "dec4.0") for a in "yx"} |
                                             {"depth.enc0.0.conv_y", "depth.enc0.0.conv_x"})
+    # ... and (round 5) the 7-tap stride-2 pair of enc.1.0 as F(4,4) over [even | odd] views: 3.5 of 7 multiplies per output and input channel
+    s2 = [c for c in plan.conv_log if c.get("stride2")]
+    assert [c["name"] for c in s2] == ["depth.enc1.0.conv_y", "depth.enc1.0.conv_x"] and all(c["macs"] * 2 == c["ref_macs"] and c["lds"] <= 160 * 1024 for c in s2)
     for c in wino_1d:
         m_, r_ = c.get("wino_m", 2), max(c["k"])
         assert (m_, r_) in ((2, 3), (4, 3), (4, 7)) and c["macs"] == c["ref_macs"] * (m_ + r_ - 1) // (m_ * r_) and c["lds"] <= 160 * 1024
@@ -363,7 +366,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     # phase-decomposed at 9/16
     wino_u = [c for c in plan.conv_log if c.get("upconv")]
     assert {c["name"] for c in wino_u} == {"mask.dec2.0", "mask.dec3.0"} and all(c["macs"] * 4 == c["ref_macs"] and c["sig"].startswith("u_") for c in wino_u)
-    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t + wino_1d + wino_u)
+    wino_saved = sum(c["ref_macs"] - c["macs"] for c in wino + wino_t + wino_1d + wino_u + s2)
     upconv_phased = sum(c["ref_macs"] for c in plan.conv_log if c["name"] in ("mask.dec0.0", "mask.dec1.0")) / 1e9       # 0.579 of the 3.934 GMAC
     assert abs((plan.conv_macs() + aux + wino_saved) / 1e9 - (61.07 - upconv_phased * 7 / 16)) < 0.01
     direct = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", winograd=False)               # A/B aid: every 3x3 layer on the direct kernel
@@ -374,7 +377,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log if not c.get("winograd"))
-    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 14 + 2
+    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 14 + 2 + 2
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
@@ -846,7 +849,8 @@ def test_f2_table_documents_its_coverage():
     """`hip_exact_convs="f2"`: tuned_winograd_f2.json holds MEASURED F(2,.) choices only for the c2 / c3 keys whose
     main-table entry is a larger form; every other such key falls back to a rule (variant 11 for a 3x3 layer, the direct kernel for a 1-D
     layer) whose throughput is unmeasured - the documentation says so with these counts, and the fallback itself is pinned here."""
-    larger = [k for k, v in engine.WINOGRAD.items() if v >= 40 or v // 10 == 3]
+    # (the `s2k` keys - stride-2 pairs, round 5 - are not part of this: under "f2" / "direct" those layers simply stay on the direct kernel)
+    larger = [k for k, v in engine.WINOGRAD.items() if (v >= 40 or v // 10 == 3) and not k.startswith("s2k")]
     covered = [k for k in larger if k in engine.WINOGRAD_F2]
     assert set(engine.WINOGRAD_F2) <= set(larger)
     assert all(k.endswith("_b1") or k.endswith("_b8") for k in covered)                  # the c2 / c3 keys
@@ -988,7 +992,7 @@ def test_cooktoom_weight_packing_and_plan_routing(hip_lib, monkeypatch):
         axis = 0 if c["k"][0] == 1 else 1
         monkeypatch.setitem(engine.WINOGRAD, ("x7_", "y7_")[axis] + engine.winograd_signature(c["cout"], [s_[1] for s_ in c["spec"]["src_shapes"]], 256, 512, 1), code)
     plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
-    routed = {c["name"]: c for c in plan.conv_log if max(c["k"]) == 7 and c.get("winograd")}
+    routed = {c["name"]: c for c in plan.conv_log if max(c["k"]) == 7 and c.get("winograd") and not c.get("stride2")}     # (stride-2 enc.1.0: its own test)
     assert set(routed) == {"depth.enc0.0.conv_y", "depth.enc0.0.conv_x"}
     cy, cx = routed["depth.enc0.0.conv_y"], routed["depth.enc0.0.conv_x"]
     assert cy["wino_m"] == 4 and cy["macs"] * 28 == cy["ref_macs"] * 10 and cy["sig"].startswith("y7_") and 0 < cy["lds"] <= 160 * 1024
@@ -1104,6 +1108,46 @@ def _check_host_geometry_against_the_reference_form():
         k = torch.tensor([[[489.23, 0, 248.31, 0], [0, 489.23, 126.69, 0], [0, 0, 1, 0], [0, 0, 0, 1]]])
         a = (k, poses[0], [k, k], poses[1:])
         assert all(torch.equal(x, y) for x, y in zip(host_geometry(*a), host_geometry_reference_form(*a))), trial
+
+
+def test_winograd44s_weight_packing_holds_the_same_transformed_filters(hip_lib):
+    """mr_wino44s_pack_weights_f32 (csrc/conv_wino44s.hip: F(4x4,3x3) with the positions of a tile split over two waves): the same U = G g G^T values
+    as mr_wino44_pack_weights_f32, re-ordered [group of 32 couts][chunk of 4 channels, source-major][block of 16][position half][row ii of the
+    half][column half jh][64 lanes][4] with position p = 6 (3 half + ii) + 4 jh + e (zero pads for 4 jh + e >= 6)."""
+    from monorec_amd import cooktoom
+    g = torch.Generator().manual_seed(14)
+    srcs_c, cout = [6, 9], 40
+    cin = sum(srcs_c)
+    sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
+    cp4 = [(c + 3) // 4 * 4 for c in srcs_c]
+    groups = (cout + 31) // 32
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    n = hip_lib.mr_wino44s_packed_weight_floats(cout, sc, len(srcs_c))
+    assert n == groups * (sum(cp4) // 4) * 6144
+    packed = torch.full((n,), float("nan"))
+    _lib.check(hip_lib.mr_wino44s_pack_weights_f32(w.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
+    st = packed.numpy().reshape(groups, sum(cp4) // 4, 2, 2, 3, 2, 64, 4)        # [g][chunk][block][half][ii][jh][lane][e]
+    G = np.array([[float(v) for v in row] for row in cooktoom.cook_toom(4, 3)[1]])
+    want = np.einsum("pi,ocij,qj->pqoc", G, w.double().numpy(), G)               # U[pi][pj][cout][cin]
+    assert not np.isnan(st).any()
+    off, cin_off = 0, 0
+    for c, cp in zip(srcs_c, cp4):
+        for cl in range(cp):
+            q, hi = (off + cl) // 4, (off + cl) % 4
+            for co in range(groups * 32):
+                lane = hi * 16 + co % 16
+                for hf in range(2):
+                    for ii in range(3):
+                        for jh in range(2):
+                            for e in range(4):
+                                pj = 4 * jh + e
+                                got = st[co // 32, q, (co // 16) % 2, hf, ii, jh, lane, e]
+                                exp = want[3 * hf + ii, pj, co, cin_off + cl] if (pj < 6 and co < cout and cl < c) else 0.0
+                                assert abs(got - exp) <= 2e-7 * max(1.0, abs(exp)), (co, cl, hf, ii, pj)
+        off, cin_off = off + cp, cin_off + c
+    assert hip_lib.mr_wino44s_packed_weight_floats(0, sc, len(srcs_c)) == 0
+    d = _lib.WinoDesc()
+    assert hip_lib.mr_conv3x3_winograd44s_lds_bytes(ctypes.byref(d)) == -1 and hip_lib.mr_conv3x3_winograd44s_f32(ctypes.byref(d), None) == -1
 
 
 def test_host_geometry_shortcuts_are_bit_identical_to_the_reference_form():

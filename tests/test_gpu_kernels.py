@@ -399,9 +399,16 @@ def test_cost_volume_matches_oracle_and_reference_fixture(hip_lib, case):
 
 # Bars of the RELAXED window sums (separable 3x3 sums, x * fp32(1/9)): another rounding of the same nine-term sums, amplified by the SSIM ratio
 # where the variances are tiny.  Measured on the MI355X (tools/sessions/r05_s1.sh) and set to ~2x that; validity may not move at all.
-RELAXED_SFCV_ATOL = 2e-4          # single-frame volumes vs the reference fixture (exact-order kernel: 5e-7)
-RELAXED_SFCV_OUTLIERS = (1e-4, 2e-4)   # (threshold, allowed fraction of entries beyond it)
-RELAXED_CV_OUTLIERS = (2e-4, 3e-3)     # fused volume: the frame weights amplify where they nearly cancel (as between any two summation orders)
+RELAXED_SFCV_ATOL = 1e-4          # single-frame volumes vs the reference fixture and vs the exact-order kernel (which is 5e-7 from the reference);
+                                  # measured (r05_s1): 3.2e-5 / 3.7e-5 vs the fixture, 4.5e-5 / 4.0e-5 vs the exact kernel (d64_f4 / small)
+RELAXED_CV_OUTLIERS = (1e-4, 1e-3)     # fused volume: (threshold, allowed fraction of entries beyond it) - the frame weights amplify where they nearly
+RELAXED_CV_MAX = 5e-3                  # cancel (as between any two summation orders); measured max 7.3e-5 / 8.1e-5, nothing beyond 1e-4
+
+
+def _validity(vol):
+    """The all-depth validity map of a single-frame volume (monorec_model.py:219,251): a pixel is invalid iff every depth plane is exactly 0.  (A
+    single plane of a VALID pixel may also be exactly 0 - sad = 0.5 - in one summation order and +-1e-7 in another: that is a value, not a flip.)"""
+    return (vol == 0).all(1)
 
 
 @pytest.mark.parametrize("entry", ["relaxed", "b8"])
@@ -427,16 +434,19 @@ def test_relaxed_cost_volume_entry_points_against_the_reference_fixture_and_the_
         # 1. reference fixture: values and zeros of the stored samples
         info = g.compare(f"sfcv{f}", sf[f], atol=RELAXED_SFCV_ATOL)
         worst = max(worst, info["max_abs"])
+        # a validity flip in the stored samples would show as a zero against a value of O(0.1 - 1): any zero / non-zero mismatch must be a tiny value
         stride = int(g.z[f"sfcv{f}.stride"])
         got, want = sf[f].reshape(-1)[::stride].numpy(), g.z[f"sfcv{f}.samples"]
-        assert np.array_equal(got == 0, want == 0), (case, f, int(((got == 0) != (want == 0)).sum()))
-        # 3. the exact entry point: not one validity flip, values within the bars
-        assert torch.equal(sf[f] == 0, sf_x[f] == 0), (case, f)
+        mism = (got == 0) != (want == 0)
+        assert not (mism & (np.maximum(np.abs(got), np.abs(want)) > 1e-5)).any(), (case, f, int(mism.sum()))
+        # 3. the exact entry point: not one validity flip over the whole map, values within the bar
+        assert torch.equal(_validity(sf[f]), _validity(sf_x[f])), (case, f)
         d = (sf[f] - sf_x[f]).abs()
-        assert float(d.max()) <= RELAXED_SFCV_ATOL and float((d > RELAXED_SFCV_OUTLIERS[0]).float().mean()) <= RELAXED_SFCV_OUTLIERS[1], (float(d.max()),)
-    assert torch.equal(cv == 0, cv_x == 0)
+        assert float(d.max()) <= RELAXED_SFCV_ATOL, (float(d.max()),)
+    assert torch.equal(_validity(cv), _validity(cv_x))
     dcv = (cv - cv_x).abs()
-    assert float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean()) <= RELAXED_CV_OUTLIERS[1], (float(dcv.max()), float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean()))
+    assert float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean()) <= RELAXED_CV_OUTLIERS[1] and float(dcv.max()) <= RELAXED_CV_MAX, \
+        (float(dcv.max()), float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean()))
     assert any(float((a - b).abs().max()) > 0 for a, b in zip(sf, sf_x)), "the relaxed instantiation did not run"
     # 2. this host's oracle
     ocv, osf = orc.cost_volume(batch, steps=g.depths)
@@ -444,7 +454,7 @@ def test_relaxed_cost_volume_entry_points_against_the_reference_fixture_and_the_
         flips = ((sf[f] == 0).all(1) != (osf[f] == 0).all(1)).float().mean().item()
         assert flips <= 1e-4, (f, flips)
         bad = ((sf[f] - osf[f]).abs() > 2e-4).float().mean().item()
-        assert bad <= 2e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
+        assert bad <= 1e-4, (f, bad, (sf[f] - osf[f]).abs().max().item())
     print(case, entry, "sfcv vs reference fixture max |diff| %.2e; vs exact entry point: sfcv %.2e, cv %.2e (beyond %.0e: %.2e of the entries)" %
           (worst, max(float((a - b).abs().max()) for a, b in zip(sf, sf_x)), float(dcv.max()), RELAXED_CV_OUTLIERS[0],
            float((dcv > RELAXED_CV_OUTLIERS[0]).float().mean())))
@@ -931,13 +941,19 @@ WINO44_EXTRA_CASES = [((32,), 32, (64, 128), 2, ACT_LEAKY_RELU, False, 1),      
                       ((48,), 48, (40, 192), 1, ACT_LEAKY_RELU, False, 1)]        # 48 = 32 + 16: the second group's upper block is empty; H % 16 != 0
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("case", range(len(WINO_CASES) + len(WINO44_EXTRA_CASES)))
-def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
-    """mr_conv3x3_winograd44_f32 (F(4x4,3x3), csrc/conv_wino44.hip) against F.conv2d(padding=1) on the CPU.  Its transforms have coefficients up
-    to 8, so it rounds more than F(2x2,3x3): the fp32 emulation of the form (oracle/numerics_study_winograd.py) is within 9e-6 of the fp64
-    result on these cases (F(2x2,3x3): 6e-7); bar 4e-5 of the output scale - model level: depth moves by 2.4e-7."""
+def test_winograd44_conv_matches_torch_fp32(hip_lib, case, split):
+    """mr_conv3x3_winograd44_f32 (F(4x4,3x3), csrc/conv_wino44.hip) - and, `split`, mr_conv3x3_winograd44s_f32 (csrc/conv_wino44s.hip, round 5: the
+    36 positions of a tile over two waves, partial output transforms added through LDS, two workgroups per CU) - against F.conv2d(padding=1) on the
+    CPU.  The transforms have coefficients up to 8, so the form rounds more than F(2x2,3x3): its fp32 emulation (oracle/numerics_study_winograd.py)
+    is within 9e-6 of the fp64 result on these cases (F(2x2,3x3): 6e-7); bar 4e-5 of the output scale - model level: depth moves by 2.4e-7."""
     srcs_c, cout, (h, w), batch, act, residual, _ = (WINO_CASES + WINO44_EXTRA_CASES)[case]
     lib = hip_lib
+    size_fn, pack_fn, lds_fn, run_fn, lds_cap = ((lib.mr_wino44s_packed_weight_floats, lib.mr_wino44s_pack_weights_f32, lib.mr_conv3x3_winograd44s_lds_bytes,
+                                                  lib.mr_conv3x3_winograd44s_f32, 80 * 1024) if split else
+                                                 (lib.mr_wino44_packed_weight_floats, lib.mr_wino44_pack_weights_f32, lib.mr_conv3x3_winograd44_lds_bytes,
+                                                  lib.mr_conv3x3_winograd44_f32, 160 * 1024))
     g = torch.Generator().manual_seed(100 + case)
     srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
     cin = sum(srcs_c)
@@ -949,9 +965,9 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
         ref = ref + res
     ref = _act_ref(ref, act, 0.1, 0.0)
     sc = (ctypes.c_int32 * len(srcs_c))(*srcs_c)
-    n = lib.mr_wino44_packed_weight_floats(cout, sc, len(srcs_c))
+    n = size_fn(cout, sc, len(srcs_c))
     packed = torch.empty(n)
-    _lib.check(lib.mr_wino44_pack_weights_f32(wt.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
+    _lib.check(pack_fn(wt.data_ptr(), cout, sc, len(srcs_c), packed.data_ptr()))
     d = _lib.WinoDesc()
     dsrcs = [s.to(DEV) for s in srcs]
     for i, s in enumerate(dsrcs):
@@ -960,9 +976,9 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
     pk, bs, rs = packed.to(DEV), bias.to(DEV), (res.to(DEV) if residual else None)
     d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
     d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), (rs.data_ptr() if residual else None)
-    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, 1, 3
-    assert 0 < lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) <= 160 * 1024
-    _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()), "mr_conv3x3_winograd44_f32")
+    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, 1, 4 if split else 3
+    assert 0 < lds_fn(ctypes.byref(d)) <= lds_cap                  # (split: two workgroups per CU)
+    _lib.check(run_fn(ctypes.byref(d), _stream()), "mr_conv3x3_winograd44[s]_f32")
     torch.cuda.synchronize()
     got = out.cpu()
     assert torch.isfinite(got).all()
@@ -970,15 +986,15 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case):
     assert err <= 4e-5 * max(1.0, float(ref.abs().max())), err
     if case == 0:
         d.width = 98
-        assert lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()) == -2            # width % 4: unsupported
+        assert run_fn(ctypes.byref(d), _stream()) == -2            # width % 4: unsupported
         d.width, d.packed_weights = w, None
-        assert lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()) == -1
+        assert run_fn(ctypes.byref(d), _stream()) == -1
 
 
 def test_plan_routes_3x3_layers_to_the_f44_kernel(hip_lib, monkeypatch):
     """Table code 31 sends a 3x3 stride-1 layer to mr_conv3x3_winograd44_f32 (through the native launch list as well); the executed
     multiply-adds are a quarter of the reference's."""
-    codes = (0, 21, 31)
+    codes = (0, 21, 31, 41)                                    # 41: F(4x4,3x3) with the positions split over two waves (csrc/conv_wino44s.hip)
     g = torch.Generator().manual_seed(80)
     xs = [torch.randn(2, 16, 32, 128, generator=g), torch.randn(2, 24, 32, 128, generator=g)]
     wt = torch.randn(48, 40, 3, 3, generator=g) * (1.0 / (3.0 * math.sqrt(40.0)))
@@ -996,6 +1012,8 @@ def test_plan_routes_3x3_layers_to_the_f44_kernel(hip_lib, monkeypatch):
         assert bool(log.get("winograd")) == bool(code) and log["ref_macs"] == 2 * 32 * 128 * 48 * 40 * 9
         if code == 31:
             assert log["wino_variant"] == 3 and log["macs"] * 4 == log["ref_macs"] and log["wgs"] == 2 * 2 * 2 * 2
+        if code == 41:
+            assert log["wino_variant"] == 4 and log["macs"] * 4 == log["ref_macs"] and log["wgs"] == 4 * 2 * 2 * 2 and log["lds"] <= 80 * 1024
         plan.run_stage("main", _stream())
         torch.cuda.synchronize()
         assert float((out.cpu() - ref).abs().max()) <= 4e-5 * max(1.0, float(ref.abs().max())), code
@@ -1213,7 +1231,7 @@ def test_stride2_conv_relu2_pair_on_the_cooktoom_kernel_matches_torch_fp32(hip_l
     assert tuple(ref.shape) == (batch, cout, h // 2, w // 2)
     sig = engine.stride2_signature(k, cmid, cin, h // 2, w // 2, batch)
     outs = {}
-    for code in (10 * mby + mbx, 0):
+    for code in (10 * mby + mbx, 10 * mby, 0):                 # both halves; only the k x 1 half (dense intermediate, 1 x k half direct); neither
         monkeypatch.setitem(engine.WINOGRAD, sig, code)
         plan = engine.Plan.bare(DEV, state=sd)
         plan.winograd = True
@@ -1223,9 +1241,9 @@ def test_stride2_conv_relu2_pair_on_the_cooktoom_kernel_matches_torch_fp32(hip_l
         plan.conv_relu2("main", "t", [xd], "p", mid, out, stride=2)
         plan.finalize()
         routed = [bool(c.get("stride2")) for c in plan.conv_log]
-        assert routed == [bool(code), bool(code)], (code, routed)
+        assert routed == [bool(code), bool(code % 10)], (code, routed)
         assert [c["ref_macs"] for c in plan.conv_log] == [batch * (h // 2) * w * cmid * cin * k, batch * (h // 2) * (w // 2) * cout * cmid * k]
-        if code:
+        if code % 10:
             r2 = (k + 1) // 2
             assert [c["macs"] for c in plan.conv_log] == [batch * (h // 2) * w * cmid * 2 * cin * (3 + r2) // 4, batch * (h // 2) * (w // 2) * cout * 2 * cmid * (3 + r2) // 4]
         plan.run_stage("main", _stream())
@@ -1235,7 +1253,7 @@ def test_stride2_conv_relu2_pair_on_the_cooktoom_kernel_matches_torch_fp32(hip_l
     scale = max(1.0, float(ref.abs().max()))
     err = float((outs[10 * mby + mbx] - ref).abs().max())
     assert err <= 3e-5 * scale, (err, scale)                              # two chained layers; F(4,4) / F(4,3) per layer: 1e-5
-    assert float((outs[0] - ref).abs().max()) <= 2e-5 * scale
+    assert float((outs[10 * mby] - ref).abs().max()) <= 3e-5 * scale and float((outs[0] - ref).abs().max()) <= 2e-5 * scale
 
 
 def test_plan_routes_layers_to_the_cooktoom_forms(hip_lib, monkeypatch):

@@ -129,13 +129,13 @@ def test_c2_config_with_separable_cost_volume_sums(hip_lib):
     info = g.compare("result", out["result"], atol=RESULT_ATOL)
     print("c2, separable cost-volume sums: result vs reference fixture", info,
           "vs the default plan %.2e" % (out["result"] - base["result"]).abs().max().item())
-    assert info["max_abs"] <= 2e-5                     # measured ~2e-6: far inside the 1e-4 bar, and pinned well below it
+    assert info["max_abs"] <= 5e-6                     # measured 1.4e-6 (the default plan: 1.3e-6): far inside the 1e-4 bar, and pinned well below it
     g.compare("cv_mask", out["cv_mask"], atol=1e-4)
     for f in range(g.frames):
-        g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=2e-4)
-        assert torch.equal(out["single_frame_cvs"][f] == 0, base["single_frame_cvs"][f] == 0)       # not one validity flip
+        g.compare(f"sfcv{f}", out["single_frame_cvs"][f], atol=1e-4)
+        assert torch.equal((out["single_frame_cvs"][f] == 0).all(1), (base["single_frame_cvs"][f] == 0).all(1))   # not one validity flip (all-depth zero = invalid)
         assert float((out["single_frame_cvs"][f] - base["single_frame_cvs"][f]).abs().max()) > 0    # (the relaxed kernel did run)
-    g.compare("cost_volume", out["cost_volume"], atol=2e-4, max_outlier_frac=3e-3)
+    g.compare("cost_volume", out["cost_volume"], atol=2e-4, max_outlier_frac=1e-3)
 
 
 def test_reference_example_sample_with_metrics(hip_lib):

@@ -40,7 +40,11 @@ def timed(fn, iters=50):
 def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, variant=0):
     sc = [int(s.shape[1]) for s in srcs]
     arr = (ctypes.c_int32 * len(sc))(*sc)
-    if variant == 3:                                   # F(4x4,3x3): csrc/conv_wino44.hip
+    if variant == 4:                                   # F(4x4,3x3), positions split over two waves: csrc/conv_wino44s.hip
+        n = lib.mr_wino44s_packed_weight_floats(weight.shape[0], arr, len(sc))
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(lib.mr_wino44s_pack_weights_f32(weight.contiguous().data_ptr(), weight.shape[0], arr, len(sc), packed.data_ptr()), "pack")
+    elif variant == 3:                                 # F(4x4,3x3): csrc/conv_wino44.hip
         n = lib.mr_wino44_packed_weight_floats(weight.shape[0], arr, len(sc))
         packed = torch.empty(n, dtype=torch.float32)
         _lib.check(lib.mr_wino44_pack_weights_f32(weight.contiguous().data_ptr(), weight.shape[0], arr, len(sc), packed.data_ptr()), "pack")
@@ -62,12 +66,14 @@ def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, varia
     d.residual = residual.data_ptr() if residual is not None else None
     d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
     keep = (pk, bs, d)
+    if variant == 4:
+        return (lambda stream: _lib.check(lib.mr_conv3x3_winograd44s_f32(ctypes.byref(d), stream), "wino44s")), keep
     if variant == 3:
         return (lambda stream: _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), stream), "wino44")), keep
     return (lambda stream: _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), "wino")), keep
 
 
-CODES = (1, 2, 11, 12, 21, 31)
+CODES = (1, 2, 11, 12, 21, 31, 41)
 
 
 def main():
@@ -78,11 +84,13 @@ def main():
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--depths", type=int, default=32)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--codes", default=None, help="comma-separated subset of the kernel codes to time (default: all)")
     ap.add_argument("--min-pixels", type=int, default=0, help="skip layers with fewer output pixels per image (a quick pass over the big layers)")
     ap.add_argument("--emit", default=None, help="write {signature: 0 | 1 | 2 | 11 | 12} (fastest kernel per layer; Winograd must win by 3 %%; + 10 = input "
                                                  "transform in registers) to this JSON file; entries already in the file for other shapes are kept")
     a = ap.parse_args()
     lib = _lib.load()
+    codes = CODES if a.codes is None else tuple(int(c) for c in a.codes.split(","))
     m = MonoRecModel(cv_depth_steps=a.depths)
     sd = synth.seeded_state_dict(m.state_dict(), seed=0)
     ref_plan = engine.Plan(sd, a.batch, a.height, a.width, a.frames, a.depths, (0.33, 0.0025), "cpu", winograd=False)
@@ -109,7 +117,7 @@ def main():
         direct = plan.stages["main"][0][1]
         row = {"name": c["name"], "cin": cin, "cout": cout, "hw": list(sp["grid"]), "n": sp["out_shape"][0], "sched": [c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"]],
                "direct_us": round(timed(direct), 1)}
-        for code in CODES:                   # cout blocks per wave, + 10: input transform in registers, + 20: ... with tail workgroups, 31: F(4x4,3x3)
+        for code in codes:                   # cout blocks per wave, + 10: input transform in registers, + 20: ... with tail workgroups, 31: F(4x4,3x3), 41: F(4x4,3x3) split over two waves
             mbw, variant = code % 10, code // 10
             if mbw == 2 and cout <= 32:
                 continue

@@ -707,8 +707,12 @@ class MonoRecModel(nn.Module):
         return self._geometry_finish(prep, self._geometry_begin(prep))
 
     def _device_idle(self):
-        """No forward of this model is in flight on any slot (every completion event the host has not collected yet has happened)."""
-        return all(ev.query() for plan in self._plans.values() for ev in plan.enqueued)
+        """No forward of this model is in flight as far as the HOST already knows: every forward it enqueued has been waited for on the host
+        (`handle.synchronize()`, or the run-ahead wait of a later submit on the same slot).  Deliberately NOT a query of the completion events:
+        r05_s2 measured that polling the events of the OTHER slot's running keyframe from prepare() costs 6 % of the two-in-flight rate (701-710
+        against 742-756 keyframes/s for the round-4 tree on the same box; hipEventQuery on an event whose stream still has work queued makes the
+        runtime submit a marker behind it - a blocked packet in that keyframe's hardware queue)."""
+        return not any(plan.enqueued for plan in self._plans.values())
 
     def _forward_slot(self, prep):
         """Slot of a forward() call: 0 - one set of resident buffers and packed weights stays hot -, unless its plan hands out copies of
@@ -946,7 +950,7 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = [owned[f"pred{i}"] for i in range(4)]
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-            return _Pending(data_dict, done, device, None, owned=True)
+            return _Pending(data_dict, done, device, None, owned=True, enqueued=plan.enqueued)
         data_dict["cost_volume"] = plan.buf["cost_volume"]
         if not (plan.lean_outputs and plan.b8):               # (lean: the buffer holds raw per-frame costs, not monorec_model.py:251's volumes)
             data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
@@ -958,7 +962,7 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = list(plan.preds)
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-        handle = _Pending(data_dict, done, device, plan.consumers)
+        handle = _Pending(data_dict, done, device, plan.consumers, enqueued=plan.enqueued)
         if not own:                                           # forward() collects its handle before anyone else can see the slot
             plan.handles = [hd for hd in plan.handles if hd() is not None and not hd().collected]
             plan.handles.append(weakref.ref(handle))
@@ -1067,8 +1071,9 @@ class _GroupHandle:
 class _Pending:
     """Handle of an enqueued forward (MonoRecModel.submit)."""
 
-    def __init__(self, data_dict, done, device, consumers=None, owned=False):
+    def __init__(self, data_dict, done, device, consumers=None, owned=False, enqueued=None):
         self._data, self._done, self._device, self._consumers = data_dict, done, device, consumers
+        self._enqueued = enqueued   # the slot's deque of completion events the host has not waited for yet (synchronize() takes this one out)
         self.collected = False      # result() / synchronize() taken: forward() may reuse the slot's resident output buffers as a copy source
         self.owned = owned          # the outputs already live in memory the caller owns (forward())
 
@@ -1086,6 +1091,11 @@ class _Pending:
         """Wait on the HOST for the forward and return the output dict: the caller's stream needs no wait packet then (a blocked
         one slows the other hardware queues down) - the way to collect results in a pipelined loop."""
         _host_wait(self._done)
+        if self._enqueued is not None:          # the host now knows this forward is complete (MonoRecModel._device_idle)
+            try:
+                self._enqueued.remove(self._done)
+            except ValueError:
+                pass
         self.collected = True
         return self._data
 

@@ -783,7 +783,10 @@ def test_forward_produces_its_outputs_in_two_caller_owned_arenas(hip_lib):
     with torch.no_grad():
         out = m(dict(batch))
         plan = next(iter(m._plans.values()))
-        assert plan.outputs_rebindable and plan.bound != plan._resident
+        # the launches were re-targeted at the caller's arenas while they were enqueued and the plan is back on its resident buffers as soon as
+        # forward() returns (anything that drives the plan directly afterwards must not write into memory the caller may free)
+        assert plan.outputs_rebindable and plan.bound == plan._resident
+        assert out["result"].data_ptr() not in {t.data_ptr() for t in plan.buf.values()} and out["cost_volume"].data_ptr() != plan.buf["cost_volume"].data_ptr()
         small = out["result"].untyped_storage()
         assert small.data_ptr() == out["cv_mask"].untyped_storage().data_ptr() == out["inv_depth_min"].untyped_storage().data_ptr()
         assert small.data_ptr() == out["predicted_inverse_depths"][3].untyped_storage().data_ptr()

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--count", default="")
     ap.add_argument("--flag", action="append", default=[])
     a = ap.parse_args()
-    src = a.source if os.path.exists(a.source) else os.path.join(ROOT, "monorec_amd", "csrc", a.source)
+    src = os.path.abspath(a.source) if os.path.exists(a.source) else os.path.join(ROOT, "monorec_amd", "csrc", a.source)
     asm = compile_asm(src, a.flag)
     demangle = {}
     try:

@@ -236,6 +236,10 @@ def host_geometry_reference_form(keyframe_intrinsics, keyframe_pose, intrinsics,
 HOST_SPIN_SECONDS = 0.004       # longest busy-poll of _host_wait before it falls back to a sleeping wait
 
 
+import os as _os
+_LAZY_PREPARE = _os.environ.get("MR_DIAG_LAZY_PREPARE", "1") != "0"      # diagnostic A/B switch of tools/sessions/r05_s4.sh
+
+
 def _host_wait(event):
     """Block the host until `event` has happened - by polling, for a bounded time.  hipEventSynchronize polls only for a while and
     then sleeps, and a sleeping wait wakes up late (measured on MI355X / ROCm 7: sequential forwards of 2 ms each went to 3.2 ms
@@ -602,7 +606,7 @@ class MonoRecModel(nn.Module):
         prep = self._parse(data_dict)
         with self._lock, torch.cuda.device(prep.device):
             self._wait_inputs(prep.device)
-            if self._device_idle():
+            if self._device_idle() and _LAZY_PREPARE:
                 # nothing of this model is in flight (first request of a stream, a stream that ran dry): the device would sit idle through
                 # the pose algebra (gather round trip + ~0.1 ms of 4x4 operators, 0.5 ms on a device that has just been synchronised:
                 # r04_s32).  The token stays without matrices and submit() forms them behind the encoder stage's launches, exactly as

@@ -238,6 +238,7 @@ HOST_SPIN_SECONDS = 0.004       # longest busy-poll of _host_wait before it fall
 
 import os as _os
 _LAZY_PREPARE = _os.environ.get("MR_DIAG_LAZY_PREPARE", "1") != "0"      # diagnostic A/B switch of tools/sessions/r05_s4.sh
+_STREAM_LAYOUT = _os.environ.get("MR_DIAG_STREAM_LAYOUT")                  # diagnostic: creation order of the model's streams (MonoRecModel._device_streams)
 
 
 def _host_wait(event):
@@ -342,6 +343,7 @@ class MonoRecModel(nn.Module):
         self._plans = {}
         self._graphs = {}
         self._streams = {}
+        self._dev_streams = {}           # device -> every stream of this model there, created in one fixed order (_device_streams)
         self._consts = {}
         self._const_slab = {}
         self._packed_state = None
@@ -424,7 +426,7 @@ class MonoRecModel(nn.Module):
 
     def __getstate__(self):          # copy.deepcopy / pickle: device plans, streams, graphs and the lock are rebuilt on demand
         state = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
-        for k in ("_plans", "_graphs", "_streams", "_consts", "_const_slab", "_prep_pinned"):
+        for k in ("_plans", "_graphs", "_streams", "_dev_streams", "_consts", "_const_slab", "_prep_pinned"):
             state[k] = {}
         state["_packed_state"] = None
         state["_open_group"] = None
@@ -435,10 +437,38 @@ class MonoRecModel(nn.Module):
         super().__setstate__(state)
         self._lock = threading.RLock()
 
+    def _device_streams(self, device):
+        """Every HIP stream this model uses on `device`, created at ONE point in a FIXED order: the gather stream of prepare(), then per in-flight
+        slot its main and encoder streams.  The order is not cosmetic: PyTorch hands out pool streams round-robin and ROCm maps them onto the
+        hardware queues in creation order, and which two streams end up next to each other there moves the two-keyframes-in-flight rate by 8 %
+        (r05_s4: 694-710 keyframes/s at c2 when the first request happened to create the slot streams BEFORE the gather stream - a parse-only token on
+        an idle device - against 742-762 in this order; round 4's call order produced it by accident).  `_STREAM_LAYOUT` names the order
+        ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an unused pool stream); MR_DIAG_STREAM_LAYOUT: experiments only."""
+        key = str(device)
+        if key not in self._dev_streams:
+            layout = _STREAM_LAYOUT or ",".join(["g"] + [f"m{s_},e{s_},_" for s_ in range(self._in_flight)])
+            made, pads = {}, []
+            for name in layout.split(","):
+                st = torch.cuda.Stream(device)
+                if name == "_":
+                    pads.append(st)
+                else:
+                    made[name] = st
+            for s_ in range(self._in_flight):            # a layout that leaves something out: created behind it
+                for n_ in (f"m{s_}", f"e{s_}"):
+                    if n_ not in made:
+                        made[n_] = torch.cuda.Stream(device)
+            if "g" not in made:
+                made["g"] = torch.cuda.Stream(device)
+            made["_pads"] = pads                         # (kept alive: a released pool slot would shift the streams created later)
+            self._dev_streams[key] = made
+        return self._dev_streams[key]
+
     def _slot_streams(self, slot, device):
         st = self._streams.get((slot, str(device)))
         if st is None:
-            st = {n: torch.cuda.Stream(device) for n in ("main", "enc", "geom")}
+            ds = self._device_streams(device)
+            st = {"main": ds[f"m{slot}"], "enc": ds[f"e{slot}"]}
             if self._single_stream:
                 st["enc"] = st["main"]
             self._streams[(slot, str(device))] = st
@@ -683,7 +713,7 @@ class MonoRecModel(nn.Module):
         pk = (str(device), len(dm), b)
         pinned = self._prep_pinned.get(pk)
         if pinned is None:
-            pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), torch.cuda.Stream(device))
+            pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), self._device_streams(device)["g"])
         hm, gs = pinned
         ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
         _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")

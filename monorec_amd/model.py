@@ -438,29 +438,34 @@ class MonoRecModel(nn.Module):
         self._lock = threading.RLock()
 
     def _device_streams(self, device):
-        """Every HIP stream this model uses on `device`, created at ONE point in a FIXED order: the gather stream of prepare(), then per in-flight
-        slot its main and encoder streams.  The order is not cosmetic: PyTorch hands out pool streams round-robin and ROCm maps them onto the
-        hardware queues in creation order, and which two streams end up next to each other there moves the two-keyframes-in-flight rate by 8 %
-        (r05_s4: 694-710 keyframes/s at c2 when the first request happened to create the slot streams BEFORE the gather stream - a parse-only token on
-        an idle device - against 742-762 in this order; round 4's call order produced it by accident).  `_STREAM_LAYOUT` names the order
-        ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an unused pool stream); MR_DIAG_STREAM_LAYOUT: experiments only."""
+        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the gather stream of prepare(), then per
+        in-flight slot its main and encoder streams.  The order is not cosmetic: ROCm binds a stream to one of its GPU_MAX_HW_QUEUES hardware queues when the
+        stream is first USED, in order of first use, and which of the model's streams end up on which queue moves the two-keyframes-in-flight rate by 8 % for the
+        life of the process (r05_s4 / s5, c2: 683-710 keyframes/s when the FIRST request of the process happened to launch on a slot's encoder stream before its
+        main stream - a parse-only token on an idle device - against 742-762 with main before encoder; round 4 had the good order by accident of its call order).
+        So every stream gets one 4-byte launch here, in `_STREAM_LAYOUT` order ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an extra
+        stream that only takes a queue); MR_DIAG_STREAM_LAYOUT: experiments only."""
         key = str(device)
         if key not in self._dev_streams:
-            layout = _STREAM_LAYOUT or ",".join(["g"] + [f"m{s_},e{s_},_" for s_ in range(self._in_flight)])
+            layout = _STREAM_LAYOUT or ",".join(["g"] + [f"m{s_},e{s_}" for s_ in range(self._in_flight)])
+            names = layout.split(",")
+            for s_ in range(self._in_flight):            # a layout that leaves something out: behind it
+                names += [n_ for n_ in (f"m{s_}", f"e{s_}") if n_ not in names]
+            if "g" not in names:
+                names.append("g")
             made, pads = {}, []
-            for name in layout.split(","):
+            touch = torch.zeros(len(names), dtype=torch.float32, device=device)
+            torch.cuda.synchronize(device)
+            for i, name in enumerate(names):
                 st = torch.cuda.Stream(device)
+                with torch.cuda.stream(st):
+                    touch[i:i + 1].fill_(1.0)            # the stream's first launch: this is when it gets its hardware queue
+                st.synchronize()
                 if name == "_":
                     pads.append(st)
                 else:
                     made[name] = st
-            for s_ in range(self._in_flight):            # a layout that leaves something out: created behind it
-                for n_ in (f"m{s_}", f"e{s_}"):
-                    if n_ not in made:
-                        made[n_] = torch.cuda.Stream(device)
-            if "g" not in made:
-                made["g"] = torch.cuda.Stream(device)
-            made["_pads"] = pads                         # (kept alive: a released pool slot would shift the streams created later)
+            made["_pads"] = pads                         # (kept alive)
             self._dev_streams[key] = made
         return self._dev_streams[key]
 

@@ -237,7 +237,6 @@ HOST_SPIN_SECONDS = 0.004       # longest busy-poll of _host_wait before it fall
 
 
 import os as _os
-_LAZY_PREPARE = _os.environ.get("MR_DIAG_LAZY_PREPARE", "1") != "0"      # diagnostic A/B switch of tools/sessions/r05_s4.sh
 _STREAM_LAYOUT = _os.environ.get("MR_DIAG_STREAM_LAYOUT")                  # diagnostic: creation order of the model's streams (MonoRecModel._device_streams)
 
 
@@ -438,16 +437,17 @@ class MonoRecModel(nn.Module):
         self._lock = threading.RLock()
 
     def _device_streams(self, device):
-        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the gather stream of prepare(), then per
-        in-flight slot its main and encoder streams.  The order is not cosmetic: ROCm binds a stream to one of its GPU_MAX_HW_QUEUES hardware queues when the
-        stream is first USED, in order of first use, and which of the model's streams end up on which queue moves the two-keyframes-in-flight rate by 8 % for the
-        life of the process (r05_s4 / s5, c2: 683-710 keyframes/s when the FIRST request of the process happened to launch on a slot's encoder stream before its
-        main stream - a parse-only token on an idle device - against 742-762 with main before encoder; round 4 had the good order by accident of its call order).
-        So every stream gets one 4-byte launch here, in `_STREAM_LAYOUT` order ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an extra
-        stream that only takes a queue); MR_DIAG_STREAM_LAYOUT: experiments only."""
+        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the gather stream of prepare(), then the main
+        streams of the in-flight slots, then their encoder streams.  The order is not cosmetic: ROCm binds a stream to a hardware queue when the stream is first
+        USED, in order of first use, and where the model's four busy streams sit among the queues sets the two-keyframes-in-flight rate for the life of the
+        process - measured at c2 (tools/sessions/r05_s6.sh, 200 steps): the four next to each other, in any order, 757-769 keyframes/s; another stream first used
+        between them 693-717; spread out with unused streams between them 509-558.  Round 4 had a good order by accident of its call order (750); the first tree
+        of round 5 lost 8 % when its first request happened to launch on an encoder stream before the gather stream (r05_s1 - s5).  So every stream gets one
+        4-byte launch here, in `_STREAM_LAYOUT` order ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an extra stream that only takes a
+        queue); MR_DIAG_STREAM_LAYOUT: experiments only."""
         key = str(device)
         if key not in self._dev_streams:
-            layout = _STREAM_LAYOUT or ",".join(["g"] + [f"m{s_},e{s_}" for s_ in range(self._in_flight)])
+            layout = _STREAM_LAYOUT or ",".join(["g"] + [f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(self._in_flight)])
             names = layout.split(",")
             for s_ in range(self._in_flight):            # a layout that leaves something out: behind it
                 names += [n_ for n_ in (f"m{s_}", f"e{s_}") if n_ not in names]
@@ -641,12 +641,8 @@ class MonoRecModel(nn.Module):
         prep = self._parse(data_dict)
         with self._lock, torch.cuda.device(prep.device):
             self._wait_inputs(prep.device)
-            if self._device_idle() and _LAZY_PREPARE:
-                # nothing of this model is in flight (first request of a stream, a stream that ran dry): the device would sit idle through
-                # the pose algebra (gather round trip + ~0.1 ms of 4x4 operators, 0.5 ms on a device that has just been synchronised:
-                # r04_s32).  The token stays without matrices and submit() forms them behind the encoder stage's launches, exactly as
-                # forward() does - the device starts on the pose-independent stage at once.
-                return prep
+            # (A parse-only token for the first request on an idle device - pose algebra behind the encoder stage's launches, as forward() does it - was
+            # built and measured in round 5: 705-709 against 716-718 keyframes/s on 20-step lines, r05_s6.  Not kept.)
             self._geometry(prep)
         return prep
 
@@ -744,14 +740,6 @@ class MonoRecModel(nn.Module):
     def _geometry(self, prep):
         """kinv / proj of a parsed request into the token.  Inputs must be ready."""
         return self._geometry_finish(prep, self._geometry_begin(prep))
-
-    def _device_idle(self):
-        """No forward of this model is in flight as far as the HOST already knows: every forward it enqueued has been waited for on the host
-        (`handle.synchronize()`, or the run-ahead wait of a later submit on the same slot).  Deliberately NOT a query of the completion events:
-        r05_s2 measured that polling the events of the OTHER slot's running keyframe from prepare() costs 6 % of the two-in-flight rate (701-710
-        against 742-756 keyframes/s for the round-4 tree on the same box; hipEventQuery on an event whose stream still has work queued makes the
-        runtime submit a marker behind it - a blocked packet in that keyframe's hardware queue)."""
-        return not any(plan.enqueued for plan in self._plans.values())
 
     def _forward_slot(self, prep):
         """Slot of a forward() call: 0 - one set of resident buffers and packed weights stays hot -, unless its plan hands out copies of
@@ -989,7 +977,7 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = [owned[f"pred{i}"] for i in range(4)]
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-            return _Pending(data_dict, done, device, None, owned=True, enqueued=plan.enqueued)
+            return _Pending(data_dict, done, device, None, owned=True)
         data_dict["cost_volume"] = plan.buf["cost_volume"]
         if not (plan.lean_outputs and plan.b8):               # (lean: the buffer holds raw per-frame costs, not monorec_model.py:251's volumes)
             data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
@@ -1001,7 +989,7 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = list(plan.preds)
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-        handle = _Pending(data_dict, done, device, plan.consumers, enqueued=plan.enqueued)
+        handle = _Pending(data_dict, done, device, plan.consumers)
         if not own:                                           # forward() collects its handle before anyone else can see the slot
             plan.handles = [hd for hd in plan.handles if hd() is not None and not hd().collected]
             plan.handles.append(weakref.ref(handle))
@@ -1110,9 +1098,8 @@ class _GroupHandle:
 class _Pending:
     """Handle of an enqueued forward (MonoRecModel.submit)."""
 
-    def __init__(self, data_dict, done, device, consumers=None, owned=False, enqueued=None):
+    def __init__(self, data_dict, done, device, consumers=None, owned=False):
         self._data, self._done, self._device, self._consumers = data_dict, done, device, consumers
-        self._enqueued = enqueued   # the slot's deque of completion events the host has not waited for yet (synchronize() takes this one out)
         self.collected = False      # result() / synchronize() taken: forward() may reuse the slot's resident output buffers as a copy source
         self.owned = owned          # the outputs already live in memory the caller owns (forward())
 
@@ -1130,11 +1117,6 @@ class _Pending:
         """Wait on the HOST for the forward and return the output dict: the caller's stream needs no wait packet then (a blocked
         one slows the other hardware queues down) - the way to collect results in a pipelined loop."""
         _host_wait(self._done)
-        if self._enqueued is not None:          # the host now knows this forward is complete (MonoRecModel._device_idle)
-            try:
-                self._enqueued.remove(self._done)
-            except ValueError:
-                pass
         self.collected = True
         return self._data
 

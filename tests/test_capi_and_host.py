@@ -354,9 +354,11 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     wino_1d = [c for c in plan.conv_log if c.get("winograd") and min(c["k"]) == 1 and not c.get("stride2")]
     assert {c["name"] for c in wino_1d} == ({f"depth.{s}.conv_{a}" for s in ("enc0.1", "enc1.1", "enc2.1", "dec1.1", "dec2.1", "dec4.0") for a in "yx"} |
                                             {"depth.enc0.0.conv_y", "depth.enc0.0.conv_x"})
-    # ... and (round 5) the 7-tap stride-2 pair of enc.1.0 as F(4,4) over [even | odd] views: 3.5 of 7 multiplies per output and input channel
+    # ... and (round 5) the 7-tap stride-2 pair of enc.1.0 as F(4,4) over [even | odd] views (3.5 of 7 multiplies per output and input channel) and the 5 x 1
+    # half of enc.2.0 as F(4,3) over [even | odd] rows (3 of 5; its 1 x 5 half stays on the direct kernel: table code 10)
     s2 = [c for c in plan.conv_log if c.get("stride2")]
-    assert [c["name"] for c in s2] == ["depth.enc1.0.conv_y", "depth.enc1.0.conv_x"] and all(c["macs"] * 2 == c["ref_macs"] and c["lds"] <= 160 * 1024 for c in s2)
+    assert [c["name"] for c in s2] == ["depth.enc1.0.conv_y", "depth.enc1.0.conv_x", "depth.enc2.0.conv_y"] and all(c["lds"] <= 160 * 1024 for c in s2)
+    assert all(c["macs"] * 2 == c["ref_macs"] for c in s2[:2]) and s2[2]["macs"] * 5 == s2[2]["ref_macs"] * 3
     for c in wino_1d:
         m_, r_ = c.get("wino_m", 2), max(c["k"])
         assert (m_, r_) in ((2, 3), (4, 3), (4, 7)) and c["macs"] == c["ref_macs"] * (m_ + r_ - 1) // (m_ * r_) and c["lds"] <= 160 * 1024
@@ -377,7 +379,7 @@ def test_plan_dry_run_on_cpu_accounts_for_every_mac(hip_lib):
     assert max(c["lds"] for c in plan.conv_log) <= 160 * 1024
     assert all(c["mb"] in (1, 2, 3, 4, 6) and c["nb"] in (1, 2, 4) and c["split_k"] >= 1 and c["ck"] in (8, 16, 32, 64, 128)
                for c in plan.conv_log if not c.get("winograd"))
-    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 14 + 2 + 2
+    assert sum(1 for c in plan.conv_log if c.get("winograd")) == 9 + 2 + 14 + 2 + 3
     assert sum(c["phases"] == 4 for c in plan.conv_log) == 8        # four Refine transposed convolutions + four phase-decomposed Upconvs
     assert len(plan.stages["encoder"]) + len(plan.stages["encoder_tail"]) == 22 and len(plan.stages["encoder_tail"]) == 5 and plan.stages["cv"][0][0] == "cost_volume" and plan.stages["main"][0][0] == "mask.dec0.0"
 
@@ -829,7 +831,8 @@ def test_winograd_choice_table_and_rule():
     rule; widths that are not a multiple of 4 never qualify."""
     assert engine.WINOGRAD, "monorec_amd/tuned_winograd.json missing"
     # 3x3 / transposed keys: + 10 = input transform in registers, + 20 = ... with 16-channel tail workgroups; 1-D keys: 10 m + blocks = F(m, taps)
-    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 11, 12, 14, 21, 22, 23, 24, 31, 41, 42, 43, 44}          # 31: F(4x4,3x3)
+    assert set(engine.WINOGRAD.values()) <= {0, 1, 2, 3, 4, 10, 11, 12, 14, 21, 22, 23, 24, 31, 41, 42, 43, 44}      # 31: F(4x4,3x3); 10 (s2k keys): only the k x 1 half
+    assert all(k.startswith("s2k") for k, v in engine.WINOGRAD.items() if v == 10)
     assert all(v in (0, 21, 22, 23, 24, 41, 42, 43) for k, v in engine.WINOGRAD.items() if k[:3] in ("x7_", "y7_"))
     assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1) in (3, 41, 42, 43) and engine.choose_winograd_1d(1, 256, [256], 16, 32, 1) == 0 and engine.choose_winograd_1d(0, 48, [48], 256, 510, 1) == 0
     assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1, 7) == 43 and engine.choose_winograd_1d(1, 48, [32, 3], 256, 512, 1, 7) == 43      # depth.enc0.0 @ c2: F(4,7)

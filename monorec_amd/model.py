@@ -237,7 +237,8 @@ HOST_SPIN_SECONDS = 0.004       # longest busy-poll of _host_wait before it fall
 
 
 import os as _os
-_STREAM_LAYOUT = _os.environ.get("MR_DIAG_STREAM_LAYOUT")                  # diagnostic: creation order of the model's streams (MonoRecModel._device_streams)
+_STREAM_LAYOUT = _os.environ.get("MR_DIAG_STREAM_LAYOUT")                  # diagnostic: creation / first-use order of the model's streams (MonoRecModel._device_streams)
+_STREAM_PRIO = _os.environ.get("MR_DIAG_STREAM_PRIO", "")                  # diagnostic: kinds of streams ("m", "e", "g") created with high priority
 
 
 def _host_wait(event):
@@ -437,17 +438,17 @@ class MonoRecModel(nn.Module):
         self._lock = threading.RLock()
 
     def _device_streams(self, device):
-        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the gather stream of prepare(), then the main
-        streams of the in-flight slots, then their encoder streams.  The order is not cosmetic: ROCm binds a stream to a hardware queue when the stream is first
+        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the main streams of the in-flight slots, their
+        encoder streams, then the gather stream of prepare().  The order is not cosmetic: ROCm binds a stream to a hardware queue when the stream is first
         USED, in order of first use, and where the model's four busy streams sit among the queues sets the two-keyframes-in-flight rate for the life of the
-        process - measured at c2 (tools/sessions/r05_s6.sh, 200 steps): the four next to each other, in any order, 757-769 keyframes/s; another stream first used
-        between them 693-717; spread out with unused streams between them 509-558.  Round 4 had a good order by accident of its call order (750); the first tree
+        process - measured at c2 (tools/sessions/r05_s6.sh, r05_s7.sh, 200 steps): the four next to each other, in any order, 757-769 keyframes/s (mains, encoders, gather last:
+        767-768, the default); another stream first used between them 693-717; spread out with unused streams between them 509-558.  Round 4 had a good order by accident of its call order (750); the first tree
         of round 5 lost 8 % when its first request happened to launch on an encoder stream before the gather stream (r05_s1 - s5).  So every stream gets one
         4-byte launch here, in `_STREAM_LAYOUT` order ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an extra stream that only takes a
         queue); MR_DIAG_STREAM_LAYOUT: experiments only."""
         key = str(device)
         if key not in self._dev_streams:
-            layout = _STREAM_LAYOUT or ",".join(["g"] + [f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(self._in_flight)])
+            layout = _STREAM_LAYOUT or ",".join([f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(self._in_flight)] + ["g"])
             names = layout.split(",")
             for s_ in range(self._in_flight):            # a layout that leaves something out: behind it
                 names += [n_ for n_ in (f"m{s_}", f"e{s_}") if n_ not in names]
@@ -457,7 +458,7 @@ class MonoRecModel(nn.Module):
             touch = torch.zeros(len(names), dtype=torch.float32, device=device)
             torch.cuda.synchronize(device)
             for i, name in enumerate(names):
-                st = torch.cuda.Stream(device)
+                st = torch.cuda.Stream(device, priority=-1 if (name[:1] in _STREAM_PRIO and name != "_") else 0)
                 with torch.cuda.stream(st):
                     touch[i:i + 1].fill_(1.0)            # the stream's first launch: this is when it gets its hardware queue
                 st.synchronize()

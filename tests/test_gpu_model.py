@@ -944,10 +944,11 @@ def test_harsh_weights_on_the_reference_example_sample_stage_by_stage(hip_lib):
 
 @pytest.mark.gpu
 def test_the_models_streams_are_created_once_in_a_fixed_order(hip_lib):
-    """Which of the model's streams end up next to each other in PyTorch's stream pool / ROCm's hardware queues moves the two-keyframes-in-flight rate
-    by 8 % (tools/sessions/r05_s4.sh, r05_s5.sh, r05_s6.sh), so MonoRecModel._device_streams creates AND first uses ALL of them at one point in one order - gather
-    stream, the slots' main streams, their encoder streams - whatever the caller does first: prepare() + submit() (round 4's order), a submit() with a parse-only token on an idle device
-    (what round 5's first tree did: slot streams before the gather stream, 694-710 instead of 742-762 keyframes/s), or forward()."""
+    """Where the model's four busy streams sit among ROCm's hardware queues - bound at first use, in order of first use - sets the two-keyframes-in-flight rate
+    for the life of the process (tools/sessions/r05_s4.sh - s7.sh: next to each other 757-769 keyframes/s at c2, something between them 693-717, spread out
+    509-558), so MonoRecModel._device_streams creates AND first uses ALL of them at one point in one order - the slots' main streams, their encoder streams,
+    the gather stream - whatever the caller does first: prepare() + submit(), a bare submit(), or forward() (which launches on a slot's encoder stream
+    before its main stream: the first-use order that cost the first tree of round 5 8 %)."""
     batch = _to_dev(synth.make_batch(1, 64, 96, 2, seed=77))
     orders = []
     for first in ("prepare", "submit", "forward"):
@@ -963,7 +964,7 @@ def test_the_models_streams_are_created_once_in_a_fixed_order(hip_lib):
                 m(dict(batch))
         torch.cuda.synchronize()
         ds = m._dev_streams[str(torch.device(DEV))]
-        assert [k for k in ds if k != "_pads"] == ["g", "m0", "m1", "e0", "e1"]
+        assert [k for k in ds if k != "_pads"] == ["m0", "m1", "e0", "e1", "g"]
         assert m._slot_streams(0, torch.device(DEV))["main"] is ds["m0"] and m._slot_streams(1, torch.device(DEV))["enc"] is ds["e1"]
         assert all(v[1] is ds["g"] for v in m._prep_pinned.values())
         ids = [ds[k].cuda_stream for k in ("g", "m0", "e0", "m1", "e1")]

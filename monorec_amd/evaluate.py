@@ -53,7 +53,7 @@ class Evaluater:
     (`evaluation_log`: NaN batch => invalid, mean over valid batches, batch-size-weighted running mean, evaluater.py:45-49,
     94-118) then runs on the index-sorted union, so the log equals the single-process log bit for bit on every rank."""
 
-    def __init__(self, model, roi=None, max_distance=None, metric_names=_metrics.SPARSE_METRICS, in_flight=2, sums_fn=None):
+    def __init__(self, model, roi=None, max_distance=None, metric_names=_metrics.SPARSE_METRICS, in_flight=None, sums_fn=None):
         unknown = [m for m in metric_names if m not in _metrics.SPARSE_METRICS]
         if unknown:
             raise NotImplementedError(f"metrics outside the fused sparse set: {unknown}")
@@ -62,7 +62,8 @@ class Evaluater:
         self._cols = [_metrics.SPARSE_METRICS.index(m) for m in self.metric_names]
         # forwards kept in flight: never more than the model has slots - a deeper queue would let submit() reuse a slot whose
         # resident `result` has not been reduced yet (the metric launch would then read the wrong keyframe's prediction)
-        self.in_flight = max(1, min(int(in_flight), int(getattr(model, "_in_flight", in_flight))))
+        slots = int(getattr(model, "_in_flight", in_flight or 2))
+        self.in_flight = max(1, min(int(in_flight) if in_flight is not None else slots, slots))      # default: every slot of the model
         self._sums_fn = sums_fn or _metrics.sparse_metric_sums_device   # (B, 8) per-sample sums; injectable for host-logic tests
 
     # the 4x4 matrices feed the model's HOST-side pose algebra (model.host_geometry): moved to the device they would have to come back,

@@ -273,8 +273,9 @@ class MonoRecModel(nn.Module):
                  pretrain_dropout_mode=0, augmentation=None, use_mono=True, use_stereo=False, use_ssim=True,
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
-                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=2, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False):
+                 mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=4, hip_bf16=False, hip_bf16x3=False,
+                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False,
+                 hip_slot_streams=1):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -319,6 +320,11 @@ class MonoRecModel(nn.Module):
         # profiling aid: encoder and main stages on ONE stream, so that a kernel trace of `hip_in_flight=1` shows isolated kernel
         # durations (with two streams the ResNet launches overlap the cost volume / mask encoder and inflate each other)
         self._single_stream = bool(hip_single_stream)
+        # Streams per in-flight slot of submit(): 1 (default since round 5) = all stages of a keyframe on ONE stream, 2 = encoder stage on a second
+        # stream (rounds 2-4).  The GPU runs four hardware queues side by side; measured at c2 (tools/sessions/r05_s8.sh, s9.sh, 200 / 20 steps): four
+        # slots x one stream 820-827 / 749-754 keyframes/s, two slots x two streams 762-766 / 716-719, three x one 791, four x two 794, five x one
+        # 744.  forward() - one keyframe at a time - keeps its encoder stage on a second stream ("e0": 1187 vs 1278 us per keyframe, r04_s17).
+        self._slot_streams_n = 2 if int(hip_slot_streams) >= 2 else 1
         self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
@@ -448,12 +454,10 @@ class MonoRecModel(nn.Module):
         queue); MR_DIAG_STREAM_LAYOUT: experiments only."""
         key = str(device)
         if key not in self._dev_streams:
-            layout = _STREAM_LAYOUT or ",".join([f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(self._in_flight)] + ["g"])
+            n_enc = self._in_flight if self._slot_streams_n == 2 else 1          # one stream per slot: only forward() has an encoder stream ("e0")
+            layout = _STREAM_LAYOUT or ",".join([f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"])
             names = layout.split(",")
-            for s_ in range(self._in_flight):            # a layout that leaves something out: behind it
-                names += [n_ for n_ in (f"m{s_}", f"e{s_}") if n_ not in names]
-            if "g" not in names:
-                names.append("g")
+            names += [n_ for n_ in [f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"] if n_ not in names]   # left out: behind
             made, pads = {}, []
             touch = torch.zeros(len(names), dtype=torch.float32, device=device)
             torch.cuda.synchronize(device)
@@ -470,14 +474,20 @@ class MonoRecModel(nn.Module):
             self._dev_streams[key] = made
         return self._dev_streams[key]
 
-    def _slot_streams(self, slot, device):
-        st = self._streams.get((slot, str(device)))
+    def _slot_streams(self, slot, device, own=False):
+        """{"main", "enc"} of an in-flight slot.  `own` = forward(): with one stream per slot the encoder stage of a forward() still gets a stream of its own
+        ("e0"; forward() calls are sequential, so they can share it whatever slot they run on)."""
+        st = self._streams.get((slot, str(device), bool(own)))
         if st is None:
             ds = self._device_streams(device)
-            st = {"main": ds[f"m{slot}"], "enc": ds[f"e{slot}"]}
             if self._single_stream:
-                st["enc"] = st["main"]
-            self._streams[(slot, str(device))] = st
+                enc = ds[f"m{slot}"]
+            elif self._slot_streams_n == 2:
+                enc = ds[f"e{slot}"]
+            else:
+                enc = ds["e0"] if own else ds[f"m{slot}"]
+            st = {"main": ds[f"m{slot}"], "enc": enc}
+            self._streams[(slot, str(device), bool(own))] = st
         return st
 
     def _plan_for(self, slot, batch, h, w, nf, device):
@@ -571,7 +581,7 @@ class MonoRecModel(nn.Module):
         _, plan = self._plan_for(slot, b, h, w, nf, prep.device)
         if not plan.outputs_rebindable:
             return None
-        streams = self._slot_streams(slot, prep.device)
+        streams = self._slot_streams(slot, prep.device, own=True)
         return self._bind_owned_outputs(plan, prep.device, (streams["main"], streams["enc"]))
 
     def _own_outputs(self, out):
@@ -758,7 +768,7 @@ class MonoRecModel(nn.Module):
 
     def _submit_one(self, data_dict, prepared=None, slot=None):
         """Enqueue one forward on the next in-flight slot and return a handle without making the caller's stream
-        wait for it.  Keyframes are independent, so a stream of keyframes is served with `hip_in_flight` (default 2)
+        wait for it.  Keyframes are independent, so a stream of keyframes is served with `hip_in_flight` (default 4)
         of them on the GPU at once - on separate HIP streams and resident buffers - which fills the launch
         head/tail bubbles that a single batch-1 keyframe leaves on 256 CUs:
 
@@ -878,7 +888,7 @@ class MonoRecModel(nn.Module):
             slot = self._slot_counter[0]
             self._slot_counter[0] = (slot + 1) % self._in_flight
         key, plan = self._plan_for(slot, b, h, w, nf, device)
-        streams = self._slot_streams(slot, device)
+        streams = self._slot_streams(slot, device, own=own)
         main, enc = streams["main"], streams["enc"]
         caller = torch.cuda.current_stream(device)
         # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time
@@ -902,20 +912,27 @@ class MonoRecModel(nn.Module):
             # the launches read dense fp32 inputs where they are (no device copy); anything else - and hipGraph replay, whose
             # captured launches keep their pointers - goes through the slot's resident buffers
             plan.bind_inputs(keyframe, frames, in_place=not self._hip_graph)
+            one = enc is main              # one stream per slot (the default of submit()): stream order is the only dependency, no events
             for t in [keyframe] + frames:
                 t.record_stream(main)
-                t.record_stream(enc)
-            enc.wait_stream(main)          # behind the inputs and behind the slot's previous main stage (it reads the image features)
+                if not one:
+                    t.record_stream(enc)
+            if not one:
+                enc.wait_stream(main)      # behind the inputs and behind the slot's previous main stage (it reads the image features)
 
             def encoder_stage():
-                self._run_stage(key, plan, "encoder", enc)    # ResNet up to layer3, pose independent, its own stream
-                enc_done = torch.cuda.Event()
-                enc_done.record(enc)
-                # ResNet layer4 is output-only (image_features[4]): it keeps running on the encoder stream while the mask /
+                self._run_stage(key, plan, "encoder", enc)    # ResNet up to layer3, pose independent (its own stream when the slot has two)
+                enc_done = None
+                if not one:
+                    enc_done = torch.cuda.Event()
+                    enc_done.record(enc)
+                # ResNet layer4 is output-only (image_features[4]): with two streams it keeps running on the encoder stream while the mask /
                 # depth stages proceed, and only the completion event of the keyframe waits for it
                 self._run_stage(key, plan, "encoder_tail", enc)
-                tail_done = torch.cuda.Event()
-                tail_done.record(enc)
+                tail_done = None
+                if not one:
+                    tail_done = torch.cuda.Event()
+                    tail_done.record(enc)
                 return enc_done, tail_done
 
             def cv_stage(kinv, proj):
@@ -950,9 +967,11 @@ class MonoRecModel(nn.Module):
                 cv_stage(prepared.kinv, prepared.proj)   # head of the longest chain (cost volume -> mask encoder -> mask decoder -> depth): first
                 enc_done, tail_done = encoder_stage()
             # join: mask decoder -> depth
-            main.wait_event(enc_done)
+            if not one:
+                main.wait_event(enc_done)
             self._run_stage(key, plan, "main", main)
-            main.wait_event(tail_done)
+            if not one:
+                main.wait_event(tail_done)
             done = torch.cuda.Event()
             done.record(main)
             plan.enqueued.append(done)

@@ -952,7 +952,7 @@ def test_the_models_streams_are_created_once_in_a_fixed_order(hip_lib):
     batch = _to_dev(synth.make_batch(1, 64, 96, 2, seed=77))
     orders = []
     for first in ("prepare", "submit", "forward"):
-        m, _ = _model(8, graph=False, in_flight=2)
+        m, _ = _model(8, graph=False, in_flight=2, hip_slot_streams=2)
         with torch.no_grad():
             if first == "prepare":
                 req = dict(batch)
@@ -966,8 +966,18 @@ def test_the_models_streams_are_created_once_in_a_fixed_order(hip_lib):
         ds = m._dev_streams[str(torch.device(DEV))]
         assert [k for k in ds if k != "_pads"] == ["m0", "m1", "e0", "e1", "g"]
         assert m._slot_streams(0, torch.device(DEV))["main"] is ds["m0"] and m._slot_streams(1, torch.device(DEV))["enc"] is ds["e1"]
+        assert m._slot_streams(1, torch.device(DEV), own=True)["enc"] is ds["e1"]
         assert all(v[1] is ds["g"] for v in m._prep_pinned.values())
         ids = [ds[k].cuda_stream for k in ("g", "m0", "e0", "m1", "e1")]
         assert len(set(ids)) == 5                                # five distinct streams, each first used at creation, in this order
         orders.append(first)
     assert orders == ["prepare", "submit", "forward"]
+    # the default since round 5: four slots with ONE stream each (820-827 keyframes/s at c2 against 762-766 for two slots x two streams, r05_s9); only
+    # forward() - one keyframe at a time - keeps its encoder stage on a second stream
+    m, _ = _model(8, graph=False, in_flight=4)
+    with torch.no_grad():
+        m.submit(dict(batch)).synchronize()
+    ds = m._dev_streams[str(torch.device(DEV))]
+    assert [k for k in ds if k != "_pads"] == ["m0", "m1", "m2", "m3", "e0", "g"]
+    sub, own = m._slot_streams(2, torch.device(DEV)), m._slot_streams(2, torch.device(DEV), own=True)
+    assert sub["enc"] is sub["main"] is ds["m2"] and own["main"] is ds["m2"] and own["enc"] is ds["e0"]

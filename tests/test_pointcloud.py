@@ -125,8 +125,8 @@ def test_unchanged_reference_loop_body_with_two_keyframes_in_flight(hip_lib):
     import torch.nn.functional as F
     from monorec_amd import MonoRecModel
     from monorec_amd.pointcloud import PLYSaver
-    model = MonoRecModel(cv_depth_steps=8)                                 # hip_in_flight defaults to 2
-    assert model._in_flight == 2
+    model = MonoRecModel(cv_depth_steps=8, hip_in_flight=2)
+    assert model._in_flight == 2 and MonoRecModel(cv_depth_steps=8)._in_flight == 4       # (the default: four slots, one stream each, since round 5)
     model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=0))
     model = model.to(DEV).eval()
     max_d, min_d, mask_fill, use_mask, roi = 400, 3, 32, True, [4, 120, 8, 180]

@@ -62,7 +62,7 @@ class Evaluater:
         self._cols = [_metrics.SPARSE_METRICS.index(m) for m in self.metric_names]
         # forwards kept in flight: never more than the model has slots - a deeper queue would let submit() reuse a slot whose
         # resident `result` has not been reduced yet (the metric launch would then read the wrong keyframe's prediction)
-        slots = int(getattr(model, "_in_flight", in_flight or 2))
+        slots = int(getattr(model, "hip_in_flight", in_flight or 2))
         self.in_flight = max(1, min(int(in_flight) if in_flight is not None else slots, slots))      # default: every slot of the model
         self._sums_fn = sums_fn or _metrics.sparse_metric_sums_device   # (B, 8) per-sample sums; injectable for host-logic tests
 

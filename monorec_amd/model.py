@@ -275,7 +275,7 @@ class MonoRecModel(nn.Module):
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=4, hip_bf16=False, hip_bf16x3=False,
                  hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False,
-                 hip_slot_streams=1):
+                 hip_slot_streams=None):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -323,7 +323,10 @@ class MonoRecModel(nn.Module):
         # Streams per in-flight slot of submit(): 1 (default since round 5) = all stages of a keyframe on ONE stream, 2 = encoder stage on a second
         # stream (rounds 2-4).  The GPU runs four hardware queues side by side; measured at c2 (tools/sessions/r05_s8.sh, s9.sh, 200 / 20 steps): four
         # slots x one stream 820-827 / 749-754 keyframes/s, two slots x two streams 762-766 / 716-719, three x one 791, four x two 794, five x one
-        # 744.  forward() - one keyframe at a time - keeps its encoder stage on a second stream ("e0": 1187 vs 1278 us per keyframe, r04_s17).
+        # 744.  One keyframe at a time - forward(), or hip_in_flight=1 - keeps its encoder stage on a second stream ("e0": 1187 vs 1278 us per
+        # keyframe, r04_s17): None = 2 streams with one slot, 1 stream per slot otherwise.
+        if hip_slot_streams is None:
+            hip_slot_streams = 2 if self._in_flight == 1 else 1
         self._slot_streams_n = 2 if int(hip_slot_streams) >= 2 else 1
         self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
@@ -443,18 +446,26 @@ class MonoRecModel(nn.Module):
         super().__setstate__(state)
         self._lock = threading.RLock()
 
+    @property
+    def hip_in_flight(self):
+        """Keyframes a stream of submit() calls keeps on the GPU at once (the constructor's `hip_in_flight`)."""
+        return self._in_flight
+
     def _device_streams(self, device):
-        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the main streams of the in-flight slots, their
-        encoder streams, then the gather stream of prepare().  The order is not cosmetic: ROCm binds a stream to a hardware queue when the stream is first
-        USED, in order of first use, and where the model's four busy streams sit among the queues sets the two-keyframes-in-flight rate for the life of the
-        process - measured at c2 (tools/sessions/r05_s6.sh, r05_s7.sh, 200 steps): the four next to each other, in any order, 757-769 keyframes/s (mains, encoders, gather last:
-        767-768, the default); another stream first used between them 693-717; spread out with unused streams between them 509-558.  Round 4 had a good order by accident of its call order (750); the first tree
-        of round 5 lost 8 % when its first request happened to launch on an encoder stream before the gather stream (r05_s1 - s5).  So every stream gets one
-        4-byte launch here, in `_STREAM_LAYOUT` order ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an extra stream that only takes a
-        queue); MR_DIAG_STREAM_LAYOUT: experiments only."""
+        """Every HIP stream this model uses on `device`, created AND FIRST USED at one point in a FIXED order: the main streams of the in-flight slots, the
+        encoder streams (one per slot with `hip_slot_streams=2`, else only forward()'s "e0"), then the gather stream of prepare().  The order is not cosmetic:
+        ROCm binds a stream to a hardware queue when the stream is first USED, in order of first use, and where the model's busy streams sit among the queues
+        sets the pipelined rate for the life of the process - measured at c2 with two slots x two streams (tools/sessions/r05_s6.sh, r05_s7.sh, 200 steps):
+        the four next to each other, in any order, 757-769 keyframes/s; another stream first used between them 693-717; spread out with unused streams between
+        them 509-558.  Round 4 had a good order by accident of its call order (750); the first tree of round 5 lost 8 % when its first request happened to
+        launch on an encoder stream before the gather stream (r05_s1 - s5).  The GPU runs about four queues side by side, and four slots with ONE stream each
+        use them best (r05_s9: 820-827 against 762-766 for 2 x 2, 794 for 4 x 2, 744 for 5 x 1): the default.  So every stream gets one 4-byte launch here,
+        in `_STREAM_LAYOUT` order ("g" gather, "m<slot>" / "e<slot>" main / encoder stream of a slot, "_" an extra stream that only takes a queue);
+        MR_DIAG_STREAM_LAYOUT: experiments only."""
         key = str(device)
         if key not in self._dev_streams:
-            n_enc = self._in_flight if self._slot_streams_n == 2 else 1          # one stream per slot: only forward() has an encoder stream ("e0")
+            # one stream per slot: forward() borrows the next slot's stream for its encoder stage (_slot_streams); an "e0" only if there is no next slot
+            n_enc = self._in_flight if self._slot_streams_n == 2 else (1 if self._in_flight == 1 else 0)
             layout = _STREAM_LAYOUT or ",".join([f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"])
             names = layout.split(",")
             names += [n_ for n_ in [f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"] if n_ not in names]   # left out: behind
@@ -475,8 +486,9 @@ class MonoRecModel(nn.Module):
         return self._dev_streams[key]
 
     def _slot_streams(self, slot, device, own=False):
-        """{"main", "enc"} of an in-flight slot.  `own` = forward(): with one stream per slot the encoder stage of a forward() still gets a stream of its own
-        ("e0"; forward() calls are sequential, so they can share it whatever slot they run on)."""
+        """{"main", "enc"} of an in-flight slot.  `own` = forward(): with one stream per slot the encoder stage of a forward() still runs beside the cost volume -
+        on the NEXT slot's stream (its hardware queue is a neighbour of this slot's; a fifth stream behind the four slots shares a hardware pipe with the
+        first: forward() 566 -> 533 keyframes/s, r05_s10).  forward() calls are sequential; a submit() pending on that slot only delays the stage (stream order)."""
         st = self._streams.get((slot, str(device), bool(own)))
         if st is None:
             ds = self._device_streams(device)
@@ -485,7 +497,7 @@ class MonoRecModel(nn.Module):
             elif self._slot_streams_n == 2:
                 enc = ds[f"e{slot}"]
             else:
-                enc = ds["e0"] if own else ds[f"m{slot}"]
+                enc = ds[f"m{slot}"] if not own else (ds[f"m{(slot + 1) % self._in_flight}"] if self._in_flight > 1 else ds["e0"])
             st = {"main": ds[f"m{slot}"], "enc": enc}
             self._streams[(slot, str(device), bool(own))] = st
         return st

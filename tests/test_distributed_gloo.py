@@ -131,7 +131,7 @@ class _StubHandle:
 
 class _StubModel:
     """Stands in for MonoRecModel on the CPU: `submit()` derives a deterministic 'prediction' from the keyframe."""
-    _in_flight = 2
+    hip_in_flight = 2
 
     def eval(self):
         return self

@@ -973,11 +973,18 @@ def test_the_models_streams_are_created_once_in_a_fixed_order(hip_lib):
         orders.append(first)
     assert orders == ["prepare", "submit", "forward"]
     # the default since round 5: four slots with ONE stream each (820-827 keyframes/s at c2 against 762-766 for two slots x two streams, r05_s9); only
-    # forward() - one keyframe at a time - keeps its encoder stage on a second stream
+    # forward() - one keyframe at a time - keeps its encoder stage on a second stream: the next slot's
     m, _ = _model(8, graph=False, in_flight=4)
     with torch.no_grad():
         m.submit(dict(batch)).synchronize()
     ds = m._dev_streams[str(torch.device(DEV))]
-    assert [k for k in ds if k != "_pads"] == ["m0", "m1", "m2", "m3", "e0", "g"]
+    assert [k for k in ds if k != "_pads"] == ["m0", "m1", "m2", "m3", "g"]
     sub, own = m._slot_streams(2, torch.device(DEV)), m._slot_streams(2, torch.device(DEV), own=True)
-    assert sub["enc"] is sub["main"] is ds["m2"] and own["main"] is ds["m2"] and own["enc"] is ds["e0"]
+    assert sub["enc"] is sub["main"] is ds["m2"] and own["main"] is ds["m2"] and own["enc"] is ds["m3"]
+    assert m._slot_streams(3, torch.device(DEV), own=True)["enc"] is ds["m0"]
+    # one slot: two streams (the encoder stage beside the cost volume), as in rounds 2-4
+    m, _ = _model(8, graph=False, in_flight=1)
+    with torch.no_grad():
+        m(dict(batch))
+    ds = m._dev_streams[str(torch.device(DEV))]
+    assert [k for k in ds if k != "_pads"] == ["m0", "e0", "g"] and m._slot_streams(0, torch.device(DEV))["enc"] is ds["e0"]

@@ -193,7 +193,9 @@ __device__ __forceinline__ void dbg_stamp(const ConvKArgs& a, int k) {
 #else
     if ((a.dbg & 16) && threadIdx.x == 0) {
         const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
-        ((unsigned long long*)a.ws)[wg * 12 + k] = (k == 9 || k == 10) ? clock64() : wall_clock64();
+        // split-K launches keep their slabs at the head of the workspace: the stamps go behind them (tools/wg_timeline.py sizes the buffer)
+        float* base = a.ws + (a.ksplit > 1 ? (long long)a.ksplit * a.nphase * a.batch * (a.CB * 16) * a.Ho * a.Wo : 0);
+        ((unsigned long long*)base)[wg * 12 + k] = (k == 9 || k == 10) ? clock64() : wall_clock64();
     }
 #endif
 }

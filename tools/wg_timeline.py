@@ -43,12 +43,17 @@ def main():
         w = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
         b = torch.randn(cout, generator=g)
         pw = [torch.randn(cout, cin, kh, kw, generator=g) * 0.05 for _ in range(nph)] if nph > 1 else None
-        sched = (c["mb"], c["nb"], 1, c["ck"], c.get("waves", 4))          # stamps live in the workspace: split_k forced to 1
+        sched = (c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4), c.get("kws", 0))    # the product's schedule, split-K included
         p, fn = build_candidate(spec, sched, (srcs, out, res_t, w if nph == 1 else None, b, pw))
         desc = [k for k in p.keep if isinstance(k, _lib.ConvDesc)][0]
         wgs = p.conv_log[0]["wgs"]
-        stamps = torch.zeros(wgs * 12, dtype=torch.int64, device="cuda")
-        desc.workspace = stamps.data_ptr()
+        # the stamps live in the workspace, behind the split-K slabs (dbg_stamp in csrc/conv_mfma.hip)
+        n_, co_, oh_, ow_ = spec["out_shape"][0], (cout + 15) // 16 * 16, spec["grid"][0], spec["grid"][1]
+        slab_floats = c["split_k"] * nph * n_ * co_ * oh_ * ow_ if c["split_k"] > 1 else 0
+        assert slab_floats % 2 == 0
+        ws = torch.zeros(slab_floats // 2 + wgs * 12, dtype=torch.int64, device="cuda")
+        stamps = ws[slab_floats // 2:]
+        desc.workspace = ws.data_ptr()
         s = torch.cuda.current_stream().cuda_stream
         for _ in range(5):
             fn(s)

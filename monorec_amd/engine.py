@@ -155,7 +155,7 @@ class _Ref:
 # sessions (A/B of a candidate table, of one kernel family); a stray one must not pass silently: `active_env_overrides()` is
 # echoed into bench.py's config block, and the first plan built under any of them warns once.
 ENV_OVERRIDES = ("MR_TUNED_SCHEDULES", "MR_TUNED_WINOGRAD", "MR_B8", "MR_B8_NB4", "MR_WINOGRAD", "MR_ONE_CHANNEL_KERNELS", "MR_HIP_LIBRARY",
-                 "MR_DIAG_STREAM_LAYOUT", "MR_DIAG_STREAM_PRIO", "MR_DIAG_FILL_PACE_US")
+                 "MR_DIAG_STREAM_LAYOUT", "MR_DIAG_STREAM_PRIO")
 _warned_env = [False]
 
 

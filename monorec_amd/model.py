@@ -238,7 +238,6 @@ HOST_SPIN_SECONDS = 0.004       # longest busy-poll of _host_wait before it fall
 
 import os as _os
 _STREAM_LAYOUT = _os.environ.get("MR_DIAG_STREAM_LAYOUT")                  # diagnostic: creation / first-use order of the model's streams (MonoRecModel._device_streams)
-_FILL_PACE = float(_os.environ.get("MR_DIAG_FILL_PACE_US", "0")) * 1e-6   # diagnostic: least spacing of submit() calls into a pipeline that is still filling
 _STREAM_PRIO = _os.environ.get("MR_DIAG_STREAM_PRIO", "")                  # diagnostic: kinds of streams ("m", "e", "g") created with high priority
 
 
@@ -353,7 +352,6 @@ class MonoRecModel(nn.Module):
         self._plans = {}
         self._graphs = {}
         self._streams = {}
-        self._last_submit = 0.0
         self._dev_streams = {}           # device -> every stream of this model there, created in one fixed order (_device_streams)
         self._consts = {}
         self._const_slab = {}
@@ -908,15 +906,6 @@ class MonoRecModel(nn.Module):
         # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time
         while len(plan.enqueued) >= self._queue_depth:
             _host_wait(plan.enqueued.popleft())
-        if _FILL_PACE > 0 and not own and self._in_flight > 1:
-            # diagnostic (tools/sessions/r05_s13.sh): keyframes submitted into an EMPTY pipeline within 2 ms of each other run in lock-step and keep completing
-            # in bursts (r05_s11); here the submits into a pipeline that is still filling are spaced out
-            busy = sum(1 for k_, p_ in self._plans.items() if k_[0] != slot and k_[1:] == key[1:] and getattr(p_, "enqueued", None)
-                       and not p_.enqueued[-1].query())
-            if busy < self._in_flight - 1:
-                while time.perf_counter() < self._last_submit + _FILL_PACE:
-                    time.sleep(0)
-        self._last_submit = time.perf_counter()
         start_time = time.time()
         # The launches below overwrite the slot's previous outputs: the host waits for whatever the caller's stream - and any other
         # stream that took results of this slot through `.result()` - has been given to do with them so far (host waits, not stream

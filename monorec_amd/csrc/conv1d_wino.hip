@@ -27,11 +27,17 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int WCK = 8;                                   // input channels per chunk (one per wave in the DMA phase)
 constexpr int RAW_PITCH = 40, RAW_ROWS = 10, RAW_PLANE = RAW_PITCH * RAW_ROWS;   // rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35
+// 1 x 3 (AXIS 0): tile t reads columns 2 t + 3 .. 2 t + 6 of its row - lane stride 2, so dword reads of the two channels of a 32-lane group always collide
+// (an even plane pitch keeps the parity of the bank): read as aligned 8-byte pairs from column 2 t + 2 instead, conflict free over the 64 banks of a
+// ds_read_b64 when the plane pitch is 32 mod 64 (tools/lds_banks.py)
+constexpr int RAW_PLANE_X = 416;
+static_assert(RAW_PLANE_X >= RAW_PLANE && RAW_PLANE_X % 64 == 32 && RAW_PLANE % 32 == 16, "plane pitches");
 constexpr int NPOS = 4;
 
 struct W1KArgs {
@@ -70,6 +76,11 @@ __device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const floa
                  "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
 }
+// One aligned 8-byte LDS read that stays one: left to itself hipcc drops the halves a caller does not use and re-pairs the rest into ds_read2_b32 -
+// two dword accesses with the 32-bank rule (volatile keeps the access whole; the explicit LDS address space keeps it a ds_ instruction)
+__device__ __forceinline__ f32x2 lds_pair(const float* p) {
+    return *(const volatile __attribute__((address_space(3))) f32x2*)(__attribute__((address_space(3))) const float*)p;
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
@@ -95,7 +106,8 @@ template <int AXIS, int MBW>
 __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int U_FLOATS = NPOS * 2 * MBW * 64;            // U fragments of one chunk: [p][c4][cout block][64 lanes]
-    constexpr int BUF = WCK * RAW_PLANE + U_FLOATS;          // one pipeline buffer: raw input region + U
+    constexpr int PLANE = AXIS == 0 ? RAW_PLANE_X : RAW_PLANE;
+    constexpr int BUF = WCK * PLANE + U_FLOATS;              // one pipeline buffer: raw input region + U
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
     int cs = 0, cc0 = 0;                                      // chunk cursor: source, first channel
     auto issue = [&](int q, int pb) {
         const unsigned buf_addr = lds_base + pb * BUF * 4;
-        const unsigned u_addr = buf_addr + WCK * RAW_PLANE * 4;
+        const unsigned u_addr = buf_addr + WCK * PLANE * 4;
         const float* wsrc = wgrp + (long long)q * U_FLOATS;
         if (wave < U_FLOATS / 256) dma_global_x4(u_addr + wave * 1024, wsrc + wave * 256 + lane * 4);     // 2 MBW <= 8 pieces of 1 KiB
         const i32x4 srd = make_srd(a.src[cs], a.src_bytes[cs]);
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
         const int so = ((b * a.src_c[cs] + cc0 + (cok ? wave : 0)) * HW) * 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (RAW_PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
+            if (voff4[i] != -2) dma_buffer_x4(buf_addr + wave * (PLANE * 4) + i * 1024, cok ? voff4[i] : -1, srd, so);
         cc0 += WCK;
         if (cc0 >= a.src_cpad[cs]) { cc0 = 0; ++cs; }
     };
@@ -141,21 +153,27 @@ __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
     issue(0, 0);
     // the 4 inputs of this lane's tile, channel lane >> 4 of a quad: offsets patch0 + i * pstep in its channel plane
     const int t = lane & 15;
-    const int patch0 = (lane >> 4) * RAW_PLANE + (AXIS == 0 ? (wave + 1) * RAW_PITCH + 2 * t + 3
-                                                            : (2 * (wave >> 1)) * RAW_PITCH + 4 + (wave & 1) * 16 + t);
-    constexpr int pstep = AXIS == 0 ? 1 : RAW_PITCH;
+    // AXIS 0: aligned pairs from column 2 t + 2 on (inputs = columns 2 t + 3 .. 2 t + 6); AXIS 1: rows 2 (wave >> 1) .. + 3 at column 4 + 16 (wave & 1) + t
+    const int patch0 = (lane >> 4) * PLANE + (AXIS == 0 ? (wave + 1) * RAW_PITCH + 2 * t + 2
+                                                        : (2 * (wave >> 1)) * RAW_PITCH + 4 + (wave & 1) * 16 + t);
     for (int q = 0; q < a.nchunks; ++q) {
         const int pb = q & 1;
         const float* raw = lds + pb * BUF;
-        const float* ub = raw + WCK * RAW_PLANE + lane;
+        const float* ub = raw + WCK * PLANE + lane;
         dma_wait_all();
         __syncthreads();                                      // raw + U of chunk q visible; everyone is done with the other buffer
         if (q + 1 < a.nchunks) issue(q + 1, pb ^ 1);
         float v[2][NPOS];                                     // B operands of this lane: (B^T d)[p] of channels 4 c4 + (lane >> 4)
 #pragma unroll
         for (int c4 = 0; c4 < 2; ++c4) {
-            const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE;
-            const float d0 = rp[0], d1 = rp[pstep], d2 = rp[2 * pstep], d3 = rp[3 * pstep];
+            const float* rp = raw + patch0 + c4 * 4 * PLANE;
+            float d0, d1, d2, d3;
+            if constexpr (AXIS == 0) {
+                const f32x2 g0 = lds_pair(rp), g1 = lds_pair(rp + 2), g2 = lds_pair(rp + 4);
+                d0 = g0.y; d1 = g1.x; d2 = g1.y; d3 = g2.x;
+            } else {
+                d0 = rp[0]; d1 = rp[RAW_PITCH]; d2 = rp[2 * RAW_PITCH]; d3 = rp[3 * RAW_PITCH];
+            }
             v[c4][0] = d0 - d2;
             v[c4][1] = d1 + d2;
             v[c4][2] = d2 - d1;
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(512) void conv1d3_wino_kernel(const W1KArgs a) {
 // Same skeleton as conv1d3_wino_kernel; what changes with (M outputs per tile, R taps), N = M + R - 1 positions:
 //   AXIS 0 (1 x R): wave = output row, lane & 15 = tile of M columns -> workgroup = 8 rows x 16 M columns, no vertical halo;
 //   AXIS 1 (R x 1): wave = (tile of M rows, half of the 32 columns) -> workgroup = 4 M rows x 32 columns, R - 1 halo rows;
-//   4 halo columns either side (16-byte groups; >= (R - 1) / 2), channel-plane pitch == 16 mod 32 banks; the transforms are the generated
+//   4 halo columns either side (16-byte groups; >= (R - 1) / 2), channel-plane pitch by the width of the patch reads (CtGeom::PLANE); the transforms are the generated
 //   straight-line chains of cooktoom_1d.h (dyadic coefficients), N accumulator sets per output-channel block.
 template <int M, int R> struct CtForm;
 template <> struct CtForm<4, 3> {
@@ -238,8 +256,14 @@ struct CtGeom {
     static constexpr int NG = ROWS * G4;                         // 16-byte groups of one channel plane
     static constexpr int NI = (NG + 63) / 64;                    // DMA instructions per plane (1 KiB each)
     static constexpr int PLANE0 = ROWS * PITCH;
-    static constexpr int PLANE = PLANE0 + ((16 - PLANE0 % 32) + 32) % 32;      // == 16 mod 32: the four channels of a B read on distinct banks
-    static_assert(PL <= 4 && PITCH % 4 == 0 && PLANE % 4 == 0 && PLANE % 32 == 16, "raw region layout");
+    // Plane pitch by what reads the patches (lane = 16 channel + tile; MI355X_MICROARCH.md, LDS; tools/lds_banks.py):
+    //   AXIS 1: dword reads at channel * PLANE + tile, two groups of 32 lanes over 32 banks -> 16 mod 32;
+    //   AXIS 0, M = 4: 16-byte reads at channel * PLANE + 4 tile, groups of 16 lanes ({0-3, 12-15, 20-27}, ...) over 64 banks: the two channels of a
+    //           group fill the 16 slots of a 256-byte row exactly when PLANE = 0 mod 64 (rounds 3-4 used 16 mod 32 here too: two cycles per group);
+    //   AXIS 0, M = 2: 8-byte reads at channel * PLANE + 2 tile, two groups of 32 lanes over 64 banks -> 32 mod 64.
+    static constexpr int PMOD = AXIS == 1 ? 32 : 64, PREM = AXIS == 1 ? 16 : (M == 4 ? 0 : 32);
+    static constexpr int PLANE = PLANE0 + ((PREM - PLANE0 % PMOD) + PMOD) % PMOD;
+    static_assert(PL <= 4 && PITCH % 4 == 0 && PLANE % 4 == 0 && PLANE % PMOD == PREM && PLANE >= PLANE0, "raw region layout");
 };
 
 template <int AXIS, int MBW, int M, int R>
@@ -553,7 +577,7 @@ int derive1(const mr_wino_desc* d, W1Derived* out, bool views = false) {
     const int groups = (d->out_channels + 16 * mbw - 1) / (16 * mbw);
     if (d->batch >= 65536 || groups >= 65536) return MR_ERR_UNSUPPORTED;
     out->grid = dim3((unsigned)(k.tiles_x * ((d->height + 7) / 8)), (unsigned)groups, (unsigned)d->batch);
-    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE + ufl)) * 4;
+    out->lds_bytes = (size_t)(2 * (WCK * RAW_PLANE_X + ufl)) * 4;     // (the larger of the two axes' plane pitches; the Upconv kernel and AXIS 1 use 400)
     out->mbw = mbw;
     return 0;
 }

@@ -29,11 +29,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int WCK = 8;                                   // input channels per chunk (one per wave in the DMA / transform phases)
-constexpr int RAW_PITCH = 40, RAW_ROWS = 10, RAW_PLANE = RAW_PITCH * RAW_ROWS;   // floats: rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35
+constexpr int RAW_PITCH = 40, RAW_ROWS = 10;             // floats: rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35
+// Plane pitch 32 mod 64 (400 -> 416): the in-register-transform kernels read the patch of tile t - columns 2 t + 3 .. 2 t + 6, lane = 16 channel + t - as
+// aligned 8-byte pairs from column 2 t + 2 on; a ds_read_b64 serves 32 lanes = two channels over 64 banks, conflict free when the second channel
+// starts 32 banks on.  (Until round 5 these were dword reads at lane stride 2 with a pitch of 16 mod 32: the two channels of a group always met on
+// the same 16 banks - an even pitch keeps the bank parity; tools/lds_banks.py.)  The LDS-transform kernel (channel = wave) does not care.
+constexpr int RAW_PLANE = 416;
+static_assert(RAW_PLANE >= RAW_PITCH * RAW_ROWS && RAW_PLANE % 64 == 32, "plane pitch");
 constexpr int V_PITCH = 80;                              // floats per (position, channel): 64 tiles + 16
 constexpr int V_FLOATS = 16 * WCK * V_PITCH;
 
@@ -74,6 +81,11 @@ __device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const floa
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
+}
+// One aligned 8-byte LDS read that stays one: left to itself hipcc drops the halves a caller does not use and re-pairs the rest into ds_read2_b32 -
+// two dword accesses with the 32-bank rule (volatile keeps the access whole; the explicit LDS address space keeps it a ds_ instruction)
+__device__ __forceinline__ f32x2 lds_pair(const float* p) {
+    return *(const volatile __attribute__((address_space(3))) f32x2*)(__attribute__((address_space(3))) const float*)p;
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -242,8 +254,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoKArgs a) {
 // the last 32-channel workgroup multiplying zero weights.  The tail group is produced by workgroups of another shape instead: 16 x 32
 // output pixels (8 tile rows, one per wave) x ONE block of 16 channels - the same 8 (tile row, channel block) units of work per
 // workgroup, the same sweep (16 positions x 2 channel quads MFMAs per wave and chunk), one A read per MFMA.  Raw region 18 rows x 40
-// columns (plane pitch 720 floats = 16 mod 32 banks, like 400), U fragments of a chunk 8 KiB.
-constexpr int RAW_ROWS_T = 18, RAW_PLANE_T = RAW_PITCH * RAW_ROWS_T;
+// columns (plane pitch 736 floats = 32 mod 64 banks, like 416), U fragments of a chunk 8 KiB.
+constexpr int RAW_ROWS_T = 18, RAW_PLANE_T = 736;         // 720 -> 32 mod 64, as RAW_PLANE
+static_assert(RAW_PLANE_T >= RAW_PITCH * RAW_ROWS_T && RAW_PLANE_T % 64 == 32, "plane pitch");
 constexpr int U_FLOATS_T = 16 * 2 * 64;
 constexpr int BUF_T = WCK * RAW_PLANE_T + U_FLOATS_T;
 
@@ -291,7 +304,7 @@ __device__ __forceinline__ void wino_rb_tail(const WinoKArgs& a, float* lds) {
 
     issue(0, 0);
     const int tb = wave;                                      // tile row 0..7
-    const int patch0 = (lane >> 4) * RAW_PLANE_T + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 3;
+    const int patch0 = (lane >> 4) * RAW_PLANE_T + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 2;      // aligned pairs; the patch starts one column on
     for (int q = 0; q < a.nchunks; ++q) {
         const int pb = q & 1;
         const float* raw = lds + pb * BUF_T;
@@ -305,9 +318,10 @@ __device__ __forceinline__ void wino_rb_tail(const WinoKArgs& a, float* lds) {
             const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE_T;
             float d[4][4], t[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[r][c] = rp[r * RAW_PITCH + c];
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 g0 = lds_pair(rp + r * RAW_PITCH), g1 = lds_pair(rp + r * RAW_PITCH + 2), g2 = lds_pair(rp + r * RAW_PITCH + 4);
+                d[r][0] = g0.y; d[r][1] = g1.x; d[r][2] = g1.y; d[r][3] = g2.x;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 t[0][c] = d[0][c] - d[2][c];
@@ -377,7 +391,7 @@ __device__ __forceinline__ void wino_rb_tail(const WinoKArgs& a, float* lds) {
 // reads per lane and chunk), ONE barrier per chunk instead of two; the price is that the two waves of a tile row (the cout halves)
 // both transform its patches.  Same products in the same order per accumulator as the kernel above: bit-identical outputs.
 template <int MBW>
-__global__ __launch_bounds__(512) void conv3x3_wino_rb_kernel(const WinoKArgs a) {
+__global__ __launch_bounds__(512, MBW == 1 ? 4 : 2) void conv3x3_wino_rb_kernel(const WinoKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (MBW == 1 && (int)blockIdx.y == a.tail_grp) { wino_rb_tail(a, lds); return; }      // 16-channel tail group: 16-row workgroups
     constexpr int U_FLOATS = 16 * 2 * (2 * MBW) * 64;
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_rb_kernel(const WinoKArgs a)
 
     issue(0, 0);
     const int tb = wave & 3, chalf = wave >> 2;
-    const int patch0 = (lane >> 4) * RAW_PLANE + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 3;   // channel lane >> 4, tile (tb, lane & 15)
+    const int patch0 = (lane >> 4) * RAW_PLANE + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 2;   // channel lane >> 4, tile (tb, lane & 15): aligned pairs, the patch starts one column on
     for (int q = 0; q < a.nchunks; ++q) {
         const int pb = q & 1;
         const float* raw = lds + pb * BUF;
@@ -440,9 +454,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino_rb_kernel(const WinoKArgs a)
             const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE;
             float d[4][4], t[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[r][c] = rp[r * RAW_PITCH + c];
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 g0 = lds_pair(rp + r * RAW_PITCH), g1 = lds_pair(rp + r * RAW_PITCH + 2), g2 = lds_pair(rp + r * RAW_PITCH + 4);
+                d[r][0] = g0.y; d[r][1] = g1.x; d[r][2] = g1.y; d[r][3] = g2.x;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 t[0][c] = d[0][c] - d[2][c];

@@ -11,8 +11,8 @@
 //
 // Skeleton = the in-register-transform kernels (conv3x3_wino_rb_kernel, conv1d_ct_kernel): workgroup = 8 waves = 4 tile rows x 2 blocks of 16
 // output channels: 16 x 64 output pixels x 32 channels; K in chunks of 8 input channels; the haloed region (18 rows x 72 columns per channel, plane
-// pitch 1296 = 16 mod 32 banks, hardware zero fill = padding) and the chunk's U fragments (36 positions; host-packed G g G^T, formed in double and
-// rounded once) arrive by LDS-DMA in one of two pipeline buffers (2 x 76.5 KB: one workgroup per CU - the 36 accumulator sets need 144 of a wave's
+// pitch 1344 = 0 mod 64 banks - see PLANE -, hardware zero fill = padding) and the chunk's U fragments (36 positions; host-packed G g G^T, formed in double and
+// rounded once) arrive by LDS-DMA in one of two pipeline buffers (2 x 78 KB: one workgroup per CU - the 36 accumulator sets need 144 of a wave's
 // 256 registers, so two waves per SIMD is what fits anyway); ONE barrier per chunk.  A lane reads the 6x6 patch of its (tile, channel) as 18
 // 16-byte LDS reads, transforms rows then columns with the generated F(4,3) chain (one channel quad at a time: 36 live B operands), reads the
 // quad's 36 A operands up front and issues 36 MFMAs (a variant with ONE 16-byte read per patch row and the outer columns from the
@@ -40,10 +40,14 @@ constexpr int RH = 16, RW = 64;                          // output pixels per wo
 constexpr int ROWS = RH + 2, PITCH = RW + 8;             // raw region: rows oy0 - 1 .. oy0 + 16, columns ox0 - 4 .. ox0 + 67
 constexpr int G4 = PITCH / 4, NG = ROWS * G4;            // 16-byte groups per channel plane (324)
 constexpr int NI = (NG + 63) / 64;                       // DMA instructions per plane (6)
-constexpr int PLANE = ROWS * PITCH;                      // 1296 floats = 16 mod 32 banks
+// Plane pitch: a patch read is a ds_read_b128 at (lane >> 4) * PLANE + 4 (lane & 15) + const: served in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...
+// MI355X_MICROARCH.md, LDS) over 64 banks, i.e. conflict free when the 16 lanes of a group - two channels - hit 16 distinct 16-byte slots of a 256-byte
+// row: PLANE = 0 mod 64 floats.  (Rounds 3-4 ran the dword rule "16 mod 32" here - 1296 - which puts lanes 12-15 of one channel on the slots of lanes
+// 20-23 of the next: every group took two cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 33 % in profiles/r04_c3_pmc_summary.json; tools/lds_banks.py.)
+constexpr int PLANE = (ROWS * PITCH + 63) / 64 * 64;     // 1296 -> 1344 floats
 constexpr int U_FLOATS = NP * 2 * 2 * 64;                // U fragments of one chunk: [channel quad][cout block][j][64 lanes][i]
 constexpr int BUF = WCK * PLANE + U_FLOATS;              // one pipeline buffer
-static_assert(PLANE % 32 == 16 && PLANE % 4 == 0 && U_FLOATS % 256 == 0, "layout");
+static_assert(PLANE % 64 == 0 && PLANE >= ROWS * PITCH && U_FLOATS % 256 == 0 && 2 * BUF * 4 <= 160 * 1024, "layout");
 
 struct W44KArgs {
     const float* src[MR_MAX_SOURCES];

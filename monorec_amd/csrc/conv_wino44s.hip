@@ -11,7 +11,7 @@
 //     K loop;
 //   * the vertical input transform of a half needs only 5 of the 6 patch rows (B^T of F(4,3): rows 0-2 read d0..d4, rows 3-5 read d1..d5) and is
 //     accumulated row by row as the patch rows arrive from LDS (no 36-register patch); the horizontal transform is the generated ct_input_4_3 chain;
-//   * K in chunks of ONE channel quad (4 channels): 2 x (11.25 KB raw region + 24 KB of U) = 70.5 KB of LDS, ~125 registers: two workgroups per CU,
+//   * K in chunks of ONE channel quad (4 channels): 2 x (12 KB raw region + 24 KB of U) = 72 KB of LDS, ~125 registers: two workgroups per CU,
 //     four waves per SIMD from two barrier domains.
 // Workgroup = 8 waves = 2 tile rows x 2 blocks of 16 output channels x 2 position halves: 8 x 64 output pixels x 32 channels.  Same arithmetic per
 // product as conv_wino44.hip (same U = G g G^T, same B^T d B); the output transform adds its two partial tiles in a fixed order (half 0 + half 1).
@@ -34,10 +34,10 @@ constexpr int RH = 8, RW = 64;                           // output pixels per wo
 constexpr int ROWS = RH + 2, PITCH = RW + 8;             // raw region: rows oy0 - 1 .. oy0 + 8, columns ox0 - 4 .. ox0 + 67
 constexpr int G4 = PITCH / 4, NG = ROWS * G4;            // 16-byte groups per channel plane (180)
 constexpr int NI = (NG + 63) / 64;                       // DMA instructions per plane (3)
-constexpr int PLANE = ROWS * PITCH;                      // 720 floats = 16 mod 32 banks
+constexpr int PLANE = (ROWS * PITCH + 63) / 64 * 64;     // 720 -> 768 floats = 0 mod 64 banks: the 16-byte patch reads are conflict free (see conv_wino44.hip)
 constexpr int U_FLOATS = 2 * 2 * 3 * 2 * 64 * 4;         // U of one chunk: [block][half][ii][jh][64 lanes][4: j = 4 jh + 0..3; j = 6, 7 are zero pads] = 24 KB
-constexpr int BUF = SCK * PLANE + U_FLOATS;              // one pipeline buffer (35.25 KB)
-static_assert(PLANE % 32 == 16 && PLANE % 4 == 0 && U_FLOATS % 256 == 0 && 2 * BUF * 4 <= 80 * 1024, "layout: two workgroups per CU");
+constexpr int BUF = SCK * PLANE + U_FLOATS;              // one pipeline buffer (36 KB)
+static_assert(PLANE % 64 == 0 && PLANE >= ROWS * PITCH && U_FLOATS % 256 == 0 && 2 * BUF * 4 <= 80 * 1024, "layout: two workgroups per CU");
 
 struct W44SArgs {
     const float* src[MR_MAX_SOURCES];

@@ -1,42 +1,44 @@
 #!/bin/bash
-# Round 5, session 14 (final library): whole gpu suite + smoke, profile sets of c2 / c3 / configs[4] bf16 regenerated on ABI 18 (stamped per plan), the lines that quote them.
+# Round 5, session 14: LDS bank conflicts of the patch / B-fragment reads taken out (tools/lds_banks.py): plane pitches of conv_wino44 / 44s / the 1 x k Cook-Toom
+# forms / conv_b8 re-derived for 16-byte reads (64 banks, groups of 16 lanes); the lane-stride-2 patch reads of the in-register-transform kernels
+# (F(2x2,3x3), ConvTranspose F(2x2,2x2), F(2,3) 1 x 3) as aligned 8-byte reads on a 32-mod-64 pitch.  Parity of every kernel, then old library (ab_old/) against new.
 cd "$(dirname "$0")/../.." || exit 1
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/r05_s14
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider > $OUT/suite.log 2>&1; echo "suite rc=$?"; tail -3 $OUT/suite.log | cut -c1-300
-timeout 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
-bash tools/profile_round.sh r05_c2 > $OUT/profile_c2.log 2>&1; echo "profile c2 rc=$?"
-bash tools/profile_round.sh r05_c3 "--batch 8 --frames 4 --depths 64" 20 > $OUT/profile_c3.log 2>&1; echo "profile c3 rc=$?"
-bash tools/profile_round.sh r05_c5bf16 "--height 512 --width 1024 --frames 4 --depths 48 --bf16" 20 > $OUT/profile_c5bf16.log 2>&1; echo "profile c5bf16 rc=$?"
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_style.json 2> $OUT/driver_style.err; echo "driver-style rc=$?"
-timeout 200 python bench.py --steps 200 --no-primer --no-cpu-baseline --in-flight 1 > $OUT/c2_inflight1.json 2> /dev/null
-timeout 200 python bench.py --steps 200 --no-primer --no-cpu-baseline --no-forward-api --in-flight 2 --slot-streams 2 > $OUT/c2_2x2.json 2> /dev/null
-timeout 200 python bench.py --steps 40 --batch 8 --frames 4 --depths 64 --no-primer --no-cpu-baseline > $OUT/c3.json 2> /dev/null
-timeout 200 python bench.py --steps 40 --batch 8 --frames 4 --depths 64 --no-primer --no-cpu-baseline --no-forward-api --cv-separable > $OUT/c3_separable.json 2> /dev/null
-timeout 200 python bench.py --steps 60 --height 512 --width 1024 --frames 4 --depths 48 --bf16 --no-cpu-baseline --no-primer > $OUT/c5_bf16.json 2> /dev/null
-timeout 200 python bench.py --steps 60 --height 512 --width 1024 --frames 4 --depths 48 --bf16 --lean-outputs --no-cpu-baseline --no-primer --no-forward-api > $OUT/c5_bf16_lean.json 2> /dev/null
-timeout 200 python bench.py --steps 60 --height 512 --width 1024 --frames 4 --depths 48 --no-cpu-baseline --no-primer --no-forward-api > $OUT/c5_f32.json 2> /dev/null
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_b8.py -m gpu -q --maxfail=20 -p no:cacheprovider > $OUT/kernels.log 2>&1; echo "kernel tests rc=$?"; tail -15 $OUT/kernels.log | cut -c1-250
+OLD=$REPO/ab_old/libmonorec_hip.so
+run() {  # tag lib args...
+  tag=$1; lib=$2; shift 2
+  if [ "$lib" = old ]; then export MR_HIP_LIBRARY=$OLD; else unset MR_HIP_LIBRARY; fi
+  timeout 300 python bench.py --no-cpu-baseline --no-primer --no-forward-api --dump-layers $OUT/layers_${tag}_$lib.json "$@" > $OUT/${tag}_$lib.json 2>/dev/null
+  python - "$tag" "$lib" $OUT/${tag}_$lib.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+print(sys.argv[1], sys.argv[2], round(d["value"], 1), "kf/s; sum of kernels ms", round(d["device_ms_per_step_sum_of_kernels"], 3))
+PY
+  unset MR_HIP_LIBRARY
+}
+for rep in 1 2; do
+  for lib in old new; do
+    run c2_$rep $lib --steps 200
+    run c3_$rep $lib --steps 40 --batch 8 --frames 4 --depths 64
+    run c5bf16_$rep $lib --steps 60 --height 512 --width 1024 --frames 4 --depths 48 --bf16
+  done
+done
 python - <<'PY'
 import json
-for f in ("driver_style", "c2_inflight1", "c2_2x2", "c3", "c3_separable", "c5_bf16", "c5_bf16_lean", "c5_f32"):
-    try:
-        d = json.loads(open(f"gpurun_out/r05_s14/{f}.json").read().strip().splitlines()[-1])
-        r = d["roofline"]
-        fa = d.get("forward_api", {}).get("value")
-        print(f, round(d["value"], 1), "kf/s; 200:", d.get("value_200_steps") and round(d["value_200_steps"], 1), "primed", d.get("value_host_primed") and round(d["value_host_primed"], 1),
-              "forward_api", fa and round(fa, 1), "bound", r["bound"], "frac", round(r["frac"], 3), r.get("frac_source"),
-              "vs_direct", r.get("vs_direct_conv_ceiling") and round(r["vs_direct_conv_ceiling"], 3), "pipelined", round(r["frac_pipelined"], 3), "stale" if "stale_profile" in r else "current",
-              "launches", r.get("all_kernel_launches_per_step"), "host inputs", d.get("with_host_inputs", {}).get("value"), "cpu", d.get("cpu_baseline", {}).get("value"))
-    except Exception as e:
-        print(f, "failed", repr(e))
+for cfg in ("c2", "c3", "c5bf16"):
+    tot = {}
+    for lib in ("old", "new"):
+        rows = {}
+        for rep in (1, 2):
+            for r in json.load(open(f"gpurun_out/r05_s14/layers_{cfg}_{rep}_{lib}.json")):
+                rows.setdefault(r["name"], []).append(r["seconds"] * 1e6)
+        tot[lib] = {k: min(v) for k, v in rows.items()}
+    print(cfg, "sum of kernels us: old", round(sum(tot["old"].values()), 1), "new", round(sum(tot["new"].values()), 1))
+    ch = sorted(((tot["new"][k] - tot["old"][k], k) for k in tot["old"] if k in tot["new"]))
+    for dlt, k in ch[:14] + ch[-6:]:
+        if abs(dlt) > 0.02 * tot["old"][k] and abs(dlt) > 0.3:
+            print("   %-34s %8.1f -> %8.1f us (%+.1f %%)" % (k, tot["old"][k], tot["new"][k], 100 * dlt / tot["old"][k]))
 PY
-tail -1 $OUT/driver_style.json > profiles/r05_c2_bench_driver_style.json
-tail -1 $OUT/c2_inflight1.json > profiles/r05_c2_inflight1_line.json
-tail -1 $OUT/c2_2x2.json > profiles/r05_c2_two_slots_two_streams_line.json
-tail -1 $OUT/c3.json > profiles/r05_c3_line.json
-tail -1 $OUT/c3_separable.json > profiles/r05_c3_separable_line.json
-tail -1 $OUT/c5_bf16.json > profiles/r05_c5bf16_line.json
-tail -1 $OUT/c5_bf16_lean.json > profiles/r05_c5bf16_lean_line.json
-tail -1 $OUT/c5_f32.json > profiles/r05_c5_f32_line.json
-mkdir -p $OUT/profiles && cp profiles/r05_* $OUT/profiles/ 2>/dev/null; ls $OUT/profiles | wc -l

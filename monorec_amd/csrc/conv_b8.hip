@@ -56,8 +56,7 @@ struct B8Args {
     const float* bias;
     int act;
     float p0;
-    int tiles_x, TH, IH, IW, PLANE;  // PLANE: 16-byte positions between the channel blocks of a staged tile (>= NPOS, see derive8)
-    int NPOS;                        // IH * IW: positions of the haloed tile
+    int tiles_x, TH, IH, IW, PLANE;
     int ntiles, tiles_per_wg;        // a workgroup walks tiles_per_wg consecutive tiles
     int nphase, batch;
     const void* w[4];
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
 #pragma unroll
     for (int j = 0; j < B8_MAX_PPT; ++j) {
         const int p = tid + 64 * WV * j;
-        live[j] = p < a.NPOS;
+        live[j] = p < PLANE;
         piy[j] = p / a.IW;
         pix_[j] = p - piy[j] * a.IW;
     }
@@ -577,14 +576,11 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     const int tiles_y = (d->out_h + k.TH - 1) / k.TH;
     k.IH = (k.TH - 1) * k.SH + k.KH;
     k.IW = 31 * k.SW + k.KW;
-    k.NPOS = k.IH * k.IW;
-    if ((k.NPOS + 64 * wv - 1) / (64 * wv) > B8_MAX_PPT) return MR_ERR_UNSUPPORTED;
-    // Pitch between the four channel blocks of a staged tile, in 16-byte positions.  A B fragment is one ds_read_b128 per lane at block (lane >> 4),
-    // position base + SW (lane & 15), served in groups of 16 lanes = 8 + 8 lanes of two blocks ({0-3, 12-15, 20-27}, ...; MI355X_MICROARCH.md, LDS)
-    // over the 16 slots of a 256-byte row: conflict free when the second block's positions fall on the slots the first leaves free - pitch = 0 mod 16
-    // at column stride 1 (the first block takes slots 0-3, 12-15, the second 4-11), an odd pitch at column stride 2 (even / odd slots).  Until round 5
-    // the pitch was IH * IW (136, 204, ... : two cycles per group; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 35 % in profiles/r04_c5bf16_pmc_summary.json).
-    k.PLANE = k.SW == 2 ? (k.NPOS | 1) : (k.NPOS + 15) / 16 * 16;
+    // (IH * IW positions between the four channel blocks: by the bank arithmetic of tools/lds_banks.py a pitch of 0 mod 16 - odd at column stride 2 - makes the
+    // 16-byte B-fragment reads conflict free, and it measured 0.8 % SLOWER over the configs[4] keyframe (tools/sessions/r05_s14.sh): these reads cost their
+    // latency, not LDS cycles.  Not kept.)
+    k.PLANE = k.IH * k.IW;
+    if ((k.PLANE + 64 * wv - 1) / (64 * wv) > B8_MAX_PPT) return MR_ERR_UNSUPPORTED;
     const long long ntiles = (long long)k.tiles_x * tiles_y;
     if (ntiles >= (1ll << 31) || ngroups >= 65536 || (long long)d->batch * nphase >= 65536) return MR_ERR_UNSUPPORTED;
     k.ntiles = (int)ntiles;

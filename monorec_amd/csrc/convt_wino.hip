@@ -22,17 +22,14 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int WCK = 8;
-constexpr int RAW_PITCH = 40, RAW_ROWS = 10;             // rows y0 - pt .. (9 used), columns x0 - 4 .. x0 + 35
-// Plane pitch 32 mod 64 (400 -> 416): the in-register-transform kernels read the 3 patch columns of tile t (from column 2 t + 4 - pl on; lane = 16 channel + t)
-// as two aligned 8-byte pairs from column 2 t + 4 - 2 pl: a ds_read_b64 serves two channels over 64 banks, conflict free when the second starts 32 banks
-// on (dword reads at lane stride 2 always met on the same 16 banks; see conv_wino.hip, tools/lds_banks.py)
-constexpr int RAW_PLANE = 416;
-static_assert(RAW_PLANE >= RAW_PITCH * RAW_ROWS && RAW_PLANE % 64 == 32, "plane pitch");
+constexpr int RAW_PITCH = 40, RAW_ROWS = 10, RAW_PLANE = RAW_PITCH * RAW_ROWS;   // rows y0 - pt .. (9 used), columns x0 - 4 .. x0 + 35
+// (The in-register-transform kernels below read their patches as dwords at lane stride 2: the two channels of a 32-lane group meet on the same 16 banks
+// - tools/lds_banks.py.  The fix that pays in conv_wino.hip - aligned 8-byte reads on a 32-mod-64 pitch - was 2-8 % SLOWER here (tools/sessions/r05_s14.sh:
+// two pairs cover 4 columns and the 3 wanted ones sit at a parity-dependent offset, a select per element); not kept.)
 constexpr int V_PITCH = 80;                                                      // 64 tiles + 16: channel pitch = 16 mod 32 banks
 constexpr int NPOS = 9;
 constexpr int V_FLOATS = NPOS * WCK * V_PITCH;
@@ -76,11 +73,6 @@ __device__ __forceinline__ void dma_global_x1(unsigned lds_byte_addr, const floa
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                  "global_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
-}
-// One aligned 8-byte LDS read that stays one: left to itself hipcc drops the halves a caller does not use and re-pairs the rest into ds_read2_b32 -
-// two dword accesses with the 32-bank rule (volatile keeps the access whole; the explicit LDS address space keeps it a ds_ instruction)
-__device__ __forceinline__ f32x2 lds_pair(const float* p) {
-    return *(const volatile __attribute__((address_space(3))) f32x2*)(__attribute__((address_space(3))) const float*)p;
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -241,8 +233,7 @@ __global__ __launch_bounds__(512) void convt4x4_wino_kernel(const WinoTKArgs a) 
 // ---- 16-channel tail of the in-register-transform kernel (variant 2; as wino_rb_tail in conv_wino.hip) ---------------------------------
 // out_channels = 32 a + r, 0 < r <= 16 (depth.dec3: 48): the tail channels come from workgroups of 16 x 32 input positions x ONE block of
 // 16 channels (8 tile rows, one per wave) instead of a half-empty 32-channel group.  Raw region 18 rows x 40 columns, U of a chunk 4.5 KiB.
-constexpr int RAW_ROWS_TT = 18, RAW_PLANE_TT = 736;       // 720 -> 32 mod 64, as RAW_PLANE
-static_assert(RAW_PLANE_TT >= RAW_PITCH * RAW_ROWS_TT && RAW_PLANE_TT % 64 == 32, "plane pitch");
+constexpr int RAW_ROWS_TT = 18, RAW_PLANE_TT = RAW_PITCH * RAW_ROWS_TT;
 constexpr int U_FLOATS_TT = NPOS * 2 * 64;                   // 1152
 constexpr int U_PAD_TT = (U_FLOATS_TT + 255) & ~255;         // 1280
 constexpr int BUF_TT = WCK * RAW_PLANE_TT + U_PAD_TT;
@@ -296,7 +287,7 @@ __device__ __forceinline__ void convt_rb_tail(const WinoTKArgs& a, float* lds) {
 
     issue(0, 0);
     const int tb = wave;
-    const int patch0 = (lane >> 4) * RAW_PLANE_TT + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 4 - 2 * pl;      // aligned pairs; the patch starts pl columns on
+    const int patch0 = (lane >> 4) * RAW_PLANE_TT + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 4 - pl;
     for (int q = 0; q < a.nchunks; ++q) {
         const int pb = q & 1;
         const float* raw = lds + pb * BUF_TT;
@@ -310,10 +301,9 @@ __device__ __forceinline__ void convt_rb_tail(const WinoTKArgs& a, float* lds) {
             const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE_TT;
             float d[3][3], t[3][3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const f32x2 g0 = lds_pair(rp + r * RAW_PITCH), g1 = lds_pair(rp + r * RAW_PITCH + 2);
-                d[r][0] = pl ? g0.y : g0.x; d[r][1] = pl ? g1.x : g0.y; d[r][2] = pl ? g1.y : g1.x;
-            }
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[r][c] = rp[r * RAW_PITCH + c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 t[0][c] = d[0][c] - d[1][c];
@@ -428,7 +418,7 @@ __global__ __launch_bounds__(512) void convt4x4_wino_rb_kernel(const WinoTKArgs 
 
     issue(0, 0);
     const int tb = wave & 3, chalf = wave >> 2;
-    const int patch0 = (lane >> 4) * RAW_PLANE + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 4 - 2 * pl;   // channel lane >> 4, tile (tb, lane & 15): aligned pairs, the patch starts pl columns on
+    const int patch0 = (lane >> 4) * RAW_PLANE + (2 * tb) * RAW_PITCH + 2 * (lane & 15) + 4 - pl;   // channel lane >> 4, tile (tb, lane & 15)
     for (int q = 0; q < a.nchunks; ++q) {
         const int pb = q & 1;
         const float* raw = lds + pb * BUF;
@@ -442,10 +432,9 @@ __global__ __launch_bounds__(512) void convt4x4_wino_rb_kernel(const WinoTKArgs 
             const float* rp = raw + patch0 + c4 * 4 * RAW_PLANE;
             float d[3][3], t[3][3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const f32x2 g0 = lds_pair(rp + r * RAW_PITCH), g1 = lds_pair(rp + r * RAW_PITCH + 2);
-                d[r][0] = pl ? g0.y : g0.x; d[r][1] = pl ? g1.x : g0.y; d[r][2] = pl ? g1.y : g1.x;
-            }
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[r][c] = rp[r * RAW_PITCH + c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 t[0][c] = d[0][c] - d[1][c];

@@ -1059,17 +1059,15 @@ class Plan:
             th = waves * nb // 2
             ih, iw = (th - 1) * sh + kh, 31 * sw + kw
             plane = ih * iw
-            pitch = (plane | 1) if sw == 2 else (plane + 15) // 16 * 16          # block pitch of the staged tile (derive8: conflict-free B reads)
             wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * groups * batch * phases
-            lds = 2 * (64 * pitch + 1024 * kh * kw * mb)
+            lds = 2 * (64 * plane + 1024 * kh * kw * mb)
             if lds <= 160 * 1024 and plane <= 2 * 64 * waves and (wgs >= (1024 if nb == 4 else 512) or (waves, nb) == (4, 1)):
                 return mb, nb, waves
         for waves, nb in ((8, 2), (8, 1), (4, 2), (4, 1)):          # whatever launches
             th = waves * nb // 2
             plane = ((th - 1) * sh + kh) * (31 * sw + kw)
-            pitch = (plane | 1) if sw == 2 else (plane + 15) // 16 * 16
             for m in (mb, 2, 1):
-                if 2 * (64 * pitch + 1024 * kh * kw * m) <= 160 * 1024 and plane <= 2 * 64 * waves:
+                if 2 * (64 * plane + 1024 * kh * kw * m) <= 160 * 1024 and plane <= 2 * 64 * waves:
                     return m, nb, waves
         raise ValueError("no launchable B8 schedule")
 

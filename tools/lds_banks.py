@@ -3,6 +3,9 @@
 one LDS cycle per group when every bank of the group is asked for at most one distinct address; N distinct addresses on a bank = N cycles.
 
     python tools/lds_banks.py            # the patterns of csrc/*.hip, current and candidate plane pitches
+
+What the arithmetic bought on the MI355X (tools/sessions/r05_s14.sh, old library against new): F(2x2,3x3) with the transform in registers -7.5 %, F(4x4,3x3) -2 %,
+the 1 x k Cook-Toom forms -1 %; the same change lost in convt4x4_wino_rb_kernel (+2 ... +8 %) and in conv_b8_kernel's block pitch (+0.8 %) - not kept there.
 """
 import sys
 

@@ -310,7 +310,7 @@ def test_bench_quotes_a_profile_set_only_on_an_equal_stamp(tmp_path, monkeypatch
 
 # Round 5 is moving the ABI (17 -> 18) and the tables; the committed profile sets are regenerated on the final plan in the round's last hardware
 # session (tools/sessions/r05_*).  Until then bench.py reports `stale_profile` and omits the kernel-only figures, as designed.  REMOVE when done.
-PROFILES_PENDING_REGENERATION = True
+PROFILES_PENDING_REGENERATION = False
 
 
 @pytest.mark.xfail(PROFILES_PENDING_REGENERATION, reason="profile sets of round 4 (ABI 17) until the final session of round 5 regenerates them", strict=False)

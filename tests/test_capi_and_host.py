@@ -1328,3 +1328,25 @@ def test_bf16_mode_plan_stores_mask_and_depth_activations_in_b8(hip_lib, monkeyp
     monkeypatch.delenv("MR_B8")
     var = engine.Plan(sd, 1, 64, 96, 2, 32, (0.33, 0.0025), "cpu", bf16=1, mask_use_feats=False)
     assert not var.b8 and not any(c.get("b8") for c in var.conv_log)
+
+
+def test_lds_plane_pitches_are_conflict_free_for_the_width_of_their_reads():
+    """tools/lds_banks.py restates the lane groups / bank moduli of MI355X_MICROARCH.md (LDS): the plane pitches compiled into the kernels
+    (read back from the sources) serve their patch reads in the minimum number of LDS cycles; the pitches of rounds 3-4 took twice as many."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import lds_banks
+    src = lambda f: open(os.path.join(ROOT, "monorec_amd", "csrc", f)).read()
+    w44 = src("conv_wino44.hip")
+    rows, pitch = int(re.search(r"RH = (\d+)", w44).group(1)) + 2, int(re.search(r"RW = (\d+)", w44).group(1)) + 8
+    plane44 = (rows * pitch + 63) // 64 * 64
+    assert "constexpr int PLANE = (ROWS * PITCH + 63) / 64 * 64;" in w44 and plane44 == 1344
+    b128 = lambda plane: lds_banks.cycles(lambda l: (l >> 4) * plane + 4 * (l & 15), 4)[0]
+    assert b128(plane44) == 4 and b128(1296) == 8 and b128(576) == 4 and b128(592) == 8 and b128(768) == 4
+    wino = src("conv_wino.hip")
+    assert "constexpr int RAW_PLANE = 416;" in wino and "RAW_PLANE_T = 736;" in wino and "constexpr int RAW_PLANE_X = 416;" in src("conv1d_wino.hip")
+    b64 = lambda plane: lds_banks.cycles(lambda l: (l >> 4) * plane + 2 * (l & 15) + 2, 2)[0]
+    b32 = lambda plane: lds_banks.cycles(lambda l: (l >> 4) * plane + 2 * (l & 15) + 3, 1)[0]
+    assert b64(416) == 2 and b64(736) == 2 and b64(400) == 4 and b32(400) == 4 and b32(416) == 4      # lane stride 2: dwords collide on any even pitch
+    assert lds_banks.cycles(lambda l: (l >> 4) * 400 + (l & 15), 1)[0] == 2                              # dword reads at lane stride 1: 16 mod 32
+    assert lds_banks.cycles(lambda l: 6 * l, 2)[0] == 2                                                  # conv_wino44 A operands: lane pitch 24 bytes

@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--lean-outputs", action="store_true", help="with --bf16: MonoRecModel(hip_lean_outputs=True) - no dense fp32 single_frame_cvs in the output dict")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="keyframes kept in flight per GPU (MonoRecModel.submit; the model's default: 4); 1 = strictly one forward at a time")
+    ap.add_argument("--streams", type=int, default=0, help="MonoRecModel(hip_streams=): HIP streams the in-flight slots share in one-stream-per-slot mode (0 = the model's choice: min(slots, 4))")
     ap.add_argument("--slot-streams", type=int, default=0,
                     help="MonoRecModel(hip_slot_streams=): streams per in-flight slot (0 = the model's choice: 1 since round 5, 2 with --in-flight 1; 2 = encoder stage on a second stream, rounds 2-4)")
     ap.add_argument("--graph", action="store_true",
@@ -356,7 +357,7 @@ def secondary_bf16x3(sd, batch_dev, ref, dev, args, steps=150):
     output is reported with it and must stay inside the 1e-4 bar), but not the reference's fp32 x fp32 products."""
     import collections
     from monorec_amd import MonoRecModel
-    m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_bf16x3=True, hip_slot_streams=args.slot_streams or None)
+    m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_bf16x3=True, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
     m.load_state_dict(sd)
     m = m.to(dev).eval()
     pending = collections.deque()
@@ -428,7 +429,7 @@ def secondary_dynamic_batching(sd, batch_dev, ref, dev, args, steps=160):
            "note": "requests coalesced per launch by submit(); secondary - the headline launches every request on its own.  2 and 4 are the batch sizes of the "
                    "reference's own evaluation configs (configs/evaluate/eval_monorec.json:29, eval_monorec_oxrc.json:26); both have measured table entries"}
     for k in (2, 4):
-        m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_batch_keyframes=k, hip_slot_streams=args.slot_streams or None)
+        m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_batch_keyframes=k, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
         m.load_state_dict(sd)
         m = m.to(dev).eval()
         pending = collections.deque()
@@ -462,7 +463,7 @@ def secondary_exact_convs(sd, batch_dev, ref, dev, args, steps=120):
     from monorec_amd import MonoRecModel
     out = {"unit": "keyframes/s", "steps": steps, "note": "hip_exact_convs: 'f2' = F(2,.) forms only, True = direct kernel only; secondary"}
     for tag, exact in (("f2_forms_only", "f2"), ("direct_kernel_only", True)):
-        m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_exact_convs=exact, hip_slot_streams=args.slot_streams or None)
+        m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_exact_convs=exact, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
         m.load_state_dict(sd)
         m = m.to(dev).eval()
         pending = collections.deque()
@@ -522,7 +523,7 @@ def prime_device(args, dev_index):
     cmd = [sys.executable, os.path.abspath(__file__), "--primer", "--no-cpu-baseline", "--steps", "20", "--warmup", "2",
            "--spinup-seconds", "0.5", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
            "--frames", str(args.frames), "--depths", str(args.depths), "--in-flight", str(args.in_flight),
-           "--hw-queues", str(args.hw_queues), "--queue-depth", str(args.queue_depth), "--slot-streams", str(args.slot_streams)]
+           "--hw-queues", str(args.hw_queues), "--queue-depth", str(args.queue_depth), "--slot-streams", str(args.slot_streams), "--streams", str(args.streams)]
     if args.bf16:
         cmd.append("--bf16")
     if args.bf16x3:
@@ -578,7 +579,7 @@ def main():
 
     model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16,
                          hip_bf16x3=args.bf16x3, hip_queue_depth=args.queue_depth, hip_single_stream=args.single_stream,
-                         hip_cv_separable=args.cv_separable, hip_lean_outputs=args.lean_outputs, hip_slot_streams=args.slot_streams or None)
+                         hip_cv_separable=args.cv_separable, hip_lean_outputs=args.lean_outputs, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
     sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -888,7 +889,7 @@ def main():
                                    f"{args.frames} source frames, {args.depths} depth bins, "
                                    + ("bf16x3 split-MFMA convolutions (hi/lo bf16 pairs, fp32-class accuracy; fp32 storage and cost volume), " if args.bf16x3 else
                                       "bf16 MFMA convolutions (bf16 channel-blocked activations inside the mask / depth nets; fp32 cost volume, image features and outputs), " if args.bf16 else "fp32, ") + "random-init weights",
-                       "batch_per_gpu": args.batch, "hip_graph": args.graph, "keyframes_in_flight": args.in_flight, "streams_per_slot": model._slot_streams_n,
+                       "batch_per_gpu": args.batch, "hip_graph": args.graph, "keyframes_in_flight": args.in_flight, "streams_per_slot": model._slot_streams_n, "streams": model._n_streams,
                        "host_queue_depth_per_slot": args.queue_depth, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "results_collected_by": "stream wait (handle.result())" if args.stream_collect else "host wait (handle.synchronize())",
                        "submit_and_result_streams": "caller's" if (not args.side_streams) else "one stream for submit(), one for result()",

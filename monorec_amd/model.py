@@ -275,7 +275,7 @@ class MonoRecModel(nn.Module):
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=4, hip_bf16=False, hip_bf16x3=False,
                  hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False,
-                 hip_slot_streams=None):
+                 hip_slot_streams=None, hip_streams=None):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -328,6 +328,11 @@ class MonoRecModel(nn.Module):
         if hip_slot_streams is None:
             hip_slot_streams = 2 if self._in_flight == 1 else 1
         self._slot_streams_n = 2 if int(hip_slot_streams) >= 2 else 1
+        # One-stream-per-slot mode: how many HIP streams the slots share (slot s runs on stream s % hip_streams).  The GPU runs about four hardware queues
+        # side by side (a fifth stream costs: 5 x 1 744 against 4 x 1 820-827 keyframes/s), so more than four slots means more than one slot per stream:
+        # the second keyframe of a stream is already enqueued when the first finishes - the stream does not idle while the host collects / prepares /
+        # enqueues (tools/sessions/r05_s17.sh).  Each slot keeps its own resident buffers, so results stay valid until the slot is reused.
+        self._n_streams = self._in_flight if self._slot_streams_n == 2 else max(1, min(self._in_flight, int(hip_streams) if hip_streams else 4))
         self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded
         # to bf16, fp32 accumulate - BASELINE configs[4], NOT within the parity bar), 2 bf16x3 split (hip_bf16x3, EXPERIMENTAL:
@@ -465,10 +470,10 @@ class MonoRecModel(nn.Module):
         key = str(device)
         if key not in self._dev_streams:
             # one stream per slot: forward() borrows the next slot's stream for its encoder stage (_slot_streams); an "e0" only if there is no next slot
-            n_enc = self._in_flight if self._slot_streams_n == 2 else (1 if self._in_flight == 1 else 0)
-            layout = _STREAM_LAYOUT or ",".join([f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"])
+            n_enc = self._in_flight if self._slot_streams_n == 2 else (1 if self._n_streams == 1 else 0)
+            layout = _STREAM_LAYOUT or ",".join([f"m{s_}" for s_ in range(self._n_streams)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"])
             names = layout.split(",")
-            names += [n_ for n_ in [f"m{s_}" for s_ in range(self._in_flight)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"] if n_ not in names]   # left out: behind
+            names += [n_ for n_ in [f"m{s_}" for s_ in range(self._n_streams)] + [f"e{s_}" for s_ in range(n_enc)] + ["g"] if n_ not in names]   # left out: behind
             made, pads = {}, []
             touch = torch.zeros(len(names), dtype=torch.float32, device=device)
             torch.cuda.synchronize(device)
@@ -492,13 +497,14 @@ class MonoRecModel(nn.Module):
         st = self._streams.get((slot, str(device), bool(own)))
         if st is None:
             ds = self._device_streams(device)
+            main = ds[f"m{slot % self._n_streams}"]
             if self._single_stream:
-                enc = ds[f"m{slot}"]
+                enc = main
             elif self._slot_streams_n == 2:
                 enc = ds[f"e{slot}"]
             else:
-                enc = ds[f"m{slot}"] if not own else (ds[f"m{(slot + 1) % self._in_flight}"] if self._in_flight > 1 else ds["e0"])
-            st = {"main": ds[f"m{slot}"], "enc": enc}
+                enc = main if not own else (ds[f"m{(slot + 1) % self._n_streams}"] if self._n_streams > 1 else ds["e0"])
+            st = {"main": main, "enc": enc}
             self._streams[(slot, str(device), bool(own))] = st
         return st
 

@@ -330,8 +330,13 @@ class MonoRecModel(nn.Module):
         self._slot_streams_n = 2 if int(hip_slot_streams) >= 2 else 1
         # One-stream-per-slot mode: how many HIP streams the slots share (slot s runs on stream s % hip_streams).  The GPU runs about four hardware queues
         # side by side (a fifth stream costs: 5 x 1 744 against 4 x 1 820-827 keyframes/s), so more than four slots means more than one slot per stream:
-        # the second keyframe of a stream is already enqueued when the first finishes - the stream does not idle while the host collects / prepares /
-        # enqueues (tools/sessions/r05_s17.sh).  Each slot keeps its own resident buffers, so results stay valid until the slot is reused.
+        # the second keyframe of a stream is already enqueued when the first finishes.  Measured (tools/sessions/r05_s17.sh, c2, 200 steps): 8 slots on 4
+        # streams 830-833 = 4 slots (825-831) - the four streams are not what idles -, on 8 streams 805, on 3 streams 786, 6 slots (uneven) 800; 12 slots at
+        # c2 and 8 at the configs[4] shape collapse (141-177 / 110 keyframes/s, the host blocks inside the launch calls).  More than four slots buy nothing.
+        # Each slot keeps its own resident buffers, so results stay valid until the slot is reused.
+        if self._in_flight > 8:
+            warnings.warn(f"monorec_amd: hip_in_flight={self._in_flight}: more than 8 keyframes enqueued at once made the launch calls block on the MI355X "
+                          "(141-177 instead of 830 keyframes/s at 256x512, tools/sessions/r05_s17.sh); 4 is the measured optimum")
         self._n_streams = self._in_flight if self._slot_streams_n == 2 else max(1, min(self._in_flight, int(hip_streams) if hip_streams else 4))
         self.host_enqueue_stats = [0, 0.0]   # forwards enqueued, host seconds spent enqueueing them (without the run-ahead waits)
         # convolution arithmetic: 0 fp32 MFMA (default; the 1e-4 parity path), 1 bf16 MFMA (hip_bf16: weights / activations rounded

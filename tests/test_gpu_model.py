@@ -287,6 +287,26 @@ def test_c3_full_shape_against_the_oracle(hip_lib):
     _check_against(out, ref_out, "c3 full shape")
 
 
+@pytest.mark.parametrize("batch_size", [4, 1])
+def test_oxford_robotcar_evaluation_shape_against_the_oracle(hip_lib, batch_size):
+    """The reference's second evaluation config (configs/evaluate/eval_monorec_oxrc.json:26: batch_size 4, frame_count 2; the loader feeds 320x640,
+    data_loader/oxford_robotcar_dataset.py:53) on its measured tables (tools/sessions/r05_s18.sh: every kernel family appears, the split F(4x4,3x3)
+    kernel included) against the CPU oracle at the 1e-4 bar; batch 1 = what nn.DataParallel / one request at a time sees."""
+    model, sd = _model(32, graph=False)
+    batch = synth.make_batch(batch_size, 320, 640, 2, seed=6)
+    with torch.no_grad():
+        out = model(_to_dev(batch))
+        out = {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in out.items() if k in
+               ("result", "cv_mask", "predicted_inverse_depths", "image_features", "cost_volume", "single_frame_cvs")}
+    torch.cuda.synchronize()
+    plan = next(iter(model._plans.values()))
+    assert any(c.get("wino_variant") == 4 for c in plan.conv_log) or batch_size == 1          # the tables of this shape select the split kernel (batch 4)
+    assert sum(1 for c in plan.conv_log if c.get("stride2")) >= 2
+    ref_out = orc.forward(sd, batch, cv_depth_steps=32)
+    assert out["result"].shape == (batch_size, 1, 320, 640) and len(out["single_frame_cvs"]) == 2
+    _check_against(out, ref_out, "320x640 batch %d" % batch_size)
+
+
 def test_c5_shape_in_fp32_and_bf16(hip_lib):
     """BASELINE configs[4] shape (512x1024, 4 source frames, 48 depth bins) against the CPU oracle: the fp32 path at the 1e-4
     bar, and the bf16 MFMA mode the configuration names (hip_bf16=True: bf16 operands, fp32 accumulate, fp32 storage) at its own

@@ -154,7 +154,7 @@ class _Ref:
 # Environment variables that change WHICH kernels / forms a plan runs (and therefore its numerics and speed).  They exist for the tuning
 # sessions (A/B of a candidate table, of one kernel family); a stray one must not pass silently: `active_env_overrides()` is
 # echoed into bench.py's config block, and the first plan built under any of them warns once.
-ENV_OVERRIDES = ("MR_TUNED_SCHEDULES", "MR_TUNED_WINOGRAD", "MR_B8", "MR_B8_NB4", "MR_WINOGRAD", "MR_ONE_CHANNEL_KERNELS", "MR_HIP_LIBRARY",
+ENV_OVERRIDES = ("MR_TUNED_SCHEDULES", "MR_TUNED_WINOGRAD", "MR_TUNED_B8", "MR_B8", "MR_B8_NB4", "MR_WINOGRAD", "MR_ONE_CHANNEL_KERNELS", "MR_HIP_LIBRARY",
                  "MR_DIAG_STREAM_LAYOUT", "MR_DIAG_STREAM_PRIO")
 _warned_env = [False]
 
@@ -205,6 +205,21 @@ def _load_winograd():
 
 
 _load_winograd()
+
+B8_SCHEDULES = {}   # signature of a mr_conv2d_b8 launch (Plan.conv_b8: b8_co.._ci.._k.._s.._o.._b.._p.. + _f<fp32 source>) -> (MB, NB, waves); measured
+                    # (tools/tune_b8.py) - launches without an entry follow the rule of Plan.b8_schedule
+
+
+def _load_b8_schedules():
+    import json
+    import os
+    path = os.environ.get("MR_TUNED_B8") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_b8.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            B8_SCHEDULES.update({k: tuple(int(x) for x in v) for k, v in json.load(f).items()})
+
+
+_load_b8_schedules()
 
 WINOGRAD_F2 = {}    # conv_forms = "f2": for a key whose table entry is a larger form (F(4,.), F(4x4,3x3)), the F(2,.) code that was
                     # measured best for it before the larger forms existed (0 = direct kernel: the 7-tap layers).  MEASURED for the c2 / c3
@@ -1087,8 +1102,10 @@ class Plan:
         out_h, out_w = grid
         olay, on, oc, oh, ow = self._act_info(out)
         assert on == n and oc == cout and out.is_contiguous(), (name, on, n, oc, cout)
-        mb, nb, waves = self.schedule_override.get(name) or self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist),
-                                                                             f32_source=any(i[0] == LAYOUT_F32_NCHW for i in infos))
+        f32_source = any(i[0] == LAYOUT_F32_NCHW for i in infos)
+        sig = f"b8_co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{stride[0]}x{stride[1]}_o{out_h}x{out_w}_b{n}_p{len(plist)}"
+        mb, nb, waves = (self.schedule_override.get(name) or B8_SCHEDULES.get(sig + f"_f{int(f32_source)}") or
+                         self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist), f32_source=f32_source))
         d = B8ConvDesc()
         sc = (ctypes.c_int32 * len(srcs))(*src_channels)
         for i, s_ in enumerate(srcs):
@@ -1125,7 +1142,7 @@ class Plan:
         wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * math.ceil(((cout + 15) // 16) / mb) * n * len(plist)
         self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=1, ck=32, waves=waves, kws=0,
                                   wgs=wgs, lds=int(lds), cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=len(plist), bf16=1, b8=True,
-                                  sig=f"b8_co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{stride[0]}x{stride[1]}_o{out_h}x{out_w}_b{n}_p{len(plist)}",
+                                  sig=sig, f32_source=f32_source,
                                   spec=dict(src_shapes=[(i[1], i[2], i[3], i[4]) for i in infos], src_layouts=[i[0] for i in infos], w_shape=(cout, cin, kh, kw),
                                             stride=tuple(stride), pad=tuple(pad), grid=(out_h, out_w), act=act, p0=p0, out_layout=olay,
                                             out_step=tuple(out_step))))

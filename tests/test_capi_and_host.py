@@ -1350,3 +1350,22 @@ def test_lds_plane_pitches_are_conflict_free_for_the_width_of_their_reads():
     assert b64(416) == 2 and b64(736) == 2 and b64(400) == 4 and b32(400) == 4 and b32(416) == 4      # lane stride 2: dwords collide on any even pitch
     assert lds_banks.cycles(lambda l: (l >> 4) * 400 + (l & 15), 1)[0] == 2                              # dword reads at lane stride 1: 16 mod 32
     assert lds_banks.cycles(lambda l: 6 * l, 2)[0] == 2                                                  # conv_wino44 A operands: lane pitch 24 bytes
+
+
+def test_b8_schedule_table_overrides_the_rule_per_launch_signature(monkeypatch):
+    """engine.B8_SCHEDULES (tuned_b8.json, tools/tune_b8.py): a measured (MB, NB, waves) per mr_conv2d_b8 launch signature goes ahead of the rule
+    Plan.b8_schedule; launches without an entry keep the rule's choice; the plan stamp follows the schedules."""
+    m = MonoRecModel(cv_depth_steps=8)
+    sd = synth.seeded_state_dict(m.state_dict(), seed=0)
+    monkeypatch.setattr(engine, "B8_SCHEDULES", {})
+    base = engine.Plan(sd, 1, 64, 128, 2, 8, (0.33, 0.0025), "cpu", bf16=1)
+    b8 = [c for c in base.conv_log if c.get("b8")]
+    assert b8 and all("f32_source" in c for c in b8)
+    tgt = next(c for c in b8 if c["phases"] == 1 and (c["mb"], c["nb"], c["waves"]) != (1, 1, 4))
+    key = tgt["sig"] + f"_f{int(tgt['f32_source'])}"
+    monkeypatch.setattr(engine, "B8_SCHEDULES", {key: (1, 1, 4)})
+    plan = engine.Plan(sd, 1, 64, 128, 2, 8, (0.33, 0.0025), "cpu", bf16=1)
+    for c0, c1 in zip(b8, [c for c in plan.conv_log if c.get("b8")]):
+        same_key = c0["sig"] + f"_f{int(c0['f32_source'])}" == key
+        assert (c1["mb"], c1["nb"], c1["waves"]) == ((1, 1, 4) if same_key else (c0["mb"], c0["nb"], c0["waves"])), c0["name"]
+    assert plan.launch_stamp() != base.launch_stamp()

@@ -54,6 +54,7 @@ class ConvDesc(ctypes.Structure):
         ("compute_dtype", ctypes.c_int32),
         ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
         ("k_split_waves", ctypes.c_int32),
+        ("pipeline_buffers", ctypes.c_int32),
     ]
 
 
@@ -88,7 +89,7 @@ class B8ConvDesc(ctypes.Structure):
 
 
 MR_MAX_COPY_SEGMENTS = 24
-MR_ABI_VERSION = 18            # include/monorec_hip.h
+MR_ABI_VERSION = 19            # include/monorec_hip.h
 
 
 class CopySegment(ctypes.Structure):

@@ -124,13 +124,13 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4, kws=0):
                 tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
 
 
-def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False, reduce_bytes=0):
-    """Dynamic LDS of one workgroup: pipeline buffers of (input tile + A fragments of the largest chunk) - two,
-    or one when no workgroup streams a second chunk (mirrors derive() in csrc/conv_mfma.hip); `reduce_bytes`: the scratch of the
-    K-split-across-waves reduction (waves * mb * nb KiB), which reuses the same memory."""
+def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False, reduce_bytes=0, nbuf=0):
+    """Dynamic LDS of one workgroup: a ring of pipeline buffers of (input tile + A fragments of the largest chunk) - `nbuf` 0: two,
+    or one when no workgroup streams a second chunk; n: min(n, chunks of a workgroup) (mirrors derive() in csrc/conv_mfma.hip);
+    `reduce_bytes`: the scratch of the K-split-across-waves reduction (waves * mb * nb KiB), which reuses the same memory."""
     ck_max = max(min(c, ck) for c in cpads)
     nchunks = sum(math.ceil(c / ck) for c in cpads)
-    nbuf = 2 if math.ceil(nchunks / split_k) > 1 else 1
+    nbuf = min(max(nbuf, 2), math.ceil(nchunks / split_k))
     return max(nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if int(bf16) == 1 else 16)), reduce_bytes)    # bf16x3 blocks: hi + lo = fp32 size
 
 
@@ -176,7 +176,7 @@ def _warn_env_overrides():
                       "tables / defaults (tuning aid; unset them for the measured configuration)")
 
 
-TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves]); filled from tuned_schedules.json when present
+TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves[, k_split_waves[, pipeline_buffers]]]); filled from tuned_schedules.json when present
 
 
 def _load_tuned():
@@ -331,8 +331,9 @@ def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, 
             + ("u" if mixed_phases else "") + ("", "_bf16", "_bf16x3")[int(bf16)])
 
 
-def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False):
-    """All launchable (mb, nb, split_k, ck) for a conv, with the workgroup count of each."""
+def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False, ring_depths=()):
+    """All launchable (mb, nb, split_k, ck, waves, kws, nbuf) for a conv, with the workgroup count of each.  `ring_depths`: LDS ring depths
+    (mr_conv_desc.pipeline_buffers) to list besides the two-buffer pipeline (nbuf 0)."""
     cb = (cout + 15) // 16
     unit = 16 if bf16 else 4
     cpads = [(c + unit - 1) // unit * unit for c in src_channels]
@@ -362,11 +363,18 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                         for sk in ((1,) if kws else (1, 2, 4, 8, 16)):
                             if sk > nchunks:
                                 break
-                            lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16, waves * mb * nb * 1024 if kws else 0)
-                            if lds > lds_cap:
-                                continue
-                            out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, kws=kws, wgs=wgs * sk, nchunks=nchunks,
-                                            eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
+                            wg_chunks = math.ceil(nchunks / sk)
+                            seen_depth = set()
+                            for nbuf in (0,) + tuple(ring_depths):
+                                depth = min(nbuf or 2, wg_chunks)             # what the launch will use
+                                if nbuf and (depth <= 2 or depth in seen_depth):
+                                    continue                                  # = the two-buffer pipeline / a depth already listed
+                                seen_depth.add(depth)
+                                lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16, waves * mb * nb * 1024 if kws else 0, nbuf)
+                                if lds > lds_cap:
+                                    continue
+                                out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, kws=kws, nbuf=depth if nbuf else 0, wgs=wgs * sk, nchunks=nchunks,
+                                                eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
     return out
 
 
@@ -393,7 +401,7 @@ def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, pha
     best = None
     for lds_cap in (80 * 1024, 160 * 1024):      # prefer two workgroups per CU; a one-per-CU budget only if nothing else launches
         for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=lds_cap, bf16=bf16):
-            if c["waves"] != 4 or c.get("kws"):          # 8-wave / K-split-wave workgroups only through the measured table
+            if c["waves"] != 4 or c.get("kws") or c.get("nbuf"):   # 8-wave / K-split-wave workgroups / deep rings only through the measured table
                 continue
             reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
             fill = min(1.0, c["wgs"] / 768.0)
@@ -419,7 +427,7 @@ class Plan:
     def __init__(self, state, batch, height, width, num_frames, depth_steps, inv_depth_min_max, device,
                  alpha=10.0, channel_weights=(5 / 32, 16 / 32, 11 / 32), schedule_override=None, build=True, bf16=False, use_ssim=True, sfcv_mult_mask=True,
                  pretrain_mode=0, no_cv=False, mask_use_cv=True, mask_use_feats=True, simple_mask=False, cv_patch_size=3,
-                 one_channel_kernels=None, winograd=None, conv_forms="table", cv_separable=False, lean_outputs=False):
+                 one_channel_kernels=None, winograd=None, conv_forms="table", cv_separable=False, lean_outputs=False, skip_layer4=False):
         if build and (height % 32 or width % 32):
             raise ValueError("MonoRec needs height and width divisible by 32 (five stride-2 stages)")
         if build and depth_steps < 2:
@@ -444,6 +452,10 @@ class Plan:
         # opt-in of the bf16 configuration (MonoRecModel(hip_bf16=True, hip_lean_outputs=True)): no dense fp32 `single_frame_cvs` - the fusion
         # kernel writes the fused volume and the B8 copies the mask encoder reads, nothing else (403 MB of HBM writes less at configs[4])
         self.lean_outputs = bool(lean_outputs)
+        # opt-in (MonoRecModel(hip_skip_dead_layer4=True)): ResNet layer4 (monorec_model.py:118-129) is computed by the reference but read by nobody -
+        # MaskModule / DepthModule consume image_features[0..3] only (:372-380, :545).  With the switch its 5 convolutions + 3 split-K
+        # finishing launches are not issued and `image_features` has four entries.
+        self.skip_layer4 = bool(skip_layer4)
         self.pix_depths_on = False    # set per forward by the model when the input dict carries per-pixel cv_depths
         self.bf16 = int(bf16)         # convolutions: 0 fp32 MFMA, 1 bf16 MFMA (MR_COMPUTE_BF16), 2 bf16x3 split (MR_COMPUTE_BF16X3); everything else fp32
         # bf16 MFMA mode: the activations BETWEEN the convolutions of the mask and depth nets are stored channel-blocked in bf16 ("B8",
@@ -501,7 +513,7 @@ class Plan:
         h = hashlib.sha256()
         for c in self.conv_log:
             h.update(repr((c["name"], c.get("winograd", 0), c.get("wino_variant", 0), c.get("wino_axis", 0), c.get("wino_m", 0), c.get("b8", 0),
-                           c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"], c["kws"], int(c.get("bf16", 0)))).encode())
+                           c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"], c["kws"], int(c.get("bf16", 0)), int(c.get("nbuf", 0)))).encode())
         h.update(f"abi{_lib.MR_ABI_VERSION}".encode())
         return h.hexdigest()[:16]
 
@@ -650,6 +662,7 @@ class Plan:
         mb, nb, split_k, ck = sched[:4]
         waves = sched[4] if len(sched) > 4 else 4
         kws = int(sched[5]) if len(sched) > 5 else 0       # K split across the waves of a workgroup
+        nbuf = int(sched[6]) if len(sched) > 6 else 0      # LDS ring depth (0: the two-buffer pipeline)
         d = ConvDesc()
         for i, s in enumerate(srcs):
             d.src[i] = s.data_ptr()
@@ -682,6 +695,7 @@ class Plan:
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
         d.waves_per_wg = waves
         d.k_split_waves = kws
+        d.pipeline_buffers = nbuf
         d.compute_dtype = int(bf16)
         if split_k > 1:
             self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
@@ -695,7 +709,7 @@ class Plan:
         macs = n * out_h * out_w * cout * cin * taps
         geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves, kws)
         wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
-        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, kws=kws, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, kws=kws, nbuf=nbuf, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
                                   sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16, mixed), bf16=bf16,
                                   spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),
@@ -1224,6 +1238,8 @@ class Plan:
         x, cin, hh, ww = pool, 64, H // 4, W // 4
         for li, cout in enumerate((64, 128, 256, 512), start=1):
             if li == 4:
+                if self.skip_layer4:
+                    break                # dead work dropped on request: image_features[4] is absent from the output
                 st = "encoder_tail"      # layer4 only feeds image_features[4]: nothing downstream waits for it
             for bi in range(2):
                 pre = f"{enc}.layer{li}.{bi}"

@@ -274,7 +274,7 @@ class MonoRecModel(nn.Module):
                  sfcv_mult_mask=True, simple_mask=False, mask_use_cv=True, mask_use_feats=True, cv_patch_size=3,
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=4, hip_bf16=False, hip_bf16x3=False,
-                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False,
+                 hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False, hip_skip_dead_layer4=False,
                  hip_slot_streams=None, hip_streams=None):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
@@ -356,6 +356,7 @@ class MonoRecModel(nn.Module):
         # opt-in, bf16 configuration only: the output dict carries no `single_frame_cvs` (nothing outside the model reads them: evaluater.py:87,
         # create_pointcloud.py:70-84 use `result` / `cv_mask`; the MaskModule reads the B8 copies) - their fp32 stores are skipped
         self._lean_outputs = bool(hip_lean_outputs)
+        self._skip_layer4 = bool(hip_skip_dead_layer4)
         if self._lean_outputs and self._bf16 != 1:
             raise ValueError("hip_lean_outputs needs hip_bf16=True (the fp32 path hands out `single_frame_cvs` like the reference)")
         self._slot_counter = [0]         # mutable on purpose: nn.DataParallel replicas (shallow copies made per forward) share it
@@ -522,7 +523,7 @@ class MonoRecModel(nn.Module):
                         use_ssim=self.use_ssim, sfcv_mult_mask=self.sfcv_mult_mask, pretrain_mode=self.pretrain_mode,
                         no_cv=self.no_cv, mask_use_cv=self.mask_use_cv or self.simple_mask,
                         mask_use_feats=self.mask_use_feats or self.simple_mask, simple_mask=self.simple_mask,
-                        cv_patch_size=self.cv_patch_size, conv_forms=self._conv_forms, cv_separable=self._cv_separable, lean_outputs=self._lean_outputs)
+                        cv_patch_size=self.cv_patch_size, conv_forms=self._conv_forms, cv_separable=self._cv_separable, lean_outputs=self._lean_outputs, skip_layer4=self._skip_layer4)
             plan.buf["depths"].copy_(depth_hypotheses(self.inv_depth_min_max, self.cv_depth_steps))
             plan.host_geom = torch.empty(batch * 9 + batch * nf * 12, dtype=torch.float32).pin_memory()
             plan.host_mats = torch.empty(2 + 2 * nf, batch, 4, 4, dtype=torch.float32).pin_memory()
@@ -1014,7 +1015,7 @@ class MonoRecModel(nn.Module):
             data_dict["cost_volume"] = owned["cost_volume"]
             if "sfcv" in owned:
                 data_dict["single_frame_cvs"] = [owned["sfcv"][f] for f in range(nf)]
-            data_dict["image_features"] = [owned[f"feat{i}"] for i in range(5)]
+            data_dict["image_features"] = [owned[f"feat{i}"] for i in range(5) if f"feat{i}" in owned]
             data_dict["cv_mask"] = owned["cv_mask"]
             data_dict["inv_depth_min"], data_dict["inv_depth_max"], data_dict["cv_depth_steps"] = owned["consts"]
             data_dict["predicted_inverse_depths"] = [owned[f"pred{i}"] for i in range(4)]
@@ -1077,6 +1078,8 @@ class MonoRecModel(nn.Module):
 
     def _run_stage(self, key, plan, stage, stream):
         """Run one stage of the plan on `stream`: eagerly, or (hip_graph) as a captured hipGraph replay."""
+        if not plan.stages[stage]:                            # (encoder_tail under hip_skip_dead_layer4: nothing to launch or capture)
+            return
         if not self._hip_graph:
             plan.run_stage(stage, stream.cuda_stream)
             return

@@ -54,7 +54,7 @@ def main():
     demangle = {}
     try:
         names = [k["name"] for k in kernels(asm)]
-        res = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True)
+        res = subprocess.run(["c++filt"] + names, capture_output=True, text=True)
         demangle = dict(zip(names, res.stdout.splitlines()))
     except Exception:
         pass

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/monorec_hip.h"
 
@@ -52,6 +53,7 @@ struct B8Args {
     int Ho, Wo;
     void* dst;
     int dst_layout, dst_H, dst_W, ostep_h, ostep_w;
+    int dst_bytes;                   // B8 destination: whole tensor, < 2 GiB (stored through a buffer descriptor)
     int Cout, CB16;
     const float* bias;
     int act;
@@ -62,6 +64,7 @@ struct B8Args {
     const void* w[4];
     long long wgroup_bytes[4];       // packed bytes per cout group
     int KHp[4], KWp[4], PT[4], PL[4], ooff_h[4], ooff_w[4];
+    int nstage;                      // input stages in LDS (ring depth): 2 .. MR_MAX_PIPELINE_BUFFERS; > 2 only without fp32 sources
     int dbg;                         // diagnostic library only (MR_B8_DBG): 1 skip the sweep, 2 skip the input staging, 4 skip the weight DMA, 8 skip the stores
 };
 
@@ -88,6 +91,19 @@ __device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const void
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// s_waitcnt vmcnt(N) takes an immediate: wait until at most `n` (wave-uniform, run time) of this wave's VMEM instructions are outstanding.
+// Rounding n DOWN is always safe (it waits for more); loads return in order, so "at most n outstanding" = everything but the n youngest has landed.
+#define MR_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void dma_wait_upto(int n) {
+    switch (n < 32 ? n : (n < 48 ? 32 : 48)) {
+        MR_VMCNT_CASE(0) MR_VMCNT_CASE(1) MR_VMCNT_CASE(2) MR_VMCNT_CASE(3) MR_VMCNT_CASE(4) MR_VMCNT_CASE(5) MR_VMCNT_CASE(6) MR_VMCNT_CASE(7)
+        MR_VMCNT_CASE(8) MR_VMCNT_CASE(9) MR_VMCNT_CASE(10) MR_VMCNT_CASE(11) MR_VMCNT_CASE(12) MR_VMCNT_CASE(13) MR_VMCNT_CASE(14) MR_VMCNT_CASE(15)
+        MR_VMCNT_CASE(16) MR_VMCNT_CASE(17) MR_VMCNT_CASE(18) MR_VMCNT_CASE(19) MR_VMCNT_CASE(20) MR_VMCNT_CASE(21) MR_VMCNT_CASE(22) MR_VMCNT_CASE(23)
+        MR_VMCNT_CASE(24) MR_VMCNT_CASE(25) MR_VMCNT_CASE(26) MR_VMCNT_CASE(27) MR_VMCNT_CASE(28) MR_VMCNT_CASE(29) MR_VMCNT_CASE(30) MR_VMCNT_CASE(31)
+        MR_VMCNT_CASE(32) MR_VMCNT_CASE(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 
 __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
     const unsigned long long p = (unsigned long long)base;
@@ -163,8 +179,8 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         piy[j] = p / a.IW;
         pix_[j] = p - piy[j] * a.IW;
     }
-    auto place = [&](int tile) {
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    int lty = tile_begin / a.tiles_x, ltx = tile_begin - lty * a.tiles_x;      // (row, column) of the load cursor's tile: one division per kernel
+    auto place = [&](int ty, int tx) {
         const int iy_base = ty * a.TH * a.SH - PT, ix_base = tx * 32 * a.SW - PL;
 #pragma unroll
         for (int j = 0; j < B8_MAX_PPT; ++j) {
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
             gpix[j] = (live[j] && (unsigned)gy < (unsigned)a.Hs && (unsigned)gx < (unsigned)a.Ws) ? gy * a.Ws + gx : -1;
         }
     };
-    place(ltile);
+    place(lty, ltx);
 
     // weights (unless resident) + B8 inputs: LDS-DMA, nothing to wait for until the barrier.  fp32 NCHW inputs: loaded into `stg` here (8
     // channel planes per position), converted and written to LDS by stage_store() AFTER the sweep of the previous chunk - the loads fly
@@ -182,14 +198,15 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         s = (a.nsrc > 2 && q >= a.src_q0[2]) ? 2 : ((a.nsrc > 1 && q >= a.src_q0[1]) ? 1 : 0);
         blk0 = (q - pick3(a.src_q0, s)) * 4;
     };
-    auto issue = [&](int q, int pb) {
+    auto issue = [&](int q, int pb) -> int {          // returns the LDS-DMA instructions THIS wave certainly issued (the ring's partial vmcnt waits count on it)
         const unsigned buf = lds_base + wres_bytes + pb * stage_bytes;
+        int issued = 0;
         if (!WRES && !B8_DBG(4)) {
             const unsigned wbuf = buf + 64 * PLANE;
             const unsigned char* wsrc = wgrp + (long long)q * wchunk_bytes;
-            for (int kb = wave; kb < T * MB; kb += WV) dma_global_x4(wbuf + kb * 1024, wsrc + kb * 1024 + lane * 16);
+            for (int kb = wave; kb < T * MB; kb += WV) { dma_global_x4(wbuf + kb * 1024, wsrc + kb * 1024 + lane * 16); ++issued; }
         }
-        if (B8_DBG(2)) return;
+        if (B8_DBG(2)) return issued;
         int s, blk0;
         source_of(q, s, blk0);
         const void* sp = pick3(a.src, s);
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
                     const int so = ((b * scb + (bok ? blk0 + k : 0)) * HsWs) * 16;
                     dma_buffer_x4(lrow + k * PLANE * 16, (bok && gpix[j] >= 0) ? gpix[j] * 16 : -1, srd, so);
                 }
+                if (64 * wave + 64 * WV * j < PLANE) issued += 4;         // lane 0 of the wave is inside the tile: the four instructions issue
             }
         } else if (F32SRC) {
             const int sc = pick3(a.src_c, s);
@@ -225,6 +243,7 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
                     }
             }
         }
+        return issued;
     };
     auto stage_store = [&](int q, int pb) {
         if (!F32SRC || B8_DBG(2)) return;
@@ -251,7 +270,8 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
     auto advance = [&]() {                                                // load cursor to the next (tile, chunk)
         if (++lq == a.nchunks) {
             lq = 0;
-            if (++ltile < tile_end) place(ltile);
+            if (++ltx == a.tiles_x) { ltx = 0; ++lty; }
+            if (++ltile < tile_end) place(lty, ltx);
         }
     };
 
@@ -285,28 +305,45 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
     // memory), so that every lane stores one complete 16-byte group - 256 contiguous bytes per 16 lanes.
     constexpr int NPAIR = NB >= 2 ? NB / 2 : 1;
     i32x4 pend[MB][NPAIR];
-    int pend_tile = -1;
+    int pend_ty = -1, pend_tx = 0;
     const bool b8_out = a.dst_layout == MR_LAYOUT_BF16_B8;
     const int dcb = (a.Cout + 7) >> 3;
+    // Round 6: SQ_INSTS_VALU / SQ_INSTS_MFMA of this kernel was 3.9 (profiles/r06_c5bf16_b8_counters.txt: 837 VALU and 734 SALU instructions per
+    // wave and tile against 216 MFMAs, most of them 64-bit address arithmetic of these stores and the exchange selects of the epilogue, issued
+    // while the matrix pipe idles - all 8 waves are in their epilogue together).  The stores now go through a buffer descriptor: the lane's
+    // offset inside a tile (row, column, channel-block half) is computed ONCE per workgroup, the tile / cout-block part is a scalar.
+    const int half = lane >> 5;                               // which 8-channel block of the 16-channel cout block this lane stores
+    int svoff[NPAIR], srow[NPAIR], scol[NPAIR];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        const int ik = NB >= 2 ? 2 * pr + ((lane >> 4) & 1) : 0;          // even quad: the pair's first pixel block, odd quad: its second
+        const int pbk = wave * NB + ik;
+        srow[pr] = pbk >> 1;
+        scol[pr] = (pbk & 1) * 16 + (lane & 15);
+        svoff[pr] = ((srow[pr] * a.ostep_h) * a.dst_W + scol[pr] * a.ostep_w + half * a.dst_H * a.dst_W) * 16;
+    }
+    bool blk_ok[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) blk_ok[m] = (grp * MB + m) * 2 + half < dcb;
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, b8_out ? a.dst_bytes : 0, 0x00020000);
     auto flush = [&]() {
-        if (pend_tile < 0) return;
-        const int ty = pend_tile / a.tiles_x, tx = pend_tile - ty * a.tiles_x;
-        const int oy0 = ty * a.TH, ox0 = tx * 32;
-        pend_tile = -1;
+        if (pend_ty < 0) return;
+        const int oy0 = pend_ty * a.TH, ox0 = pend_tx * 32;
+        pend_ty = -1;
         if (B8_DBG(8)) return;
+        const int rows_left = a.Ho - oy0, cols_left = a.Wo - ox0;                       // wave-uniform
+        const int sbase = ((oy0 * a.ostep_h + ooff_h) * a.dst_W + ox0 * a.ostep_w + ooff_w) * 16;
+        const int plane16 = a.dst_H * a.dst_W * 16;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            const int blk = ((grp * MB + m) * 16 + g4) >> 3;
-            if (blk >= dcb) continue;
+            const int soff = sbase + (b * dcb + (grp * MB + m) * 2) * plane16;          // wave-uniform: the SGPR offset of the store
 #pragma unroll
             for (int pr = 0; pr < NPAIR; ++pr) {
                 if (NB >= 2) {
-                    const int i = 2 * pr + ((lane >> 4) & 1);             // even quad: the pair's first pixel block, odd quad: its second
-                    const int oy = oy0 + (wave * NB + i) / 2, ox = ox0 + ((wave * NB + i) & 1) * 16 + (lane & 15);
-                    if (oy >= a.Ho || ox >= a.Wo) continue;
-                    const int dy = oy * a.ostep_h + ooff_h, dx = ox * a.ostep_w + ooff_w;
-                    *((i32x4*)a.dst + (((long long)b * dcb + blk) * a.dst_H + dy) * a.dst_W + dx) = pend[m][pr];
+                    if (blk_ok[m] && srow[pr] < rows_left && scol[pr] < cols_left) __builtin_amdgcn_raw_buffer_store_b128(pend[m][pr], drs, svoff[pr], soff, 0);
                 } else {                                                  // one pixel block per wave: 8 bytes per lane
+                    const int blk = ((grp * MB + m) * 16 + g4) >> 3;
+                    if (blk >= dcb) continue;
                     const int oy = oy0 + wave / 2, ox = ox0 + (wave & 1) * 16 + (lane & 15);
                     if (oy >= a.Ho || ox >= a.Wo) continue;
                     const int dy = oy * a.ostep_h + ooff_h, dx = ox * a.ostep_w + ooff_w;
@@ -317,100 +354,177 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         }
     };
 
-    issue(0, 0);
-    stage_store(0, 0);
-    advance();
-    int pb = 0;
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        f32x4 acc[MB][NB];
+    // taps flattened and software-pipelined over two register sets: the fragments of tap t + 1 are on their way from LDS while the
+    // MB * NB MFMAs of tap t issue (first hardware run: one set, 20 % of the MFMA rate - every tap waited out its own ds_reads)
+    auto sweep = [&](f32x4 (&acc)[MB][NB], const unsigned char* buf, const unsigned char* wl) {
+        bf16x8 av0[MB], bv0[NB], av1[MB], bv1[NB];
+        auto frags = [&](bf16x8 (&av)[MB], bf16x8 (&bv)[NB], int t, int tapoff) {
+#ifdef MR_B8_ABLATE                                      // diagnostic library: bit 16 = no A (weight) LDS reads, bit 32 = no B (input) LDS reads
+            if (a.dbg & 16) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < a.nchunks; ++q) {
-            const unsigned char* buf = lds + wres_bytes + pb * stage_bytes;
-            const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
-            dma_wait_all();
-            __syncthreads();                                  // this chunk (and the resident weights) visible; everyone is done with the other buffer
-            const bool more = ltile < tile_end;               // wave-uniform
-            const int nq = lq;
-            // (the DMA instructions spread over the taps of the sweep instead of this burst - what gained 4 % on the F(4x4,3x3) kernel, whose MFMA
-            // phase runs from registers - was measured here too, tools/sessions/r04_s36.sh: 181 -> 191 us on mask.enc0.1, configs[4] 324-333 ->
-            // 311-315 keyframes/s: this sweep reads its operands from LDS and a wave held by a DMA instruction stops feeding them)
-            if (more) issue(nq, pb ^ 1);
-            if (q == 0) flush();                              // the previous tile's results leave while this chunk is swept
-            // taps flattened and software-pipelined over two register sets: the fragments of tap t + 1 are on their way from LDS while the
-            // MB * NB MFMAs of tap t issue (first hardware run: one set, 20 % of the MFMA rate - every tap waited out its own ds_reads)
-            bf16x8 av0[MB], bv0[NB], av1[MB], bv1[NB];
-            auto frags = [&](bf16x8 (&av)[MB], bf16x8 (&bv)[NB], int t, int tapoff) {
+                for (int m = 0; m < MB; ++m) av[m] = __builtin_bit_cast(bf16x8, (i32x4){(int)threadIdx.x + m + t, 0x3f803f80, 0x3f803f80, 0x3f803f80});
+            } else
+#endif
+            {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) av[m] = *(const bf16x8*)(wl + (t * MB + m) * 1024);
+            }
+#ifdef MR_B8_ABLATE
+            if (a.dbg & 32) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) bv[i] = __builtin_bit_cast(bf16x8, (i32x4){(int)threadIdx.x + i + tapoff, 0x3f803f80, 0x3f803f80, 0x3f803f80});
+            } else
+#endif
+            {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) bv[i] = *(const bf16x8*)(buf + lbase[i] + tapoff);
-            };
-            auto mfmas = [&](const bf16x8 (&av)[MB], const bf16x8 (&bv)[NB]) {
+            }
+        };
+        auto mfmas = [&](const bf16x8 (&av)[MB], const bf16x8 (&bv)[NB]) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[i], acc[m][i], 0, 0, 0);
-            };
-            int kh = 0, kw = 0;                                   // tap t + 1 as (kh, kw)
-            auto next_off = [&]() {
-                if (++kw == KW) { kw = 0; ++kh; }
-                return (kh * a.IW + kw) * 16;
-            };
-            if (!B8_DBG(1)) frags(av0, bv0, 0, 0);
-            for (int t = 0; t < (B8_DBG(1) ? 0 : T); t += 2) {
-                if (t + 1 < T) frags(av1, bv1, t + 1, next_off());
-                mfmas(av0, bv0);
-                if (t + 1 < T) {
-                    if (t + 2 < T) frags(av0, bv0, t + 2, next_off());
-                    mfmas(av1, bv1);
+                for (int i = 0; i < NB; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[i], acc[m][i], 0, 0, 0);
+        };
+        int kh = 0, kw = 0;                                   // tap t + 1 as (kh, kw)
+        auto next_off = [&]() {
+            if (++kw == KW) { kw = 0; ++kh; }
+            return (kh * a.IW + kw) * 16;
+        };
+        // steady state WITHOUT a branch around either load: hipcc merges the LDS counters of the two paths of `if (t + 1 < T) frags(...)`
+        // pessimistically and put s_waitcnt lgkmcnt(0) right behind the reads it had just issued (ISA of rounds 4-5: every pair of taps waited
+        // out its own LDS latency - 58 % of the bf16 MFMA rate with every LDS read ablated, profiles/r06_c5bf16_b8_ablation.txt); the tail is peeled
+        if (B8_DBG(1)) return;
+        frags(av0, bv0, 0, 0);
+        int t = 0;
+        for (; t + 2 < T; t += 2) {
+            frags(av1, bv1, t + 1, next_off());
+            mfmas(av0, bv0);
+            frags(av0, bv0, t + 2, next_off());
+            mfmas(av1, bv1);
+        }
+        if (t + 1 < T) {
+            frags(av1, bv1, t + 1, next_off());
+            mfmas(av0, bv0);
+            mfmas(av1, bv1);
+        } else {
+            mfmas(av0, bv0);
+        }
+    };
+
+    // ---- input pipeline.  fp32 sources (F32SRC): the two-stage pipeline of round 4 - a chunk's planes are loaded into registers ahead of the sweep
+    // and converted / written to the other stage behind it.  B8 sources only: a RING of a.nstage stages (round 6) - the first nstage chunks of the
+    // workgroup's (tile, chunk) sequence go out back to back, chunk n is swept after a PARTIAL vmcnt wait (everything this wave issued up to and
+    // including chunk n has landed, the younger chunks stay in flight) and one barrier, which also frees the stage of chunk n - 1 for chunk
+    // n + nstage - 1.  With two stages of 13-40 KB a CU had 26-80 KB of loads in flight: profiles/r06_c5bf16_b8_ablation.txt - mask.enc0.1
+    // 182 us = 105 (memory pipeline alone) and 132 (sweep alone) NOT overlapped; 8 TB/s x ~2 us of latency wants ~60 KB per CU in flight.
+    const int NS = F32SRC ? 2 : a.nstage;
+    const int total_chunks = (tile_end - tile_begin) * a.nchunks;
+    int ib = 0, sb = 0, nissued = 0;                   // stage of the next issue / sweep; chunks issued so far
+    unsigned long long fifo = 0;                       // DMA instructions of the chunks in flight, 8 bits each, oldest in the low byte
+    int depth = 0, dpend = 0;
+    auto issue_next = [&]() {
+        int cnt = issue(lq, ib);
+        cnt = cnt < 255 ? cnt : 255;                   // (an undercount only makes the wait stricter)
+        fifo |= (unsigned long long)cnt << (8 * depth);
+        ++depth;
+        dpend += cnt;
+        advance();
+        ib = ib + 1 == NS ? 0 : ib + 1;
+        ++nissued;
+    };
+    if (F32SRC) {
+        issue(0, 0);
+        stage_store(0, 0);
+        advance();
+    } else {
+        for (int j = 0; j < NS && j < total_chunks; ++j) issue_next();
+    }
+    int pb = 0;
+    bool first = true;
+    int sty = tile_begin / a.tiles_x, stx = tile_begin - sty * a.tiles_x;      // the sweep cursor's tile
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        f32x4 acc[MB][NB];                                    // starts at the bias: one add per output value less in the epilogue (the sum then rounds as
+#pragma unroll                                                // bias + p1 + p2 + ... instead of (p1 + p2 + ...) + bias: inside the bf16 bar by orders of magnitude)
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
+        for (int q = 0; q < a.nchunks; ++q) {
+            if (F32SRC) {
+                const unsigned char* buf = lds + wres_bytes + pb * stage_bytes;
+                const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
+                dma_wait_all();
+                __syncthreads();                              // this chunk (and the resident weights) visible; everyone is done with the other buffer
+                const bool more = ltile < tile_end;           // wave-uniform
+                const int nq = lq;
+                // (the DMA instructions spread over the taps of the sweep instead of this burst - what gained 4 % on the F(4x4,3x3) kernel, whose MFMA
+                // phase runs from registers - was measured here too, tools/sessions/r04_s36.sh: 181 -> 191 us on mask.enc0.1, configs[4] 324-333 ->
+                // 311-315 keyframes/s: this sweep reads its operands from LDS and a wave held by a DMA instruction stops feeding them)
+                if (more) issue(nq, pb ^ 1);
+                if (q == 0) flush();                          // the previous tile's results leave while this chunk is swept
+                sweep(acc, buf, wl);
+                if (more) {
+                    stage_store(nq, pb ^ 1);                  // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
+                    advance();
                 }
+                pb ^= 1;
+            } else {
+                const unsigned char* buf = lds + wres_bytes + sb * stage_bytes;
+                const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
+                const int cnt = (int)(fifo & 255);
+                fifo >>= 8;
+                --depth;
+                dpend -= cnt;
+                dma_wait_upto(dpend);                         // this wave's share of the chunk (and of the resident weights, which went out first) has landed
+                __syncthreads();                              // ... everyone's has, and everyone is done with the stage of the previous chunk
+                if (!first && nissued < total_chunks) issue_next();
+                first = false;
+                if (q == 0) flush();                          // the previous tile's results leave while this chunk is swept
+                sweep(acc, buf, wl);
+                sb = sb + 1 == NS ? 0 : sb + 1;
             }
-            if (more) {
-                stage_store(nq, pb ^ 1);                      // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
-                advance();
-            }
-            pb ^= 1;
         }
 
         // ---- epilogue of the tile: D fragment lane l holds pixel (l & 15), couts (l >> 4) * 4 + r ------------------------------------------
         if (b8_out) {
-            const bool odd = (lane >> 4) & 1;
+            // activation: max(x, x * slope) (none: slope 1; LeakyReLU with 0 <= slope <= 1) or max(x, +0) (ReLU) - one wave-uniform branch per tile
+            auto finish = [&](auto relu_tag) {
+                constexpr bool RELU = decltype(relu_tag)::value;
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const int cout0 = (grp * MB + m) * 16 + g4;
-                unsigned lo[NB], hi[NB];                           // this lane's 4 channels of every pixel block, as bf16
+                for (int m = 0; m < MB; ++m) {
+                    unsigned lo[NB], hi[NB];                       // this lane's 4 channels of every pixel block, as bf16
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    float v[4];
+                    for (int i = 0; i < NB; ++i) {
+                        float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = acc[m][i][r] + bias[m][r];          // (padded channels: zero weights and zero bias give 0)
-                        v[r] = fmaxf(x, __uint_as_float(__float_as_uint(x * slope) & keep));
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = acc[m][i][r];          // (bias included; padded channels: zero weights and zero bias give 0)
+                            v[r] = RELU ? fmaxf(x, 0.f) : fmaxf(x, x * slope);
+                        }
+                        lo[i] = pack2(v[0], v[1]);
+                        hi[i] = pack2(v[2], v[3]);
                     }
-                    lo[i] = pack2(v[0], v[1]);
-                    hi[i] = pack2(v[2], v[3]);
-                }
-                if (NB >= 2) {
+                    if (NB >= 2) {
 #pragma unroll
-                    for (int pr = 0; pr < NPAIR; ++pr) {
-                        // even quad keeps block 2 pr and needs the partner's half of it; odd quad keeps block 2 pr + 1: each sends the other one
-                        const unsigned slo = odd ? lo[2 * pr] : lo[2 * pr + 1], shi = odd ? hi[2 * pr] : hi[2 * pr + 1];
-                        const unsigned rlo = (unsigned)__builtin_amdgcn_ds_swizzle((int)slo, 0x401F);     // lane ^ 16
-                        const unsigned rhi = (unsigned)__builtin_amdgcn_ds_swizzle((int)shi, 0x401F);
-                        pend[m][pr] = odd ? (i32x4){(int)rlo, (int)rhi, (int)lo[2 * pr + 1], (int)hi[2 * pr + 1]}
-                                          : (i32x4){(int)lo[2 * pr], (int)hi[2 * pr], (int)rlo, (int)rhi};
+                        for (int pr = 0; pr < NPAIR; ++pr) {
+                            // lanes (pixel, channel quad g) and (pixel, g ^ 1) exchange halves: v_permlane16_swap swaps the ODD 16-lane rows of its
+                            // first operand with the EVEN rows of its second - afterwards the even quads hold (own, partner's) quads of block 2 pr and the
+                            // odd quads (partner's, own) of block 2 pr + 1, both in channel order: no select, no LDS crossbar instruction
+                            const auto l = __builtin_amdgcn_permlane16_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+                            const auto h = __builtin_amdgcn_permlane16_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+                            pend[m][pr] = (i32x4){(int)l[0], (int)h[0], (int)l[1], (int)h[1]};
+                        }
+                    } else {
+                        pend[m][0] = (i32x4){(int)lo[0], (int)hi[0], 0, 0};
                     }
-                } else {
-                    pend[m][0] = (i32x4){(int)lo[0], (int)hi[0], 0, 0};
                 }
-            }
-            pend_tile = tile;
+            };
+            if (a.act == MR_ACT_RELU) finish(std::true_type{});
+            else finish(std::false_type{});
+            pend_ty = sty;
+            pend_tx = stx;
         } else if (!B8_DBG(8)) {
-            const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-            const int oy0 = ty * a.TH, ox0 = tx * 32;
+            const int oy0 = sty * a.TH, ox0 = stx * 32;
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
                 const int cout0 = (grp * MB + m) * 16 + g4;
@@ -425,12 +539,13 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (cout0 + r < a.Cout) {
-                            const float x = acc[m][i][r] + bias[m][r];
+                            const float x = acc[m][i][r];
                             o[r * chs] = fmaxf(x, __uint_as_float(__float_as_uint(x * slope) & keep));
                         }
                 }
             }
         }
+        if (++stx == a.tiles_x) { stx = 0; ++sty; }
     }
     flush();
 }
@@ -551,6 +666,11 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     k.KH = d->kh; k.KW = d->kw;
     k.Ho = d->out_h; k.Wo = d->out_w;
     k.dst = d->dst; k.dst_layout = d->dst_layout;
+    if (d->dst_layout == MR_LAYOUT_BF16_B8) {
+        const long long db = (long long)d->batch * ((d->out_channels + 7) / 8) * d->dst_plane_h * d->dst_plane_w * 16;
+        if (db >= (1ll << 31)) return MR_ERR_UNSUPPORTED;             // 32-bit byte offsets through the buffer descriptor
+        k.dst_bytes = (int)db;
+    }
     k.dst_H = d->dst_plane_h; k.dst_W = d->dst_plane_w;
     k.ostep_h = d->out_step_h < 1 ? 1 : d->out_step_h;
     k.ostep_w = d->out_step_w < 1 ? 1 : d->out_step_w;
@@ -585,13 +705,19 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     if (ntiles >= (1ll << 31) || ngroups >= 65536 || (long long)d->batch * nphase >= 65536) return MR_ERR_UNSUPPORTED;
     k.ntiles = (int)ntiles;
     // resident weights where the whole stream of a cout group fits next to the two input stages (every layer with few input channels)
+    bool any_f32 = false;
+    for (int s = 0; s < d->num_src; ++s) any_f32 = any_f32 || d->src_layout[s] == MR_LAYOUT_F32_NCHW;
+    if (d->pipeline_stages < 0 || d->pipeline_stages > MR_MAX_PIPELINE_BUFFERS) return MR_ERR_BAD_ARGUMENT;
+    const int ns = (any_f32 || d->pipeline_stages < 2) ? 2 : d->pipeline_stages;      // register-staged fp32 sources: the two-stage pipeline only
+    k.nstage = ns;
     const size_t wall = (size_t)nchunks * k.KH * k.KW * mb * 1024;
-    const size_t tile2 = 2 * (size_t)64 * k.PLANE;
+    const size_t tile2 = (size_t)ns * 64 * k.PLANE;
     out->wres = wall + tile2 <= 160 * 1024 && wall <= 112 * 1024;
     if (out->wres) {
         out->lds_bytes = wall + tile2;
         const long long jobs = ntiles * ngroups * d->batch * nphase;
         long long wgs_target = 1024;                          // ~4 workgroups per CU over the launch, each keeps its weights for tpw tiles
+        if (ns > 2) wgs_target = 512 * (long long)((160 * 1024) / out->lds_bytes > 0 ? (160 * 1024) / out->lds_bytes : 1);   // deep ring: two rounds of what fits on a CU
 #ifdef MR_B8_ABLATE
         { const char* e = getenv("MR_B8_WGS"); if (e && atoi(e) > 0) wgs_target = atoi(e); }
 #endif
@@ -600,7 +726,7 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
         if (tpw > 64) tpw = 64;
         k.tiles_per_wg = (int)tpw;
     } else {
-        out->lds_bytes = 2 * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);
+        out->lds_bytes = ns * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);
         k.tiles_per_wg = 1;
     }
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;

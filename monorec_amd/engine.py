@@ -154,7 +154,7 @@ class _Ref:
 # Environment variables that change WHICH kernels / forms a plan runs (and therefore its numerics and speed).  They exist for the tuning
 # sessions (A/B of a candidate table, of one kernel family); a stray one must not pass silently: `active_env_overrides()` is
 # echoed into bench.py's config block, and the first plan built under any of them warns once.
-ENV_OVERRIDES = ("MR_TUNED_SCHEDULES", "MR_TUNED_WINOGRAD", "MR_TUNED_B8", "MR_B8", "MR_B8_NB4", "MR_WINOGRAD", "MR_ONE_CHANNEL_KERNELS", "MR_HIP_LIBRARY",
+ENV_OVERRIDES = ("MR_TUNED_SCHEDULES", "MR_TUNED_WINOGRAD", "MR_TUNED_B8", "MR_B8", "MR_B8_NB4", "MR_B8_FEATS", "MR_WINOGRAD", "MR_ONE_CHANNEL_KERNELS", "MR_HIP_LIBRARY",
                  "MR_DIAG_STREAM_LAYOUT", "MR_DIAG_STREAM_PRIO")
 _warned_env = [False]
 
@@ -462,6 +462,7 @@ class Plan:
         # csrc/conv_b8.hip) - half the HBM bytes, the MFMA operand read from LDS as it is.  MR_B8=0: A/B aid (fp32 storage as in rounds 1-3)
         import os as _os0
         self.b8 = self.bf16 == 1 and _os0.environ.get("MR_B8", "1") != "0"
+        self.b8_feature_copies = _os0.environ.get("MR_B8_FEATS", "1") != "0"      # MR_B8_FEATS=0: A/B aid (decoders read the fp32 image features, rounds 4-5)
         self.sd = state
         self.buf = {}
         self.keep = []          # packed weights / biases (device tensors kept alive)
@@ -1118,8 +1119,10 @@ class Plan:
         assert on == n and oc == cout and out.is_contiguous(), (name, on, n, oc, cout)
         f32_source = any(i[0] == LAYOUT_F32_NCHW for i in infos)
         sig = f"b8_co{cout}_ci{'+'.join(str(c) for c in src_channels)}_k{kh}x{kw}_s{stride[0]}x{stride[1]}_o{out_h}x{out_w}_b{n}_p{len(plist)}"
-        mb, nb, waves = (self.schedule_override.get(name) or B8_SCHEDULES.get(sig + f"_f{int(f32_source)}") or
-                         self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist), f32_source=f32_source))
+        sched8 = tuple(self.schedule_override.get(name) or B8_SCHEDULES.get(sig + f"_f{int(f32_source)}") or
+                       self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist), f32_source=f32_source))
+        mb, nb, waves = sched8[:3]
+        nstage = int(sched8[3]) if len(sched8) > 3 else 0      # LDS ring depth of the input pipeline (0: two stages)
         d = B8ConvDesc()
         sc = (ctypes.c_int32 * len(srcs))(*src_channels)
         for i, s_ in enumerate(srcs):
@@ -1134,6 +1137,7 @@ class Plan:
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         d.activation, d.act_p0 = act, p0
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.waves_per_wg = mb, nb, waves
+        d.pipeline_stages = nstage
         d.num_phases = len(plist)
         for i, (wp, pt, pl, oh_, ow_) in enumerate(plist):
             wc = wp.detach().to(torch.float32).contiguous().cpu()
@@ -1149,12 +1153,12 @@ class Plan:
             d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh_, ow_
         lds = lib.mr_conv2d_b8_lds_bytes(ctypes.byref(d))
         if lds < 0:
-            _lib.check(int(lds), f"plan {name} b8 sched={(mb, nb, waves)}")
+            _lib.check(int(lds), f"plan {name} b8 sched={(mb, nb, waves, nstage)}")
         taps = sum(int(p[0].shape[2]) * int(p[0].shape[3]) for p in plist)
         macs = n * out_h * out_w * cout * cin * taps
         th = waves * nb // 2
         wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * math.ceil(((cout + 15) // 16) / mb) * n * len(plist)
-        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=1, ck=32, waves=waves, kws=0,
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=1, ck=32, waves=waves, kws=0, nbuf=nstage,
                                   wgs=wgs, lds=int(lds), cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=len(plist), bf16=1, b8=True,
                                   sig=sig, f32_source=f32_source,
                                   spec=dict(src_shapes=[(i[1], i[2], i[3], i[4]) for i in infos], src_layouts=[i[0] for i in infos], w_shape=(cout, cin, kh, kw),
@@ -1533,6 +1537,19 @@ class Plan:
                     _lib.check(lib.mr_max_over_frames_b8(src.data_ptr(), dst.data_ptr(), F, count, stream), "mr_max_over_frames_b8")
                 self.add(st, f"mask.max{i}", run_max)
         st = "main"
+        # the image features (fp32 outputs of the ResNet trunk) are each read by TWO decoder layers: one conversion launch per feature map and
+        # both readers take the B8 copy by LDS-DMA instead of staging 4-byte planes through registers (round 6: depth.dec3 157 us of which 148
+        # are that staging path, profiles/r06_c5bf16_b8_ablation.txt).  Same round-to-nearest-even as the staging path: results bit-identical.
+        fsrc = list(feats)
+        if self.b8_feature_copies:
+            for i in range(4):
+                fb = self.alloc_b8(f"feat{i}_b8", B, int(feats[i].shape[1]), int(feats[i].shape[2]), int(feats[i].shape[3]))
+
+                def run_fb(stream, src=self.ref(feats[i]), dst=fb, c_=int(feats[i].shape[1]), hw_=int(feats[i].shape[2] * feats[i].shape[3])):
+                    _lib.check(lib.mr_f32_nchw_to_b8(src.ptr(), dst.data_ptr(), B, c_, hw_, stream), "mr_f32_nchw_to_b8")
+                self.add(st, f"feat{i}.to_b8", run_fb)
+                fsrc[i] = fb
+        feats_out, feats = feats, fsrc
         x_srcs = [cvf[4], feats[3]]                                                  # :372
         for i in range(4):
             hi, wi = H >> (3 - i), W >> (3 - i)

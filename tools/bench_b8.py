@@ -44,8 +44,7 @@ def main():
     wt = torch.randn(cout, sum(srcs_c), kh, kw, generator=g) / math.sqrt(kh * kw * sum(srcs_c))
     bias = torch.zeros(cout)
     for sched in args.scheds:
-        mb, nb, wv = [int(v) for v in sched.split(",")]
-        plan = engine.Plan.bare(dev, schedule_override={"t": (mb, nb, wv)}, bf16=1)
+        plan = engine.Plan.bare(dev, schedule_override={"t": tuple(int(v) for v in sched.split(","))}, bf16=1)      # mb,nb,waves[,ring stages]
         srcs = []
         for c, lay in zip(srcs_c, lays):
             if lay:

@@ -28,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VF asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fx) : "v"(a));
 #define SA asm volatile("s_add_i32 %0, %0, 4" : "+s"(s0));
 #define DS asm volatile("ds_read_b32 %0, %1" : "=v"(lv) : "v"(laddr));
+#define BM(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ba), "v"(bb));
 #define FILL asm volatile("v_add_u32 %0, %1, %0\n s_add_i32 %2, %2, 4\n s_add_i32 %3, %3, %2" : "+v"(addr), "+s"(s0), "+s"(s1) : "s"(s0));
 
 template <int KIND, int THREADS>
@@ -39,6 +40,10 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, long long* cyc, int
     f32x16 e0 = {0}, e1 = {0};
     int addr = threadIdx.x, s0 = 1, s1 = 2;
     float fx = a, lv = 0.f;
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    const unsigned hsh = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    const i32x4v ba = {(int)(0x3f803f00u ^ (hsh & 0x007f007f)), (int)(0xbf003e80u ^ ((hsh >> 3) & 0x007f007f)), (int)(0x3e003f40u ^ ((hsh >> 5) & 0x007f007f)), (int)(0xbe803f20u ^ ((hsh >> 7) & 0x007f007f))};
+    const i32x4v bb = {(int)(0x3f003f80u ^ ((hsh >> 2) & 0x007f007f)), (int)(0x3e80bf00u ^ ((hsh >> 4) & 0x007f007f)), (int)(0x3f403e00u ^ ((hsh >> 6) & 0x007f007f)), (int)(0x3f20be80u ^ ((hsh >> 8) & 0x007f007f))};
     const unsigned laddr = (threadIdx.x & 63) * 4;
     if (iters < 0) lds[threadIdx.x] = a;          // keeps the allocation
     __syncthreads();
@@ -68,6 +73,13 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, long long* cyc, int
         if (KIND == 16) { REP4(M1(c0) M1(c1) M1(c2) M1(c3) VA VA VA VA VA VA VA VA VA VA VA VA VA VA VA VA) n = 16; }   // 16 VALU grouped per 4 MFMAs
         if (KIND == 17) { REP4(M1(c0) VF M1(c1) VF M1(c2) VF M1(c3) VF) n = 16; }                   // v_fma_f32 instead of v_add_u32, interleaved
         if (KIND == 18) { REP4(M1(c0) M1(c1) M1(c2) M1(c3) VF VF VF VF VF VF VF VF VF VF VF VF VF VF VF VF) n = 16; }   // 16 v_fma_f32 grouped per 4 MFMAs
+        if (KIND == 20) {   // v_mfma_f32_16x16x32_bf16, 12 accumulators (conv_b8_kernel's 3 x 4 register tile), operands with varied bits
+            REP4(BM(c0) BM(c1) BM(c2) BM(c3) BM(c4) BM(c5) BM(c6) BM(c7) BM(d0) BM(d1) BM(d2) BM(d3)) n = 48;
+        }
+        if (KIND == 21) {   // v_mfma_f32_32x32x16_bf16, 2 accumulators
+            REP4(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "+v"(e0), "+v"(e1) : "v"(ba), "v"(bb));)
+            n = 8;
+        }
         if (KIND == 19) { REP4(M1(c0) DS DS VA M1(c1) DS DS VA M1(c2) DS DS VA M1(c3) DS DS VA) n = 16; }   // the un-specialised sweep's mix: 2 LDS reads + 1 VALU per MFMA
     }
     const long long t1 = clock64();
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, long long* cyc, int
 
 template <int KIND, int THREADS>
 void run(const char* what, float* out, long long* cyc) {
-    const int iters = 2000, blocks = 256;
+    const int iters = (KIND == 20 || KIND == 21) ? 20000 : 2000, blocks = 256;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<KIND, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -98,7 +110,7 @@ void run(const char* what, float* out, long long* cyc) {
     c /= blocks;
     const double per_wave = (double)h[1];
     const int wps = THREADS / 256;
-    const int flop = KIND == 7 ? 4096 : 2048;
+    const int flop = KIND == 7 ? 4096 : (KIND == 20 ? 16384 : (KIND == 21 ? 32768 : 2048));
     printf("KIND %d %-58s %d wave(s)/SIMD: %6.1f cycles per MFMA and SIMD  (%.0f MFMAs/wave, %.3f ms -> %.1f TF, clock ~%.0f MHz)\n", KIND, what, wps,
            c / (per_wave * wps), per_wave, ms, (double)blocks * THREADS / 64 * per_wave * flop / (ms * 1e-3) / 1e12, c / (ms * 1e3));
 }
@@ -118,6 +130,8 @@ int main() {
     BOTH(5, "2 accumulators + 1 VALU + 2 SALU per MFMA")
     BOTH(6, "4 accumulators + 1 VALU + 2 SALU per MFMA")
     BOTH(7, "32x32x2, 2 accumulators")
+    BOTH(20, "bf16 16x16x32, 12 accumulators")
+    BOTH(21, "bf16 32x32x16, 2 accumulators")
     BOTH(9, "4 MFMA then 4 VALU grouped")
     BOTH(10, "4 x (MFMA, VALU) interleaved")
     BOTH(11, "4 MFMA then 1 VALU")

@@ -153,7 +153,7 @@ def kernel_instance(c):
         if c.get("wino_axis") is not None:
             m, taps = c.get("wino_m", 2), c.get("wino_taps") or max(c["k"])
             return f"conv1d3_wino_kernel<{c['wino_axis']}, {c['mb']}>" if (m, taps) == (2, 3) else f"conv1d_ct_kernel<{c['wino_axis']}, {c['mb']}, {m}, {taps}>"
-        return {3: "conv3x3_wino44_kernel", 4: "conv3x3_wino44s_kernel", 1: "conv3x3_wino_rb_kernel", 2: "conv3x3_wino_rb_kernel"}.get(v, "conv3x3_wino_kernel")
+        return {3: "conv3x3_wino44_kernel", 4: "conv3x3_wino44s_kernel", 5: "conv3x3_wino44w_kernel", 1: "conv3x3_wino_rb_kernel", 2: "conv3x3_wino_rb_kernel"}.get(v, "conv3x3_wino_kernel")
     sp = c.get("spec") or {}
     dma = sp.get("in_mode", 0) != 2 and sp.get("tf", 0) == 0          # MR_IN_MAXPOOL2 / an input transform: the register-staged instantiation
     return (f"conv_mfma_kernel<{c['mb']}, {c['nb']}, {'true' if dma else 'false'}, {c.get('waves', 4)}, {int(c.get('bf16', 0))}, "
@@ -791,8 +791,8 @@ def main():
                              "valu_frac_note": "SQ_INSTS_VALU x 64 lanes / sad-kernel time / 78.6e12 lane-instr/s", "counters_source": pmc_src})
             if sad.get("lds_bank_conflict_frac") is not None:
                 cv_block["lds_bank_conflict_frac"] = sad["lds_bank_conflict_frac"]
-        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") not in (3, 4))
-        n_wino44 = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") in (3, 4))
+        n_wino = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") not in (3, 4, 5))
+        n_wino44 = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and c["phases"] == 1 and tuple(c["k"]) == (3, 3) and c.get("wino_variant") in (3, 4, 5))
         n_wino_1d = sum(1 for c in model._plans[plan_key].conv_log if c.get("winograd") and min(c["k"]) == 1 and c.get("wino_m", 2) == 2 and max(c["k"]) == 3)
         ct_forms = sorted({f"F({c['wino_m']},{c.get('wino_taps') or max(c['k'])})" + (" over [even | odd] (stride 2)" if c.get("stride2") else "")
                            for c in model._plans[plan_key].conv_log

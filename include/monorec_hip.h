@@ -260,6 +260,14 @@ int mr_wino44s_pack_weights_f32(const float* weight, int32_t out_channels, const
 int64_t mr_conv3x3_winograd44s_lds_bytes(const mr_wino_desc* desc);
 int mr_conv3x3_winograd44s_f32(const mr_wino_desc* desc, void* stream);
 
+/* The same F(4x4, 3x3) convolution with ONE WAVE PER SIMD (csrc/conv_wino44w.hip, round 6, ABI 19): 4 waves of 512 registers on 16 x 64 output pixels x 32
+ * channels; a wave owns a tile row and BOTH 16-channel blocks (72 accumulator sets), so the input transform - VALU work that runs on the same ALUs as
+ * the fp32 MFMAs - is done once per 72 MFMAs instead of once per 36, and the patch reads of the next channel quad are in flight while the current
+ * quad multiplies; K in single-quad stages through a ring of four (partial vmcnt waits).  Packed weights of mr_wino44_pack_weights_f32; the same
+ * products as mr_conv3x3_winograd44_f32, summed in the same order per output (bit-identical results).  Table code 51. */
+int64_t mr_conv3x3_winograd44w_lds_bytes(const mr_wino_desc* desc);
+int mr_conv3x3_winograd44w_f32(const mr_wino_desc* desc, void* stream);
+
 /* Exported by the DIAGNOSTIC build only (python -m monorec_amd.build --timeline -> libmonorec_hip_timeline.so, selected with MR_HIP_LIBRARY):
  * bit 0 = the F(2,7) instantiations of mr_conv1d_cooktoom_f32 are present (no measured table entry ever selected them). */
 #ifdef MR_DIAGNOSTIC_LIBRARY
@@ -516,6 +524,7 @@ int mr_gather_small_f32(const float* const* srcs, int32_t num, int32_t floats_ea
 #define MR_LAUNCH_WINO44  6
 #define MR_LAUNCH_CONV_B8 7
 #define MR_LAUNCH_WINO44S 8
+#define MR_LAUNCH_WINO44W 9
 typedef struct mr_launch_item {
     int32_t kind;
     int32_t arg;

@@ -103,7 +103,7 @@ class LaunchItem(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("arg", ctypes.c_int32), ("desc", ctypes.c_void_p)]
 
 
-LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV, LAUNCH_COOKTOOM_1D, LAUNCH_WINO44, LAUNCH_CONV_B8, LAUNCH_WINO44S = 0, 1, 2, 3, 4, 5, 6, 7, 8
+LAUNCH_CONV2D, LAUNCH_WINO3X3, LAUNCH_WINO_T, LAUNCH_WINO_1D, LAUNCH_UPCONV, LAUNCH_COOKTOOM_1D, LAUNCH_WINO44, LAUNCH_CONV_B8, LAUNCH_WINO44S, LAUNCH_WINO44W = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class HeadDesc(ctypes.Structure):
@@ -253,6 +253,8 @@ ABI = {
     "mr_wino44s_pack_weights_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_void_p]),
     "mr_conv3x3_winograd44s_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
     "mr_conv3x3_winograd44s_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
+    "mr_conv3x3_winograd44w_lds_bytes": (ctypes.c_int64, [ctypes.POINTER(WinoDesc)]),
+    "mr_conv3x3_winograd44w_f32": (ctypes.c_int, [ctypes.POINTER(WinoDesc), ctypes.c_void_p]),
     "mr_abi_version": (ctypes.c_int, []),
     "mr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
 }

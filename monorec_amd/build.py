@@ -32,6 +32,7 @@ SOURCES = [
     # tools/sessions/r04_s27.sh: c2 739 vs 740, c3 654 vs 655, configs[4] bf16 333 vs 330 keyframes/s - noise, so only this kernel has it)
     ("conv_wino44.hip", ["-fno-slp-vectorize"]),
     ("conv_wino44s.hip", ["-fno-slp-vectorize"]),      # F(4x4,3x3) with the positions split over two waves: two workgroups per CU (round 5)
+    ("conv_wino44w.hip", ["-fno-slp-vectorize"]),      # F(4x4,3x3) with one wave per SIMD: both cout blocks per wave, quad pipeline in registers (round 6)
 ]
 # conv_wino44.hip (F(4x4,3x3)): out of the product library for most of round 4 (at c2 it moved keyframes/s by nothing),
 # back in once its c3 / configs[4] tables were measured (tools/sessions/r04_s18.sh): 12-15 % ahead of the best F(2x2,3x3) variant on every

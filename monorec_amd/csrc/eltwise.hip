@@ -340,6 +340,7 @@ extern "C" int mr_run_launches(const mr_launch_item* items, int32_t num, void* s
             case MR_LAUNCH_UPCONV: rc = mr_upconv2x2_winograd_f32((const mr_wino_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_WINO44: rc = mr_conv3x3_winograd44_f32((const mr_wino_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_WINO44S: rc = mr_conv3x3_winograd44s_f32((const mr_wino_desc*)items[i].desc, stream); break;
+            case MR_LAUNCH_WINO44W: rc = mr_conv3x3_winograd44w_f32((const mr_wino_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_CONV_B8: rc = mr_conv2d_b8((const mr_b8_conv_desc*)items[i].desc, stream); break;
             case MR_LAUNCH_COOKTOOM_1D:
                 rc = mr_conv1d_cooktoom_f32((const mr_wino_desc*)items[i].desc, items[i].arg & 15, (items[i].arg >> 4) & 15, (items[i].arg >> 8) & 15, stream);

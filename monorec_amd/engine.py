@@ -257,7 +257,7 @@ def choose_winograd(cout, src_channels, h, w, batch, f2=False):
     sig = winograd_signature(cout, src_channels, h, w, batch)
     if sig in WINOGRAD:
         code = WINOGRAD[sig]
-        if f2 and code // 10 in (3, 4):      # F(4x4,3x3), either kernel -> the F(2x2,3x3) variant measured before it (else: transform in registers, 32 channels)
+        if f2 and code // 10 in (3, 4, 5):      # F(4x4,3x3), either kernel -> the F(2x2,3x3) variant measured before it (else: transform in registers, 32 channels)
             code = WINOGRAD_F2.get(sig, 11)
         return code
     tiles = math.ceil(h / 8) * math.ceil(w / 32) * batch
@@ -735,7 +735,7 @@ class Plan:
             nfl = lib.mr_wino44s_packed_weight_floats(cout, sc, len(src_channels))
             packed = torch.empty(nfl, dtype=torch.float32)
             _lib.check(lib.mr_wino44s_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44s_pack_weights_f32")
-        elif variant == 3:     # F(4x4,3x3) (csrc/conv_wino44.hip): 36 positions, 16 x 64 pixels x 32 channels per workgroup
+        elif variant in (3, 5):     # F(4x4,3x3) (csrc/conv_wino44.hip; 5: csrc/conv_wino44w.hip, one wave per SIMD): 36 positions, 16 x 64 pixels x 32 channels per workgroup
             nfl = lib.mr_wino44_packed_weight_floats(cout, sc, len(src_channels))
             packed = torch.empty(nfl, dtype=torch.float32)
             _lib.check(lib.mr_wino44_pack_weights_f32(w.data_ptr(), cout, sc, len(src_channels), packed.data_ptr()), "mr_wino44_pack_weights_f32")
@@ -762,18 +762,18 @@ class Plan:
             assert residual.shape == out.shape
             d.residual = residual.data_ptr()
         d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, p0, mbw, variant
-        lds = (lib.mr_conv3x3_winograd44s_lds_bytes(ctypes.byref(d)) if variant == 4 else
+        lds = (lib.mr_conv3x3_winograd44s_lds_bytes(ctypes.byref(d)) if variant == 4 else lib.mr_conv3x3_winograd44w_lds_bytes(ctypes.byref(d)) if variant == 5 else
                lib.mr_conv3x3_winograd44_lds_bytes(ctypes.byref(d)) if variant == 3 else lib.mr_conv3x3_winograd_lds_bytes(ctypes.byref(d)))
         if lds < 0:
             _lib.check(int(lds), f"plan {name} winograd")
         ref = n * hs * ws * cout * cin * 9
         if variant == 4:
             wgs = math.ceil(hs / 8) * math.ceil(ws / 64) * n * math.ceil(cout / 32)
-        elif variant == 3:
+        elif variant in (3, 5):
             wgs = math.ceil(hs / 16) * math.ceil(ws / 64) * n * math.ceil(cout / 32)
         else:
             wgs = math.ceil(hs / 8) * math.ceil(ws / 32) * n * math.ceil(cout / (32 * mbw))
-        self.conv_log.append(dict(name=name, macs=ref // 4 if variant in (3, 4) else ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=4 if variant == 4 else 8, waves=8, kws=0, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=ref // 4 if variant in (3, 4, 5) else ref * 4 // 9, ref_macs=ref, mb=mbw, nb=0, split_k=1, ck=4 if variant in (4, 5) else 8, waves=4 if variant == 5 else 8, kws=0, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(3, 3), out=(hs, ws), batch=n, phases=1, winograd=mbw, wino_variant=variant, bf16=0,
                                   sig=winograd_signature(cout, src_channels, hs, ws, n),
                                   spec=dict(src_shapes=[tuple(s_.shape) for s_ in srcs], w_shape=(cout, cin, 3, 3), stride=(1, 1), pad=(1, 1),
@@ -785,6 +785,10 @@ class Plan:
             def run(stream):
                 _lib.check(lib.mr_conv3x3_winograd44s_f32(ctypes.byref(d), stream), name)
             run.native = (_lib.LAUNCH_WINO44S, d, 0)
+        elif variant == 5:
+            def run(stream):
+                _lib.check(lib.mr_conv3x3_winograd44w_f32(ctypes.byref(d), stream), name)
+            run.native = (_lib.LAUNCH_WINO44W, d, 0)
         elif variant == 3:
             def run(stream):
                 _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), stream), name)

@@ -1354,7 +1354,9 @@ def test_bf16_mode_plan_stores_mask_and_depth_activations_in_b8(hip_lib, monkeyp
     assert abs(plan.conv_ref_macs() / 1e9 - (61.07 - 0.068)) < 0.01          # the reference's conv multiply-adds, as in the fp32 plan
     by = {c["name"]: c for c in b8}
     assert by["mask.enc0.0"]["spec"]["src_layouts"] == [1] and by["mask.enc0.0"]["spec"]["out_layout"] == 1       # the B8 copy the cost-volume fusion kernel writes
-    assert by["mask.dec1.1"]["spec"]["src_layouts"] == [1, 0, 1]                                                   # B8 / fp32 image features / B8
+    assert by["mask.dec1.1"]["spec"]["src_layouts"] == [1, 1, 1]                                                   # B8 / B8 copy of the image features (round 6) / B8
+    assert [n for n, _ in plan.stages["main"]][:4] == [f"feat{i}.to_b8" for i in range(4)] and tuple(plan.buf["feat0_b8"].shape) == (1, 8, 128, 256, 8)
+    assert by["depth.dec3"]["spec"]["src_layouts"] == [1, 1, 0]                                                    # ... the fp32 map the depth heads read stays fp32
     assert by["depth.enc0.0.conv_y"]["spec"]["src_layouts"] == [1, 0]                                              # B8 copy of the masked volume (classifier kernel) + keyframe
     assert plan._sfcv_b8_ptrs is not None and tuple(plan.buf["sfcv_b8"].shape) == (2, 4, 256, 512, 8) and tuple(plan.buf["cost_volume_b8"].shape) == (1, 4, 256, 512, 8)
     fp32_out = {c["name"] for c in b8 if c["spec"]["out_layout"] == 0}
@@ -1363,6 +1365,10 @@ def test_bf16_mode_plan_stores_mask_and_depth_activations_in_b8(hip_lib, monkeyp
     assert plan.buf["mask.enc0.x"].dtype == torch.bfloat16 and tuple(plan.buf["mask.enc0.x"].shape) == (2, 4, 256, 512, 8)
     assert plan.buf["cost_volume"].dtype == torch.float32 and plan.buf["feat2"].dtype == torch.float32 and plan.buf["pred0"].dtype == torch.float32
     assert plan.outputs_rebindable and {r[3] for r in plan._relocs} >= {"sfcv", "feat0", "feat1", "feat2", "pred0", "pred3"}    # (the fused volume: closures only)
+    monkeypatch.setenv("MR_B8_FEATS", "0")                                                                         # A/B aid: the decoders stage the fp32 features (rounds 4-5)
+    nofc = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", bf16=1)
+    assert {c["name"]: c for c in nofc.conv_log}["mask.dec1.1"]["spec"]["src_layouts"] == [1, 0, 1] and "feat0_b8" not in nofc.buf
+    monkeypatch.delenv("MR_B8_FEATS")
     monkeypatch.setenv("MR_B8", "0")
     old = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu", bf16=1)
     assert not old.b8 and not any(c.get("b8") for c in old.conv_log) and all(c["bf16"] == 1 for c in old.conv_log)

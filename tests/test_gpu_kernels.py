@@ -1007,7 +1007,7 @@ WINO44_EXTRA_CASES = [((32,), 32, (64, 128), 2, ACT_LEAKY_RELU, False, 1),      
                       ((48,), 48, (40, 192), 1, ACT_LEAKY_RELU, False, 1)]        # 48 = 32 + 16: the second group's upper block is empty; H % 16 != 0
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "w"])
 @pytest.mark.parametrize("case", range(len(WINO_CASES) + len(WINO44_EXTRA_CASES)))
 def test_winograd44_conv_matches_torch_fp32(hip_lib, case, split):
     """mr_conv3x3_winograd44_f32 (F(4x4,3x3), csrc/conv_wino44.hip) - and, `split`, mr_conv3x3_winograd44s_f32 (csrc/conv_wino44s.hip, round 5: the
@@ -1017,7 +1017,9 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case, split):
     srcs_c, cout, (h, w), batch, act, residual, _ = (WINO_CASES + WINO44_EXTRA_CASES)[case]
     lib = hip_lib
     size_fn, pack_fn, lds_fn, run_fn, lds_cap = ((lib.mr_wino44s_packed_weight_floats, lib.mr_wino44s_pack_weights_f32, lib.mr_conv3x3_winograd44s_lds_bytes,
-                                                  lib.mr_conv3x3_winograd44s_f32, 80 * 1024) if split else
+                                                  lib.mr_conv3x3_winograd44s_f32, 80 * 1024) if split is True else
+                                                 (lib.mr_wino44_packed_weight_floats, lib.mr_wino44_pack_weights_f32, lib.mr_conv3x3_winograd44w_lds_bytes,
+                                                  lib.mr_conv3x3_winograd44w_f32, 160 * 1024) if split == "w" else      # round 6: one wave per SIMD, both cout blocks per wave
                                                  (lib.mr_wino44_packed_weight_floats, lib.mr_wino44_pack_weights_f32, lib.mr_conv3x3_winograd44_lds_bytes,
                                                   lib.mr_conv3x3_winograd44_f32, 160 * 1024))
     g = torch.Generator().manual_seed(100 + case)
@@ -1042,7 +1044,7 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case, split):
     pk, bs, rs = packed.to(DEV), bias.to(DEV), (res.to(DEV) if residual else None)
     d.num_src, d.batch, d.height, d.width, d.dst, d.out_channels = len(srcs), batch, h, w, out.data_ptr(), cout
     d.packed_weights, d.bias, d.residual = pk.data_ptr(), bs.data_ptr(), (rs.data_ptr() if residual else None)
-    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, 1, 4 if split else 3
+    d.activation, d.act_p0, d.cout_blocks_per_wave, d.variant = act, 0.1, 1, 4 if split is True else (5 if split == "w" else 3)
     assert 0 < lds_fn(ctypes.byref(d)) <= lds_cap                  # (split: two workgroups per CU)
     _lib.check(run_fn(ctypes.byref(d), _stream()), "mr_conv3x3_winograd44[s]_f32")
     torch.cuda.synchronize()
@@ -1050,6 +1052,13 @@ def test_winograd44_conv_matches_torch_fp32(hip_lib, case, split):
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err <= 4e-5 * max(1.0, float(ref.abs().max())), err
+    if split == "w":                                               # same products, same order per output as conv_wino44.hip: bit-identical
+        out3 = torch.full((batch, cout, h, w), float("nan"), device=DEV)
+        d.dst, d.variant = out3.data_ptr(), 3
+        _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), _stream()), "mr_conv3x3_winograd44_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(out3.cpu(), got), float((out3.cpu() - got).abs().max())
+        d.dst, d.variant = out.data_ptr(), 5
     if case == 0:
         d.width = 98
         assert run_fn(ctypes.byref(d), _stream()) == -2            # width % 4: unsupported

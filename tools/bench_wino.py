@@ -44,7 +44,7 @@ def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, varia
         n = lib.mr_wino44s_packed_weight_floats(weight.shape[0], arr, len(sc))
         packed = torch.empty(n, dtype=torch.float32)
         _lib.check(lib.mr_wino44s_pack_weights_f32(weight.contiguous().data_ptr(), weight.shape[0], arr, len(sc), packed.data_ptr()), "pack")
-    elif variant == 3:                                 # F(4x4,3x3): csrc/conv_wino44.hip
+    elif variant in (3, 5):                            # F(4x4,3x3): csrc/conv_wino44.hip / conv_wino44w.hip (one wave per SIMD)
         n = lib.mr_wino44_packed_weight_floats(weight.shape[0], arr, len(sc))
         packed = torch.empty(n, dtype=torch.float32)
         _lib.check(lib.mr_wino44_pack_weights_f32(weight.contiguous().data_ptr(), weight.shape[0], arr, len(sc), packed.data_ptr()), "pack")
@@ -68,12 +68,14 @@ def wino_launch(lib, srcs, weight, bias, out, act, p0, mbw, residual=None, varia
     keep = (pk, bs, d)
     if variant == 4:
         return (lambda stream: _lib.check(lib.mr_conv3x3_winograd44s_f32(ctypes.byref(d), stream), "wino44s")), keep
+    if variant == 5:
+        return (lambda stream: _lib.check(lib.mr_conv3x3_winograd44w_f32(ctypes.byref(d), stream), "wino44w")), keep
     if variant == 3:
         return (lambda stream: _lib.check(lib.mr_conv3x3_winograd44_f32(ctypes.byref(d), stream), "wino44")), keep
     return (lambda stream: _lib.check(lib.mr_conv3x3_winograd_f32(ctypes.byref(d), stream), "wino")), keep
 
 
-CODES = (1, 2, 11, 12, 21, 31, 41)
+CODES = (1, 2, 11, 12, 21, 31, 41, 51)
 
 
 def main():

@@ -69,6 +69,7 @@ def parse():
                     help="convolutions on the bf16 MFMA (BASELINE configs[4] numerics; outside the 1e-4 parity bar - never the headline)")
     ap.add_argument("--cv-separable", action="store_true", help="MonoRecModel(hip_cv_separable=True): the cost volume's 3x3 window sums formed separably (opt-in of the fp32 path; "
                                                                "volumes within 1e-4, depth within 2e-6 of the default) - a secondary configuration, never the headline")
+    ap.add_argument("--skip-layer4", action="store_true", help="MonoRecModel(hip_skip_dead_layer4=True): the dead ResNet layer4 is not launched (opt-in; the default line computes it)")
     ap.add_argument("--lean-outputs", action="store_true", help="with --bf16: MonoRecModel(hip_lean_outputs=True) - no dense fp32 single_frame_cvs in the output dict")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="keyframes kept in flight per GPU (MonoRecModel.submit; the model's default: 4); 1 = strictly one forward at a time")
@@ -520,6 +521,39 @@ def secondary_exact_convs(sd, batch_dev, ref, dev, args, steps=120):
     return out
 
 
+def secondary_skip_dead_layer4(sd, batch_dev, ref, dev, args, steps=200):
+    """SECONDARY number, never `value`: MonoRecModel(hip_skip_dead_layer4=True) - ResNet layer4 (monorec_model.py:118-129; its output image_features[4]
+    is read by nobody, :372-380,545) is not launched: 5 convolutions + 3 split-K finishing kernels less per keyframe.  `result` and
+    `cv_mask` are bit-identical (tests/test_gpu_model.py); `image_features` has four entries.  Opt-in: the default computes what the reference computes."""
+    import collections
+    from monorec_amd import MonoRecModel
+    m = MonoRecModel(cv_depth_steps=args.depths, hip_in_flight=args.in_flight, hip_skip_dead_layer4=True, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    pending = collections.deque()
+
+    def run(n):
+        last = None
+        for _ in range(n):
+            req = dict(batch_dev)
+            token = m.prepare(req)
+            if len(pending) >= args.in_flight:
+                last = pending.popleft().synchronize()
+            pending.append(m.submit(req, token))
+        while pending:
+            last = pending.popleft().synchronize()
+        torch.cuda.synchronize()
+        return last
+    with torch.no_grad():
+        run(40)
+        t0 = time.perf_counter()
+        last = run(steps)
+        dt = time.perf_counter() - t0
+    return {"value": steps * args.batch / dt, "unit": "keyframes/s", "steps": steps, "image_features_entries": len(last["image_features"]),
+            "depth_max_abs_err_vs_cpu": float((last["result"].cpu() - ref["result"]).abs().max()),
+            "note": "opt-in hip_skip_dead_layer4=True: the dead ResNet layer4 is not launched; secondary - the headline computes every layer the reference computes"}
+
+
 def forward_api(model, batch_dev, batch, steps=100):
     """Keyframes/s through the API the reference's scripts use - `data = model(data)` (evaluater/evaluater.py:83,
     create_pointcloud.py:70): one forward at a time on the caller's stream, outputs copied into tensors the caller owns (one
@@ -609,7 +643,7 @@ def main():
 
     model = MonoRecModel(cv_depth_steps=args.depths, hip_graph=args.graph, hip_in_flight=args.in_flight, hip_bf16=args.bf16,
                          hip_bf16x3=args.bf16x3, hip_queue_depth=args.queue_depth, hip_single_stream=args.single_stream,
-                         hip_cv_separable=args.cv_separable, hip_lean_outputs=args.lean_outputs, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
+                         hip_cv_separable=args.cv_separable, hip_lean_outputs=args.lean_outputs, hip_skip_dead_layer4=args.skip_layer4, hip_slot_streams=args.slot_streams or None, hip_streams=args.streams or None)
     sd = synth.seeded_state_dict(model.state_dict(), seed=0)     # random-init architecture weights (no checkpoint offline)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -942,7 +976,7 @@ def main():
                        "results_collected_by": "stream wait (handle.result())" if args.stream_collect else "host wait (handle.synchronize())",
                        "submit_and_result_streams": "caller's" if (not args.side_streams) else "one stream for submit(), one for result()",
                        "pose_matrices": "host" if args.host_mats else "device",
-                       "cv_separable_sums": bool(args.cv_separable), "lean_outputs": bool(args.lean_outputs),
+                       "cv_separable_sums": bool(args.cv_separable), "lean_outputs": bool(args.lean_outputs), "skip_dead_layer4": bool(args.skip_layer4),
                        "host_prime_ms": args.host_prime_ms,
                        "host_prime_note": "tail of the untimed warm-up: prepare() calls (pose algebra of a request; one small gather launch each when the matrices are on the device, no forward) between the closing synchronize() of the spin-up and the timed region",
                        "env_overrides": engine_env_overrides(),
@@ -997,6 +1031,7 @@ def main():
                 result["secondary_bf16x3"] = secondary_bf16x3(sd, batch_dev, ref, dev, args)
                 result["secondary_dynamic_batching"] = secondary_dynamic_batching(sd, batch_dev, ref, dev, args)
                 result["secondary_exact_convs"] = secondary_exact_convs(sd, batch_dev, ref, dev, args)
+                result["secondary_skip_dead_layer4"] = secondary_skip_dead_layer4(sd, batch_dev, ref, dev, args)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,6 +18,7 @@ stages, overlapped with the encoder stage (see MonoRecModel._forward_hip).
 """
 import ctypes
 import math
+import re
 
 import numpy as np
 import torch
@@ -243,6 +244,37 @@ def winograd_signature(cout, src_channels, h, w, batch):
     return f"co{cout}_ci{'+'.join(str(c) for c in src_channels)}_o{h}x{w}_b{batch}"
 
 
+_WSIG_RE = re.compile(r"^((?:[a-z]+\d*_)|(?:s2k\d+_))?co(\d+)_ci([\d+]+)_o(\d+)x(\d+)_b(\d+)$")
+_parsed_wino = [None, 0]
+
+
+def _wino_by_prefix():
+    if _parsed_wino[0] is None or _parsed_wino[1] != len(WINOGRAD):
+        by = {}
+        for key, code in WINOGRAD.items():
+            m = _WSIG_RE.match(key)
+            if not m:
+                continue
+            cis = [int(c) for c in m.group(3).split("+")]
+            by.setdefault(m.group(1) or "", []).append((int(m.group(2)), sum(cis), int(m.group(4)) * int(m.group(5)), int(m.group(6)), key, int(code)))
+        _parsed_wino[0], _parsed_wino[1] = by, len(WINOGRAD)
+    return _parsed_wino[0]
+
+
+def nearest_form(prefix, cout, cin, pixels, batch, valid=lambda code: True, exclude=(), max_distance=4.0):
+    """The kernel-form code (the WINOGRAD table's value) measured for the nearest signature with the same key prefix ('' 3x3, 'x_' / 'y_' / 'x7_' / 'y7_'
+    1-D, 't_' Refine, 'u_' Upconv, 's2k<taps>_' stride-2 pairs) whose code is launchable for this layer (`valid`), or None: what a layer WITHOUT a table
+    entry runs instead of the old "direct kernel unless the workgroup count says otherwise" rule (VERDICT r5 #6).  Distance as in nearest_schedules."""
+    best = None
+    for (co, ci, px, b, key, code) in _wino_by_prefix().get(prefix, ()):
+        if key in exclude or not valid(code):
+            continue
+        dist = abs(math.log2(co / cout)) + abs(math.log2(ci / cin)) + abs(math.log2(px / pixels)) + 0.5 * abs(math.log2(b / batch))
+        if dist <= max_distance and (best is None or (dist, key) < best[:2]):
+            best = (dist, key, code)
+    return None if best is None else best[2]
+
+
 def choose_winograd(cout, src_channels, h, w, batch, f2=False):
     """0 = direct MFMA kernel, 1 / 2 = Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) with 32 / 64 output channels per workgroup,
     11 / 12 = the same with the input transform in registers (mr_wino_desc.variant = 1), 21 = variant 2 (11 whose 1..16 tail channels
@@ -260,6 +292,20 @@ def choose_winograd(cout, src_channels, h, w, batch, f2=False):
         if f2 and code // 10 in (3, 4, 5):      # F(4x4,3x3), either kernel -> the F(2x2,3x3) variant measured before it (else: transform in registers, 32 channels)
             code = WINOGRAD_F2.get(sig, 11)
         return code
+    def ok(code):
+        variant, mbw = code // 10, code % 10
+        if code == 0:
+            return True
+        if variant == 2:
+            return mbw == 1 and 0 < cout % 32 <= 16
+        if variant in (0, 1):
+            return mbw == 1 or cout > 32
+        return variant in (3, 4, 5)
+    code = nearest_form("", cout, sum(src_channels), h * w, batch, valid=ok)
+    if code is not None:
+        if f2 and code // 10 in (3, 4, 5):
+            code = 11
+        return code
     tiles = math.ceil(h / 8) * math.ceil(w / 32) * batch
     if tiles * math.ceil(cout / 32) < 256:
         return 0
@@ -274,7 +320,10 @@ def choose_winograd_t(cout, src_channels, h, w, batch):
     know stay on the direct kernel."""
     if w % 4:
         return 0
-    return WINOGRAD.get("t_" + winograd_signature(cout, src_channels, h, w, batch), 0)
+    key = "t_" + winograd_signature(cout, src_channels, h, w, batch)
+    if key in WINOGRAD:
+        return WINOGRAD[key]
+    return nearest_form("t_", cout, sum(src_channels), h * w, batch, valid=lambda c: c == 0 or (c % 10) * 32 <= max(32, cout)) or 0
 
 
 def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3, f2=False):
@@ -287,7 +336,12 @@ def choose_winograd_1d(axis, cout, src_channels, h, w, batch, taps=3, f2=False):
         return 0
     prefix = ("x", "y")[axis] + ("" if taps == 3 else str(taps)) + "_"
     key = prefix + winograd_signature(cout, src_channels, h, w, batch)
-    code = WINOGRAD.get(key, 0)
+    if key in WINOGRAD:
+        code = WINOGRAD[key]
+    else:                                    # no entry: the form of the nearest measured signature of the same axis / tap count
+        code = nearest_form(prefix, cout, sum(src_channels), h * w, batch, valid=lambda c: c == 0 or (c % 10) <= math.ceil(cout / 16)) or 0
+        if f2 and code >= 40:
+            return 0
     if f2 and code >= 40:                    # F(4,.) -> what was measured best among F(2,.) and the direct kernel before the larger forms
         code = WINOGRAD_F2.get(key, 0)
     return code
@@ -304,7 +358,11 @@ def choose_stride2(taps, cout, cin, out_h, out_w, batch):
     kernel), or 0 = both halves on the direct MFMA kernel.  Only what the measured table says (tools/bench_stride2.py --emit; keys `s2k<taps>_co<cout>_ci<cin>_o<out_h>x<out_w>_b<batch>`)."""
     if taps not in (5, 7) or out_w % 4:
         return 0
-    return WINOGRAD.get(stride2_signature(taps, cout, cin, out_h, out_w, batch), 0)
+    key = stride2_signature(taps, cout, cin, out_h, out_w, batch)
+    if key in WINOGRAD:
+        return WINOGRAD[key]
+    cb = math.ceil(cout / 16)
+    return nearest_form(f"s2k{taps}_", cout, cin, out_h * out_w, batch, valid=lambda c: c == 0 or (c // 10 <= cb and c % 10 <= cb)) or 0
 
 
 def stride2_unified_weights(w, n, axis):
@@ -376,6 +434,65 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                                 out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, kws=kws, nbuf=depth if nbuf else 0, wgs=wgs * sk, nchunks=nchunks,
                                                 eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
     return out
+
+
+_SIG_RE = re.compile(r"^co(\d+)_ci([\d+]+)_k(\d+)x(\d+)_s(\d+)x(\d+)_o(\d+)x(\d+)_b(\d+)_p(\d+)(u?)(_bf16x3|_bf16)?$")
+_parsed_tuned = [None, 0]
+
+
+def _tuned_by_class():
+    """TUNED parsed once: (kh, kw, sh, sw, phases, mixed, mode) -> [(cout, cin, nsrc, pixels, batch, key, schedule)]."""
+    if _parsed_tuned[0] is None or _parsed_tuned[1] != len(TUNED):
+        by = {}
+        for key, sched in TUNED.items():
+            m = _SIG_RE.match(key)
+            if not m:
+                continue
+            cis = [int(c) for c in m.group(2).split("+")]
+            cls = (int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(10)), m.group(11), m.group(12) or "")
+            by.setdefault(cls, []).append((int(m.group(1)), sum(cis), len(cis), int(m.group(7)) * int(m.group(8)), int(m.group(9)), key, tuple(sched)))
+        _parsed_tuned[0], _parsed_tuned[1] = by, len(TUNED)
+    return _parsed_tuned[0]
+
+
+def nearest_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, bf16=False, mixed_phases=False, exclude=(), limit=6, max_distance=4.0):
+    """Round 6 (the rule path was 29 % behind the tables on the one shape where both were measured): for a launch WITHOUT a table entry, the
+    schedules measured for the nearest signatures of the same filter / stride / phase class, nearest first.  Distance = sum of |log2| ratios of output
+    channels, input channels, output pixels and (half weight) batch, + 0.5 when the number of concatenated sources differs.  The caller validates each
+    (LDS budget, chunk counts, DMA constraints are checked by the library) and falls back to the model."""
+    cls = (kh, kw, sh, sw, phases, "u" if mixed_phases else "", ("", "_bf16", "_bf16x3")[int(bf16)])
+    cin, nsrc, pix = sum(src_channels), len(src_channels), out_h * out_w
+    scored = []
+    for (co, ci, ns, px, b, key, sched) in _tuned_by_class().get(cls, ()):
+        if key in exclude:
+            continue
+        dist = (abs(math.log2(co / cout)) + abs(math.log2(ci / cin)) + abs(math.log2(px / pix)) + 0.5 * abs(math.log2(b / batch)) + (0.5 if ns != nsrc else 0.0))
+        if dist <= max_distance:
+            scored.append((dist, key, sched))
+    scored.sort()
+    out, seen = [], set()
+    for dist, key, sched in scored:
+        if sched not in seen:
+            seen.add(sched)
+            out.append(sched)
+        if len(out) >= limit:
+            break
+    return out
+
+
+def schedule_candidates(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, bf16=False, mixed_phases=False):
+    """What Plan.conv tries, in order: the table entry of the signature alone when there is one; otherwise the nearest signatures' schedules, then the model."""
+    sig = schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16, mixed_phases)
+    if sig in TUNED:
+        return [TUNED[sig]]
+    cands = nearest_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16, mixed_phases)
+    try:
+        cands.append(tuple(choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, bf16, mixed_phases)))
+    except ValueError:
+        pass
+    if not cands:
+        raise ValueError("no launchable schedule")
+    return cands
 
 
 def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, bf16=False, mixed_phases=False):
@@ -658,12 +775,8 @@ class Plan:
         out_h, out_w = grid
         nph = 1 if phases is None else len(phases)
         bf16 = self.bf16 if (in_mode != IN_MAXPOOL2 and tf == TF_NONE) else 0   # the bf16 modes need the LDS-DMA staging
-        sched = self.schedule_override.get(name) or choose_schedule(cout, src_channels, kh, kw, stride[0], stride[1],
-                                                                    out_h, out_w, n, nph, bf16, mixed)
-        mb, nb, split_k, ck = sched[:4]
-        waves = sched[4] if len(sched) > 4 else 4
-        kws = int(sched[5]) if len(sched) > 5 else 0       # K split across the waves of a workgroup
-        nbuf = int(sched[6]) if len(sched) > 6 else 0      # LDS ring depth (0: the two-buffer pipeline)
+        cands = ([self.schedule_override[name]] if self.schedule_override.get(name) else
+                 schedule_candidates(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16, mixed))
         d = ConvDesc()
         for i, s in enumerate(srcs):
             d.src[i] = s.data_ptr()
@@ -679,13 +792,9 @@ class Plan:
         d.out_channels, d.dst_total_channels, d.dst_channel_offset = cout, out.shape[1], out_ch_offset
         d.dst_plane_h, d.dst_plane_w = out.shape[2], out.shape[3]
         d.out_step_h, d.out_step_w, d.out_off_h, d.out_off_w = out_step[0], out_step[1], out_off[0], out_off[1]
-        if phases is None:
-            d.packed_weights = self._dev(pack_conv_weight(weight, src_channels, mb, ck, bf16)).data_ptr()
-            d.num_phases = 1
-        else:
-            d.num_phases = nph
+        d.num_phases = 1 if phases is None else nph
+        if phases is not None:
             for i, (wp, pt, pl, oh, ow) in enumerate(phases):
-                d.phase_weights[i] = self._dev(pack_conv_weight(wp, src_channels, mb, ck, bf16)).data_ptr()
                 d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh, ow
                 d.phase_kh[i], d.phase_kw[i] = wp.shape[2], wp.shape[3]
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
@@ -693,19 +802,35 @@ class Plan:
             assert residual.shape == out.shape
             d.residual = residual.data_ptr()
         d.activation, d.act_p0, d.act_p1 = act, p0, p1
-        d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
-        d.waves_per_wg = waves
-        d.k_split_waves = kws
-        d.pipeline_buffers = nbuf
         d.compute_dtype = int(bf16)
+        # the first candidate the library itself accepts (LDS budget, chunk counts, DMA constraints: mr_conv2d_lds_bytes validates the whole descriptor);
+        # a table entry or an override is the only candidate and must launch
+        lds, sched = -1, None
+        for sched in cands:
+            mb, nb, split_k, ck = sched[:4]
+            waves = sched[4] if len(sched) > 4 else 4
+            kws = int(sched[5]) if len(sched) > 5 else 0       # K split across the waves of a workgroup
+            nbuf = int(sched[6]) if len(sched) > 6 else 0      # LDS ring depth (0: the two-buffer pipeline)
+            d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
+            d.waves_per_wg, d.k_split_waves, d.pipeline_buffers = waves, kws, nbuf
+            d.workspace = 1 if split_k > 1 else None           # placeholder (non-null) until the shared workspace exists
+            d.packed_weights = 1                               # (placeholders: only the geometry is validated here)
+            for i in range(nph if phases is not None else 0):
+                d.phase_weights[i] = 1
+            lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
+            if lds >= 0:
+                break
+        if lds < 0:
+            _lib.check(int(lds), f"plan {name} sched={sched}")
+        if phases is None:
+            d.packed_weights = self._dev(pack_conv_weight(weight, src_channels, mb, ck, bf16)).data_ptr()
+        else:
+            for i, (wp, pt, pl, oh, ow) in enumerate(phases):
+                d.phase_weights[i] = self._dev(pack_conv_weight(wp, src_channels, mb, ck, bf16)).data_ptr()
         if split_k > 1:
             self._ws_floats[stage] = max(self._ws_floats.get(stage, 0),
                                          split_k * nph * n * ((cout + 15) // 16 * 16) * out_h * out_w)
             self._pending_ws.append((stage, d))
-            d.workspace = 1  # placeholder (non-null) until the shared workspace exists
-        lds = self.lib.mr_conv2d_lds_bytes(ctypes.byref(d))
-        if lds < 0:
-            _lib.check(int(lds), f"plan {name} sched={sched}")
         taps = kh * kw if phases is None else sum(p[0].shape[2] * p[0].shape[3] for p in phases)
         macs = n * out_h * out_w * cout * cin * taps
         geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves, kws)
@@ -1012,7 +1137,9 @@ class Plan:
         h, w = srcs[0].shape[2], srcs[0].shape[3]
         cout, cin = self.sd[wkey].shape[:2]
         if self.winograd and self.bf16 == 0 and name not in self.schedule_override and w % 4 == 0 and tuple(out.shape[2:]) == (2 * h, 2 * w):
-            mbw = WINOGRAD.get("u_" + winograd_signature(int(cout), [int(s_.shape[1]) for s_ in srcs], h, w, int(srcs[0].shape[0])), 0)
+            ukey = "u_" + winograd_signature(int(cout), [int(s_.shape[1]) for s_ in srcs], h, w, int(srcs[0].shape[0]))
+            mbw = WINOGRAD[ukey] if ukey in WINOGRAD else (nearest_form("u_", int(cout), int(cin), h * w, int(srcs[0].shape[0]),
+                                                                        valid=lambda c: c <= math.ceil(int(cout) / 16)) or 0)
             if mbw:        # measured table (tools/bench_wino1d.py --emit): the 4-multiply kernel, 16 * mbw output channels per workgroup
                 return self._upconv_winograd(stage, name, srcs, self.sd[wkey], self.sd[bkey] if bkey else None, out, mbw)
         phases = [(wp, 0, 0, py, px) for (py, px), wp in upconv_phase_weights(self.sd[wkey]).items()]

@@ -877,16 +877,49 @@ def test_winograd_choice_table_and_rule():
     assert all(v in (0, 21, 22, 23, 24, 41, 42, 43) for k, v in engine.WINOGRAD.items() if k[:3] in ("x7_", "y7_"))
     assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1) in (3, 41, 42, 43) and engine.choose_winograd_1d(1, 256, [256], 16, 32, 1) == 0 and engine.choose_winograd_1d(0, 48, [48], 256, 510, 1) == 0
     assert engine.choose_winograd_1d(0, 48, [48], 256, 512, 1, 7) == 43 and engine.choose_winograd_1d(1, 48, [32, 3], 256, 512, 1, 7) == 43      # depth.enc0.0 @ c2: F(4,7)
-    assert engine.choose_winograd_1d(0, 48, [48], 128, 256, 1, 7) == 0                                                                            # unknown 7-tap shape: direct
+    assert engine.choose_winograd_1d(0, 48, [48], 128, 256, 1, 7) == 43                                                                           # unknown 7-tap shape: the nearest measured one's form (round 6)
     assert engine.choose_winograd_t(48, [64, 64, 64], 128, 256, 1) % 10 in (1, 2) and engine.choose_winograd_t(256, [256], 16, 32, 1) == 0   # Refine: depth.dec3 / dec0 @ c2
-    assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 0 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0             # unknown shape / width % 4: direct
+    assert engine.choose_winograd_t(48, [64, 64, 64], 100, 256, 1) == 21 and engine.choose_winograd_t(48, [64], 128, 254, 1) == 0            # unknown shape: nearest signature's form / width % 4: direct
     assert engine.choose_winograd(32, [32], 256, 512, 2) == 31 and engine.choose_winograd(48, [32, 64], 256, 512, 1) == 31  # mask.enc0.*, mask.dec3.1 @ c2: F(4x4,3x3)
     assert engine.choose_winograd(64, [64], 64, 128, 1) == 0 and engine.choose_winograd(512, [512], 8, 16, 1) == 0          # ResNet l1 / l4 @ c2
     assert engine.choose_winograd(64, [64], 256, 512, 32) == 31                                                              # mask.enc0.* @ c3: F(4x4,3x3) (r04_s18)
-    assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # unknown, 24 tiles: direct
-    assert engine.choose_winograd(32, [32], 256, 768, 3) == 11         # unknown, 2304 workgroups, 32 couts: transform in registers
-    assert engine.choose_winograd(96, [96], 256, 768, 3) == 2
+    # shapes without an entry take the form measured for the NEAREST signature (round 6); only when nothing is within reach the old
+    # workgroup-count rule decides
+    assert engine.choose_winograd(32, [32], 64, 96, 1) == 0            # nearest: a small 32-channel layer that stayed on the direct kernel
+    assert engine.choose_winograd(32, [32], 256, 768, 3) == 41 and engine.choose_winograd(96, [96], 256, 768, 3) == 31      # nearest: full-resolution layers on F(4x4,3x3)
+    assert engine.choose_winograd(7, [5], 4000, 4000, 64) == 11        # nothing within reach: 2 M workgroups, <= 32 couts -> transform in registers
     assert engine.choose_winograd(32, [32], 256, 510, 4) == 0          # width % 4
+
+
+def test_rule_path_agrees_with_the_tables_it_is_derived_from():
+    """Leave-one-out replay of every table key through the nearest-signature rules: with a key hidden, the rule must still send the layer
+    to the same kernel FAMILY (direct vs reduced-multiply form) for most keys and pick the same register tile / wave count for a third of the direct
+    kernel's schedules (the tables hold many near-ties, so exact agreement is not the measure - tools/sessions/r06_* measure the time)."""
+    import collections
+    same, fam, tot = collections.Counter(), collections.Counter(), collections.Counter()
+    for key, code in engine.WINOGRAD.items():
+        m = engine._WSIG_RE.match(key)
+        assert m, key
+        pre, cis = m.group(1) or "", [int(c) for c in m.group(3).split("+")]
+        pred = engine.nearest_form(pre, int(m.group(2)), sum(cis), int(m.group(4)) * int(m.group(5)), int(m.group(6)), exclude=(key,))
+        tot[pre] += 1
+        same[pre] += pred == code
+        fam[pre] += pred is not None and (pred == 0) == (code == 0)
+    assert sum(tot.values()) == len(engine.WINOGRAD)
+    assert same[""] >= 0.55 * tot[""] and fam[""] >= 0.8 * tot[""], (same[""], fam[""], tot[""])
+    assert sum(fam.values()) >= 0.8 * sum(tot.values()), (fam, tot)
+    pad = lambda t: (tuple(t) + (4, 0, 0))[:7] if len(t) < 5 else (tuple(t) + (0, 0))[:7]
+    n = tile = 0
+    for key, sched in engine.TUNED.items():
+        m = engine._SIG_RE.match(key)
+        assert m, key
+        cis = [int(c) for c in m.group(2).split("+")]
+        mode = {"": 0, "_bf16": 1, "_bf16x3": 2}[m.group(12) or ""]
+        c = engine.nearest_schedules(int(m.group(1)), cis, int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(7)), int(m.group(8)),
+                                     int(m.group(9)), int(m.group(10)), mode, m.group(11) == "u", exclude=(key,), limit=1)
+        n += 1
+        tile += bool(c) and pad(c[0])[:2] == pad(sched)[:2] and pad(c[0])[4] == pad(sched)[4]
+    assert n == len(engine.TUNED) and tile >= 0.3 * n, (tile, n)
 
 
 def test_f2_table_documents_its_coverage():
@@ -1081,6 +1114,7 @@ def test_stride2_layers_as_stride1_forms_over_even_odd_views(hip_lib, monkeypatc
     assert [c["name"] for c in s2] == [f"depth.enc{i}.0.conv_{a}" for i in (1, 2, 3, 4) for a in "yx"] and not any(c.get("winograd") for c in s2)
     monkeypatch.setitem(engine.WINOGRAD, engine.stride2_signature(7, 64, 48, 128, 256, 1), 24)       # depth.enc1.0
     monkeypatch.setitem(engine.WINOGRAD, engine.stride2_signature(5, 128, 64, 64, 128, 1), 41)       # depth.enc2.0
+    monkeypatch.setitem(engine.WINOGRAD, engine.stride2_signature(5, 192, 128, 32, 64, 1), 0)        # depth.enc3.0: measured, stays direct (no entry = the nearest entry's form)
     plan = engine.Plan(sd, 1, 256, 512, 2, 32, (0.33, 0.0025), "cpu")
     routed = {c["name"]: c for c in plan.conv_log if c.get("stride2")}
     assert set(routed) == {"depth.enc1.0.conv_y", "depth.enc1.0.conv_x", "depth.enc2.0.conv_y", "depth.enc2.0.conv_x"}

@@ -548,6 +548,26 @@ def test_batch_independence(hip_lib):
             assert (alone[0] - full[i]).abs().max().item() < 1e-6
 
 
+def test_skip_dead_layer4_leaves_every_other_output_bit_identical(hip_lib):
+    """MonoRecModel(hip_skip_dead_layer4=True): ResNet layer4 (monorec_model.py:118-129) feeds only image_features[4], which neither
+    MaskModule (:372-380) nor DepthModule (:545) reads - not launching it must not move a bit of anything else; forward() and submit() both."""
+    full, _ = _model(8, graph=False)
+    lean, _ = _model(8, graph=False, hip_skip_dead_layer4=True)
+    batch = synth.make_batch(2, 64, 96, 2, seed=33)
+    with torch.no_grad():
+        a = full(_to_dev(batch))
+        b = lean(_to_dev(batch))
+        c = lean.submit(_to_dev(batch)).result()
+    torch.cuda.synchronize()
+    assert len(a["image_features"]) == 5 and len(b["image_features"]) == 4 and len(c["image_features"]) == 4
+    for out in (b, c):
+        for k in ("result", "cv_mask", "cost_volume"):
+            assert torch.equal(out[k], a[k]), k
+        for i in range(4):
+            assert torch.equal(out["image_features"][i], a["image_features"][i]) and torch.equal(out["predicted_inverse_depths"][i], a["predicted_inverse_depths"][i])
+        assert all(torch.equal(x, y) for x, y in zip(out["single_frame_cvs"], a["single_frame_cvs"]))
+
+
 def test_two_keyframes_in_flight_equal_sequential_forwards(hip_lib):
     """MonoRecModel.submit keeps 2 keyframes on the GPU at once (separate streams + resident buffers); every
     result must equal the strictly sequential forward of the same keyframe, in eager and in hipGraph mode."""

@@ -619,14 +619,15 @@ def main():
     primed = False
     if not args.primer and not args.no_primer and world == 1:
         primed = prime_device(args, dev_index)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
     # host placement of a rank (multi-rank jobs only): CPUs of its GPU's NUMA node shared evenly among the ranks of that node, torch's
-    # intra-op pool, the PNG-decode pool and the host-wait spin budget sized to that share (monorec_amd.distributed.place_rank)
+    # intra-op pool, the PNG-decode pool and the host-wait spin budget sized to that share (monorec_amd.distributed.place_rank) - BEFORE the
+    # device context and the process group exist, so that the runtime's helper threads inherit the mask
     from monorec_amd import distributed as mr_dist
     import monorec_amd.model as mr_model
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     placement = mr_dist.place_rank(local_rank, local_world, [0] * local_world if one_device else None)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     decode_budget, spin_s = mr_dist.host_thread_budget(placement["cpus"])
     mr_model.HOST_SPIN_SECONDS = spin_s
     placement.update({"decode_threads_budget": decode_budget, "host_spin_ms": spin_s * 1e3})

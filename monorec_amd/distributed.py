@@ -15,23 +15,27 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, single_rank_group=False):
+def init_from_env(backend=None, single_rank_group=False, pin_cpus=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  A one-process job creates no
-    group unless `single_rank_group` asks for one (tests: a 1-rank "nccl" group runs the RCCL branch on a one-GPU box)."""
+    group unless `single_rank_group` asks for one (tests: a 1-rank "nccl" group runs the RCCL branch on a one-GPU box).
+    `pin_cpus` (default: on, off with MR_PIN_CPUS=0): pin this rank to its share of the node's CPUs - BEFORE the device context and the process
+    group exist, so that the helper threads HIP and RCCL spawn inherit the mask (pinning afterwards left them unpinned)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if (world == 1 and not single_rank_group) or dist.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+    if pin_cpus is None:
+        pin_cpus = os.environ.get("MR_PIN_CPUS", "1") != "0"
+    if world > 1 and pin_cpus:
+        place_rank()            # this rank's share of the node's CPUs (NUMA node of its GPU), ahead of every thread the runtime will start
     kwargs = {}
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         kwargs["device_id"] = torch.device("cuda", local)
     dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **kwargs)
-    if world > 1:
-        place_rank()            # this rank's share of the node's CPUs (NUMA node of its GPU)
 
 
 def _parse_cpulist(text):
@@ -103,22 +107,58 @@ def _gpu_numa_cpus(device_index):
     return cpus
 
 
+_placed = {}          # the first placement of this process: {"allowed": affinity before pinning, "info": summary}
+
+
 def place_rank(local_rank=None, local_world=None, devices=None):
-    """Pin this process to its share of the node's CPUs (see `rank_cpu_set`) and size torch's intra-op pool to it.  Called by bench.py and
-    `init_from_env` in multi-rank jobs; a one-rank job is left alone.  `devices[r]` = device index of local rank r (default r).  Returns a
-    summary dict for logs / the bench line."""
+    """Pin this process - EVERY thread it has now (walks /proc/self/task) and, by inheritance, every thread started later - to its share of
+    the node's CPUs (see `rank_cpu_set`) and size torch's intra-op pool to it.  Called by bench.py and `init_from_env` in multi-rank jobs,
+    ahead of device / process-group initialisation; a one-rank job is left alone.  Idempotent: a second call returns the first call's summary
+    instead of splitting the already narrowed mask again (place_rank() followed by init_from_env() ended up on 1 / n^2 of the CPUs).
+    `devices[r]` = device index of local rank r (default r).  LOCAL_WORLD_SIZE missing: min(WORLD_SIZE, visible devices) when a device runtime is
+    up, else WORLD_SIZE.  The NUMA split is used only when every local rank's GPU is visible to this process (per-rank HIP_VISIBLE_DEVICES
+    isolation hides the others: then every rank takes an even share of the allowed CPUs, which never overlap).  Returns a summary dict."""
+    if "info" in _placed:
+        return dict(_placed["info"], repeated=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else int(local_world)
+    if local_world is None:
+        if "LOCAL_WORLD_SIZE" in os.environ:
+            local_world = int(os.environ["LOCAL_WORLD_SIZE"])
+        else:
+            local_world = int(os.environ.get("WORLD_SIZE", "1"))
+            try:
+                ndev = torch.cuda.device_count()
+                if ndev > 0:
+                    local_world = min(local_world, ndev) if ndev > 1 else local_world
+            except Exception:
+                pass
+    local_world = int(local_world)
     info = {"local_rank": local_rank, "local_world_size": local_world, "pinned": False, "cpus": len(os.sched_getaffinity(0)), "numa": False}
     if local_world <= 1:
         return info
     try:
+        allowed = sorted(os.sched_getaffinity(0))
         # one rank per GPU: the GPU of local rank r is device r, unless `devices` says otherwise (tests: every rank on device 0)
-        gpu_numa = [_gpu_numa_cpus(r if devices is None else devices[r]) for r in range(local_world)]
-        share = rank_cpu_set(local_rank, local_world, gpu_numa=gpu_numa)
-        os.sched_setaffinity(0, share)
+        try:
+            ndev = torch.cuda.device_count()
+        except Exception:
+            ndev = 0
+        want = [r if devices is None else devices[r] for r in range(local_world)]
+        gpu_numa = [_gpu_numa_cpus(dv) for dv in want] if ndev > max(want) else [None] * local_world      # a rank that cannot see its peers' GPUs does not guess
+        share = rank_cpu_set(local_rank, local_world, allowed=allowed, gpu_numa=gpu_numa)
+        tids = [0]
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")] or [0]
+        except OSError:
+            pass
+        for tid in tids:                                # sched_setaffinity(0, ..) alone pins the calling thread only
+            try:
+                os.sched_setaffinity(tid, share)
+            except OSError:
+                pass
         torch.set_num_threads(max(1, min(torch.get_num_threads(), len(share))))
-        info.update({"pinned": True, "cpus": len(share), "cpu_range": [share[0], share[-1]], "numa": gpu_numa[local_rank] is not None})
+        info.update({"pinned": True, "cpus": len(share), "cpu_range": [share[0], share[-1]], "numa": gpu_numa[local_rank] is not None, "threads_pinned": len(tids)})
+        _placed["allowed"], _placed["info"] = allowed, dict(info)
     except Exception as e:          # affinity is a placement hint, never a reason to fail the job
         info["error"] = repr(e)
     return info

@@ -88,7 +88,15 @@ def _placement_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     before = sorted(os.sched_getaffinity(0))
-    mrd.init_from_env("gloo")
+    first = mrd.place_rank()                              # a caller that places itself first ...
+    mrd.init_from_env("gloo")                             # ... must not be split a second time (1 / n^2 of the CPUs)
+    again = mrd.place_rank()
+    assert again.get("repeated") and again["cpus"] == first["cpus"]
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(sorted(os.sched_getaffinity(0))))       # threads started later inherit the mask
+    t.start(); t.join()
+    assert seen[0] == sorted(os.sched_getaffinity(0))
     q.put((rank, before, sorted(os.sched_getaffinity(0)), torch.get_num_threads()))
     dist.barrier()
     dist.destroy_process_group()
@@ -231,3 +239,20 @@ def test_reduce_batch_metrics_skips_nan_batches():
 def test_evaluater_in_flight_is_clamped_to_the_models_slots():
     from monorec_amd import evaluate
     assert evaluate.Evaluater(_StubModel(), in_flight=8, sums_fn=_cpu_sums).in_flight == 2
+
+
+def test_decode_stress_reports_every_rank_of_a_shared_host():
+    """tools/decode_stress.py: N processes placed like the ranks of one node sweep the device loader's frame cache at the same time - one
+    decoded image per keyframe each (the cache), a decode time and a host-side keyframes/s per rank: the ceiling of `with_data_loading` at N ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "decode_stress.py"), "--ranks", "2", "--keyframes", "12"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-400:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["ranks"] == 2 and [r["rank"] for r in out["per_rank"]] == [0, 1]
+    for r in out["per_rank"]:
+        assert r["decoded_images_per_keyframe"] == 1.0 and r["decode_ms_per_keyframe"] > 0 and r["host_keyframes_per_s"] > 0
+        assert r["pinned"] == (len(os.sched_getaffinity(0)) >= 2) or not r["pinned"]
+    assert abs(out["aggregate_host_keyframes_per_s"] - sum(r["host_keyframes_per_s"] for r in out["per_rank"])) < 1e-6

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools.kernel_resources import compile_asm, kernels, body  # noqa: E402
 
-MFMA_SOURCES = ["conv_mfma.hip", "conv_wino.hip", "conv_wino44.hip", "conv_wino44s.hip", "conv1d_wino.hip", "convt_wino.hip", "conv_b8.hip"]
+MFMA_SOURCES = ["conv_mfma.hip", "conv_wino.hip", "conv_wino44.hip", "conv_wino44s.hip", "conv_wino44w.hip", "conv1d_wino.hip", "convt_wino.hip", "conv_b8.hip"]
 
 
 def classify(ins):

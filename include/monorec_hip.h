@@ -308,11 +308,6 @@ typedef struct mr_b8_conv_desc {
     const void* phase_weights[4];            /* from mr_b8_pack_weights with that phase's filter size (device copies) */
     int32_t phase_kh[4], phase_kw[4];        /* 0 = kh / kw */
     int32_t phase_pad_top[4], phase_pad_left[4], phase_out_off_h[4], phase_out_off_w[4];
-    /* (ABI 19) input stages in LDS: 0 / 1 / 2 = the two-stage pipeline of round 4; n <= MR_MAX_PIPELINE_BUFFERS = a ring of n stages - the first n
-     * (tile, chunk) inputs of a workgroup are requested back to back and a chunk is swept as soon as IT has landed (partial s_waitcnt vmcnt),
-     * n - 1 chunks staying in flight: what an HBM-bound layer needs to keep ~60 KB of loads per CU outstanding.  Launches with an fp32 NCHW source
-     * (staged through registers) always run two stages.  LDS = resident weights (when they fit) + n x 64 x tile plane (+ n x the chunk's weights). */
-    int32_t pipeline_stages;
 } mr_b8_conv_desc;
 size_t mr_b8_packed_weight_bytes(int32_t out_channels, const int32_t* src_channels, int32_t num_src, int32_t kh, int32_t kw, int32_t mb);
 /* weight: (out_channels, sum(src_channels), kh, kw) fp32 in host memory -> bf16 A-fragment stream in host memory `dst` */

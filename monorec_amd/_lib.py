@@ -85,8 +85,7 @@ class B8ConvDesc(ctypes.Structure):
                 ("num_phases", ctypes.c_int32),
                 ("phase_weights", ctypes.c_void_p * 4), ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
                 ("phase_pad_top", ctypes.c_int32 * 4), ("phase_pad_left", ctypes.c_int32 * 4),
-                ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4),
-                ("pipeline_stages", ctypes.c_int32)]
+                ("phase_out_off_h", ctypes.c_int32 * 4), ("phase_out_off_w", ctypes.c_int32 * 4)]
 
 
 MR_MAX_COPY_SEGMENTS = 24

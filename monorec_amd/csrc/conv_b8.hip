@@ -64,7 +64,6 @@ struct B8Args {
     const void* w[4];
     long long wgroup_bytes[4];       // packed bytes per cout group
     int KHp[4], KWp[4], PT[4], PL[4], ooff_h[4], ooff_w[4];
-    int nstage;                      // input stages in LDS (ring depth): 2 .. MR_MAX_PIPELINE_BUFFERS; > 2 only without fp32 sources
     int dbg;                         // diagnostic library only (MR_B8_DBG): 1 skip the sweep, 2 skip the input staging, 4 skip the weight DMA, 8 skip the stores
 };
 
@@ -91,20 +90,6 @@ __device__ __forceinline__ void dma_global_x4(unsigned lds_byte_addr, const void
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(g) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// s_waitcnt vmcnt(N) takes an immediate: wait until at most `n` (wave-uniform, run time) of this wave's VMEM instructions are outstanding.
-// Rounding n DOWN is always safe (it waits for more); loads return in order, so "at most n outstanding" = everything but the n youngest has landed.
-#define MR_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-__device__ __forceinline__ void dma_wait_upto(int n) {
-    switch (n < 32 ? n : (n < 48 ? 32 : 48)) {
-        MR_VMCNT_CASE(0) MR_VMCNT_CASE(1) MR_VMCNT_CASE(2) MR_VMCNT_CASE(3) MR_VMCNT_CASE(4) MR_VMCNT_CASE(5) MR_VMCNT_CASE(6) MR_VMCNT_CASE(7)
-        MR_VMCNT_CASE(8) MR_VMCNT_CASE(9) MR_VMCNT_CASE(10) MR_VMCNT_CASE(11) MR_VMCNT_CASE(12) MR_VMCNT_CASE(13) MR_VMCNT_CASE(14) MR_VMCNT_CASE(15)
-        MR_VMCNT_CASE(16) MR_VMCNT_CASE(17) MR_VMCNT_CASE(18) MR_VMCNT_CASE(19) MR_VMCNT_CASE(20) MR_VMCNT_CASE(21) MR_VMCNT_CASE(22) MR_VMCNT_CASE(23)
-        MR_VMCNT_CASE(24) MR_VMCNT_CASE(25) MR_VMCNT_CASE(26) MR_VMCNT_CASE(27) MR_VMCNT_CASE(28) MR_VMCNT_CASE(29) MR_VMCNT_CASE(30) MR_VMCNT_CASE(31)
-        MR_VMCNT_CASE(32) MR_VMCNT_CASE(48)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 __device__ __forceinline__ i32x4 make_srd(const void* base, int bytes) {
     const unsigned long long p = (unsigned long long)base;
     i32x4 r;
@@ -198,15 +183,14 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         s = (a.nsrc > 2 && q >= a.src_q0[2]) ? 2 : ((a.nsrc > 1 && q >= a.src_q0[1]) ? 1 : 0);
         blk0 = (q - pick3(a.src_q0, s)) * 4;
     };
-    auto issue = [&](int q, int pb) -> int {          // returns the LDS-DMA instructions THIS wave certainly issued (the ring's partial vmcnt waits count on it)
+    auto issue = [&](int q, int pb) {
         const unsigned buf = lds_base + wres_bytes + pb * stage_bytes;
-        int issued = 0;
         if (!WRES && !B8_DBG(4)) {
             const unsigned wbuf = buf + 64 * PLANE;
             const unsigned char* wsrc = wgrp + (long long)q * wchunk_bytes;
-            for (int kb = wave; kb < T * MB; kb += WV) { dma_global_x4(wbuf + kb * 1024, wsrc + kb * 1024 + lane * 16); ++issued; }
+            for (int kb = wave; kb < T * MB; kb += WV) dma_global_x4(wbuf + kb * 1024, wsrc + kb * 1024 + lane * 16);
         }
-        if (B8_DBG(2)) return issued;
+        if (B8_DBG(2)) return;
         int s, blk0;
         source_of(q, s, blk0);
         const void* sp = pick3(a.src, s);
@@ -224,7 +208,6 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
                     const int so = ((b * scb + (bok ? blk0 + k : 0)) * HsWs) * 16;
                     dma_buffer_x4(lrow + k * PLANE * 16, (bok && gpix[j] >= 0) ? gpix[j] * 16 : -1, srd, so);
                 }
-                if (64 * wave + 64 * WV * j < PLANE) issued += 4;         // lane 0 of the wave is inside the tile: the four instructions issue
             }
         } else if (F32SRC) {
             const int sc = pick3(a.src_c, s);
@@ -243,7 +226,6 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
                     }
             }
         }
-        return issued;
     };
     auto stage_store = [&](int q, int pb) {
         if (!F32SRC || B8_DBG(2)) return;
@@ -412,36 +394,16 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
         }
     };
 
-    // ---- input pipeline.  fp32 sources (F32SRC): the two-stage pipeline of round 4 - a chunk's planes are loaded into registers ahead of the sweep
-    // and converted / written to the other stage behind it.  B8 sources only: a RING of a.nstage stages (round 6) - the first nstage chunks of the
-    // workgroup's (tile, chunk) sequence go out back to back, chunk n is swept after a PARTIAL vmcnt wait (everything this wave issued up to and
-    // including chunk n has landed, the younger chunks stay in flight) and one barrier, which also frees the stage of chunk n - 1 for chunk
-    // n + nstage - 1.  With two stages of 13-40 KB a CU had 26-80 KB of loads in flight: profiles/r06_c5bf16_b8_ablation.txt - mask.enc0.1
-    // 182 us = 105 (memory pipeline alone) and 132 (sweep alone) NOT overlapped; 8 TB/s x ~2 us of latency wants ~60 KB per CU in flight.
-    const int NS = F32SRC ? 2 : a.nstage;
-    const int total_chunks = (tile_end - tile_begin) * a.nchunks;
-    int ib = 0, sb = 0, nissued = 0;                   // stage of the next issue / sweep; chunks issued so far
-    unsigned long long fifo = 0;                       // DMA instructions of the chunks in flight, 8 bits each, oldest in the low byte
-    int depth = 0, dpend = 0;
-    auto issue_next = [&]() {
-        int cnt = issue(lq, ib);
-        cnt = cnt < 255 ? cnt : 255;                   // (an undercount only makes the wait stricter)
-        fifo |= (unsigned long long)cnt << (8 * depth);
-        ++depth;
-        dpend += cnt;
-        advance();
-        ib = ib + 1 == NS ? 0 : ib + 1;
-        ++nissued;
-    };
-    if (F32SRC) {
-        issue(0, 0);
-        stage_store(0, 0);
-        advance();
-    } else {
-        for (int j = 0; j < NS && j < total_chunks; ++j) issue_next();
-    }
+    // ---- input pipeline: two LDS stages - chunk q + 1 streams in (B8 sources: LDS-DMA; fp32 sources: plane loads into registers, converted and written
+    // behind the sweep) while chunk q is swept; one vmcnt(0) + barrier per chunk.  A RING of up to 8 stages with partial vmcnt waits (the conv_mfma.hip
+    // pipeline of this round) was built, was bit-identical, and is NOT kept: at two stages its bookkeeping cost 10-15 % per layer (SGPR spills, the load
+    // cursor's address arithmetic ahead of the sweep), and deeper rings won 1-5 % on 5 of 46 layer signatures (tools/sessions/r06_s6.sh, r06_s8.sh,
+    // r06_s18.sh; profiles/r06_c5bf16_b8_ablation.txt) - the kernel is not short of loads in flight, it is short of instruction issue (837 VALU + 734
+    // SALU instructions per 216 MFMAs of a wave and tile, profiles/r06_c5bf16_b8_counters.txt).
+    issue(0, 0);
+    stage_store(0, 0);
+    advance();
     int pb = 0;
-    bool first = true;
     int sty = tile_begin / a.tiles_x, stx = tile_begin - sty * a.tiles_x;      // the sweep cursor's tile
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         f32x4 acc[MB][NB];                                    // starts at the bias: one add per output value less in the epilogue (the sum then rounds as
@@ -450,39 +412,23 @@ __global__ __launch_bounds__(WV * 64) void conv_b8_kernel(const B8Args a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) acc[m][i] = (f32x4){bias[m][0], bias[m][1], bias[m][2], bias[m][3]};
         for (int q = 0; q < a.nchunks; ++q) {
-            if (F32SRC) {
-                const unsigned char* buf = lds + wres_bytes + pb * stage_bytes;
-                const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
-                dma_wait_all();
-                __syncthreads();                              // this chunk (and the resident weights) visible; everyone is done with the other buffer
-                const bool more = ltile < tile_end;           // wave-uniform
-                const int nq = lq;
-                // (the DMA instructions spread over the taps of the sweep instead of this burst - what gained 4 % on the F(4x4,3x3) kernel, whose MFMA
-                // phase runs from registers - was measured here too, tools/sessions/r04_s36.sh: 181 -> 191 us on mask.enc0.1, configs[4] 324-333 ->
-                // 311-315 keyframes/s: this sweep reads its operands from LDS and a wave held by a DMA instruction stops feeding them)
-                if (more) issue(nq, pb ^ 1);
-                if (q == 0) flush();                          // the previous tile's results leave while this chunk is swept
-                sweep(acc, buf, wl);
-                if (more) {
-                    stage_store(nq, pb ^ 1);                  // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
-                    advance();
-                }
-                pb ^= 1;
-            } else {
-                const unsigned char* buf = lds + wres_bytes + sb * stage_bytes;
-                const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
-                const int cnt = (int)(fifo & 255);
-                fifo >>= 8;
-                --depth;
-                dpend -= cnt;
-                dma_wait_upto(dpend);                         // this wave's share of the chunk (and of the resident weights, which went out first) has landed
-                __syncthreads();                              // ... everyone's has, and everyone is done with the stage of the previous chunk
-                if (!first && nissued < total_chunks) issue_next();
-                first = false;
-                if (q == 0) flush();                          // the previous tile's results leave while this chunk is swept
-                sweep(acc, buf, wl);
-                sb = sb + 1 == NS ? 0 : sb + 1;
+            const unsigned char* buf = lds + wres_bytes + pb * stage_bytes;
+            const unsigned char* wl = (WRES ? lds + q * wchunk_bytes : buf + 64 * PLANE) + lane * 16;
+            dma_wait_all();
+            __syncthreads();                              // this chunk (and the resident weights) visible; everyone is done with the other buffer
+            const bool more = ltile < tile_end;           // wave-uniform
+            const int nq = lq;
+            // (the DMA instructions spread over the taps of the sweep instead of this burst - what gained 4 % on the F(4x4,3x3) kernel, whose MFMA
+            // phase runs from registers - was measured here too, tools/sessions/r04_s36.sh: 181 -> 191 us on mask.enc0.1, configs[4] 324-333 ->
+            // 311-315 keyframes/s: this sweep reads its operands from LDS and a wave held by a DMA instruction stops feeding them)
+            if (more) issue(nq, pb ^ 1);
+            if (q == 0) flush();                          // the previous tile's results leave while this chunk is swept
+            sweep(acc, buf, wl);
+            if (more) {
+                stage_store(nq, pb ^ 1);                  // (fp32 sources) the other buffer is free: everyone passed this chunk's barrier
+                advance();
             }
+            pb ^= 1;
         }
 
         // ---- epilogue of the tile: D fragment lane l holds pixel (l & 15), couts (l >> 4) * 4 + r ------------------------------------------
@@ -705,19 +651,13 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
     if (ntiles >= (1ll << 31) || ngroups >= 65536 || (long long)d->batch * nphase >= 65536) return MR_ERR_UNSUPPORTED;
     k.ntiles = (int)ntiles;
     // resident weights where the whole stream of a cout group fits next to the two input stages (every layer with few input channels)
-    bool any_f32 = false;
-    for (int s = 0; s < d->num_src; ++s) any_f32 = any_f32 || d->src_layout[s] == MR_LAYOUT_F32_NCHW;
-    if (d->pipeline_stages < 0 || d->pipeline_stages > MR_MAX_PIPELINE_BUFFERS) return MR_ERR_BAD_ARGUMENT;
-    const int ns = (any_f32 || d->pipeline_stages < 2) ? 2 : d->pipeline_stages;      // register-staged fp32 sources: the two-stage pipeline only
-    k.nstage = ns;
     const size_t wall = (size_t)nchunks * k.KH * k.KW * mb * 1024;
-    const size_t tile2 = (size_t)ns * 64 * k.PLANE;
+    const size_t tile2 = 2 * (size_t)64 * k.PLANE;
     out->wres = wall + tile2 <= 160 * 1024 && wall <= 112 * 1024;
     if (out->wres) {
         out->lds_bytes = wall + tile2;
         const long long jobs = ntiles * ngroups * d->batch * nphase;
         long long wgs_target = 1024;                          // ~4 workgroups per CU over the launch, each keeps its weights for tpw tiles
-        if (ns > 2) wgs_target = 512 * (long long)((160 * 1024) / out->lds_bytes > 0 ? (160 * 1024) / out->lds_bytes : 1);   // deep ring: two rounds of what fits on a CU
 #ifdef MR_B8_ABLATE
         { const char* e = getenv("MR_B8_WGS"); if (e && atoi(e) > 0) wgs_target = atoi(e); }
 #endif
@@ -726,7 +666,7 @@ int derive8(const mr_b8_conv_desc* d, B8Derived* out) {
         if (tpw > 64) tpw = 64;
         k.tiles_per_wg = (int)tpw;
     } else {
-        out->lds_bytes = ns * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);
+        out->lds_bytes = 2 * ((size_t)64 * k.PLANE + (size_t)1024 * k.KH * k.KW * mb);
         k.tiles_per_wg = 1;
     }
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;

@@ -1253,7 +1253,6 @@ class Plan:
         sched8 = tuple(self.schedule_override.get(name) or B8_SCHEDULES.get(sig + f"_f{int(f32_source)}") or
                        self.b8_schedule(cout, out_h, out_w, kh, kw, stride[0], stride[1], n, len(plist), f32_source=f32_source))
         mb, nb, waves = sched8[:3]
-        nstage = int(sched8[3]) if len(sched8) > 3 else 0      # LDS ring depth of the input pipeline (0: two stages)
         d = B8ConvDesc()
         sc = (ctypes.c_int32 * len(srcs))(*src_channels)
         for i, s_ in enumerate(srcs):
@@ -1268,7 +1267,6 @@ class Plan:
         d.bias = self._dev(bias).data_ptr() if bias is not None else None
         d.activation, d.act_p0 = act, p0
         d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.waves_per_wg = mb, nb, waves
-        d.pipeline_stages = nstage
         d.num_phases = len(plist)
         for i, (wp, pt, pl, oh_, ow_) in enumerate(plist):
             wc = wp.detach().to(torch.float32).contiguous().cpu()
@@ -1284,12 +1282,12 @@ class Plan:
             d.phase_pad_top[i], d.phase_pad_left[i], d.phase_out_off_h[i], d.phase_out_off_w[i] = pt, pl, oh_, ow_
         lds = lib.mr_conv2d_b8_lds_bytes(ctypes.byref(d))
         if lds < 0:
-            _lib.check(int(lds), f"plan {name} b8 sched={(mb, nb, waves, nstage)}")
+            _lib.check(int(lds), f"plan {name} b8 sched={(mb, nb, waves)}")
         taps = sum(int(p[0].shape[2]) * int(p[0].shape[3]) for p in plist)
         macs = n * out_h * out_w * cout * cin * taps
         th = waves * nb // 2
         wgs = math.ceil(out_h / th) * math.ceil(out_w / 32) * math.ceil(((cout + 15) // 16) / mb) * n * len(plist)
-        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=1, ck=32, waves=waves, kws=0, nbuf=nstage,
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=1, ck=32, waves=waves, kws=0,
                                   wgs=wgs, lds=int(lds), cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=len(plist), bf16=1, b8=True,
                                   sig=sig, f32_source=f32_source,
                                   spec=dict(src_shapes=[(i[1], i[2], i[3], i[4]) for i in infos], src_layouts=[i[0] for i in infos], w_shape=(cout, cin, kh, kw),

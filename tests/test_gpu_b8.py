@@ -121,47 +121,6 @@ def test_conv_b8_matches_torch_on_bf16_rounded_operands(hip_lib, case):
     assert log["b8"] and log["macs"] == batch * oh * ow * cout * cin * kh * kw and 0 < log["lds"] <= 160 * 1024
 
 
-B8_RING_CASES = [
-    # (source channels, cout, (H, W), batch, (kh, kw), stride, out layout, (mb, nb, waves))
-    ((48,), 48, (40, 96), 2, (3, 3), (1, 1), 1, (3, 2, 4)),          # mask.enc0.1: resident weights, many tiles per workgroup
-    ((48,), 48, (40, 96), 1, (3, 3), (1, 1), 1, (3, 4, 8)),          # the large tile
-    ((96, 64, 96), 96, (24, 64), 1, (3, 3), (1, 1), 1, (2, 2, 8)),   # 9 chunks over three sources, weights streamed with the chunks
-    ((256,), 256, (8, 32), 1, (3, 1), (1, 1), 1, (4, 1, 4)),         # 8 chunks, one tile per workgroup
-    ((64,), 128, (32, 64), 2, (5, 1), (2, 1), 1, (4, 2, 8)),         # stride 2
-    ((32,), 24, (20, 40), 1, (3, 3), (1, 1), 0, (2, 1, 8)),          # fp32 destination, ragged tiles
-    ((5, 11), 40, (13, 20), 3, (3, 3), (1, 1), 1, (3, 1, 4)),        # ragged everything
-]
-
-
-@pytest.mark.parametrize("stages", [3, 4, 8])
-@pytest.mark.parametrize("case", range(len(B8_RING_CASES)))
-def test_conv_b8_input_ring_depth_does_not_change_a_bit(hip_lib, case, stages):
-    """mr_b8_conv_desc.pipeline_stages (ABI 19): B8 inputs stream through a ring of LDS stages with partial vmcnt waits; the K order is unchanged, so
-    every depth must reproduce the two-stage launch bit for bit (repeated: a race between a DMA and a sweep would not show on every run)."""
-    srcs_c, cout, (h, w), batch, (kh, kw), (sh, sw), olay, sched = B8_RING_CASES[case]
-    g = torch.Generator().manual_seed(500 + case)
-    srcs = [torch.randn(batch, c, h, w, generator=g) for c in srcs_c]
-    cin = sum(srcs_c)
-    wt = torch.randn(cout, cin, kh, kw, generator=g) * (1.0 / math.sqrt(kh * kw * cin))
-    bias = torch.randn(cout, generator=g) * 0.1
-    pt, _ = engine.same_pad(h, kh, sh)
-    pl, _ = engine.same_pad(w, kw, sw)
-    oh, ow = math.ceil(h / sh), math.ceil(w / sw)
-    outs = []
-    for ns in (0, stages):
-        for _ in range(3):
-            plan = engine.Plan.bare(DEV, schedule_override={"t": tuple(sched) + (ns,)}, bf16=1)
-            try:
-                got, _ = _run_b8(plan, srcs, [1] * len(srcs), wt, bias, cout, (oh, ow), olay, stride=(sh, sw), pad=(pt, pl), grid=(oh, ow), act=ACT_LEAKY_RELU, p0=0.1)
-            except RuntimeError as e:
-                if ns and "code -3" in str(e):
-                    pytest.skip(f"{ns} stages of this schedule exceed the 160 KB of LDS")
-                raise
-            outs.append(got.clone())
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0]), float((o - outs[0]).abs().max())
-
-
 @pytest.mark.parametrize("layer", ["refine", "upconv"])
 @pytest.mark.parametrize("olay", [0, 1])
 def test_b8_transposed_and_upsampling_layers(hip_lib, layer, olay):

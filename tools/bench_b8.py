@@ -44,7 +44,7 @@ def main():
     wt = torch.randn(cout, sum(srcs_c), kh, kw, generator=g) / math.sqrt(kh * kw * sum(srcs_c))
     bias = torch.zeros(cout)
     for sched in args.scheds:
-        plan = engine.Plan.bare(dev, schedule_override={"t": tuple(int(v) for v in sched.split(","))}, bf16=1)      # mb,nb,waves[,ring stages]
+        plan = engine.Plan.bare(dev, schedule_override={"t": tuple(int(v) for v in sched.split(","))}, bf16=1)      # mb,nb,waves
         srcs = []
         for c, lay in zip(srcs_c, lays):
             if lay:

@@ -40,7 +40,7 @@ def main():
     env = dict(os.environ, MR_TUNED_SCHEDULES=sched, MR_TUNED_WINOGRAD=wino, MR_TUNED_B8=b8)
     py = sys.executable
     if a.bf16:
-        steps = [("tune_b8", [py, "tools/tune_b8.py"] + shape + ["--stages", "0,3,4", "--emit", b8])]
+        steps = [("tune_b8", [py, "tools/tune_b8.py"] + shape + ["--emit", b8])]
     else:
         steps = [("tune_conv", [py, "tools/tune_conv.py"] + shape + ["--merge", "--ring", "3,4", "--out", sched] + ([] if a.all else ["--missing"])),
                  ("bench_wino", [py, "tools/bench_wino.py"] + shape + ["--emit", wino]),

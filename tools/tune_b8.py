@@ -90,8 +90,6 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--margin", type=float, default=0.97, help="a schedule must beat margin x the rule's time to enter the table")
     ap.add_argument("--emit", default=None)
-    ap.add_argument("--stages", default="0", help="comma-separated input-ring depths (mr_b8_conv_desc.pipeline_stages, ABI 19) to try per tile, e.g. 0,3,4,6 (0 = two stages); "
-                                                  "launches with an fp32 source always run two stages")
     a = ap.parse_args()
     for k in list(engine.B8_SCHEDULES):
         del engine.B8_SCHEDULES[k]                                   # the rule's choice is the reference point
@@ -111,25 +109,17 @@ def main():
         cb16 = (c["cout"] + 15) // 16
         mbs = sorted({rule[0]} | {m_ for m_ in (1, 2, 3, 4) if m_ <= cb16 and (cb16 % m_ == 0 or m_ == rule[0])}, reverse=True)
         row = {"name": c["name"], "sig": key, "rule": list(rule), "times_us": {}}
-        depths = [0] if c["f32_source"] else [int(x) for x in a.stages.split(",")]
         for mb in mbs:
             for waves, nb in TILES:
-                lds_seen = set()
-                for ns in depths:
-                    sched = (mb, nb, waves) + ((ns,) if ns else ())
-                    plan = build(c, sched, g)
-                    if plan is None:
-                        continue
-                    lds = plan.conv_log[0]["lds"]
-                    if ns and lds in lds_seen:                        # the ring was clamped to a depth already timed
-                        del plan
-                        continue
-                    lds_seen.add(lds)
-                    try:
-                        row["times_us"][",".join(str(x) for x in sched)] = round(timed(plan, a.reps), 1)
-                    except RuntimeError:                              # a combination the launcher has no instantiation for
-                        pass
-                    del plan
+                sched = (mb, nb, waves)
+                plan = build(c, sched, g)
+                if plan is None:
+                    continue
+                try:
+                    row["times_us"]["%d,%d,%d" % sched] = round(timed(plan, a.reps), 1)
+                except RuntimeError:                                  # a combination the launcher has no instantiation for
+                    pass
+                del plan
         t_rule = row["times_us"].get("%d,%d,%d" % rule)
         if t_rule is None:
             print(json.dumps(dict(row, error="the rule's schedule did not launch")), flush=True)

@@ -36,7 +36,6 @@ extern "C" {
 #define MR_ERR_LDS_BUDGET   (-3)
 
 #define MR_MAX_SOURCES 3
-#define MR_MAX_PIPELINE_BUFFERS 8   /* LDS ring depth of mr_conv2d_f32 (mr_conv_desc.pipeline_buffers) */
 #define MR_MAX_FRAMES  8
 #define MR_MAX_HEADS   4   /* one-channel 3x3 heads per mr_depth_heads_f32 launch (DepthModule has 4 predictors) */
 #define MR_MAX_VOTE_MASKS 8   /* masks voted over by mr_pointcloud_append_f32 (the reference buffers 5) */
@@ -139,14 +138,6 @@ typedef struct mr_conv_desc {
      * through LDS in a fixed order.  waves_per_wg times more workgroups for layers with few output pixels, without the workspace
      * round trip and the finishing launch of split_k (which must be 1 here; MR_COMPUTE_F32, LDS-DMA staged inputs only). */
     int32_t k_split_waves;
-    /* schedule, continued (ABI 19): depth of the LDS ring the K chunks of a workgroup stream through.  0 = two buffers (one when no workgroup sees a
-     * second chunk): the pipeline the round 1-5 tables were measured on.  n in 2..MR_MAX_PIPELINE_BUFFERS (1 is taken as 2) = min(n, chunks
-     * of a workgroup) buffers: the first n chunks are requested back to back at kernel start and chunk q is swept as soon as IT has landed (partial
-     * s_waitcnt vmcnt), chunk q + n - 1 streaming meanwhile - with n = chunks per workgroup and a small chunk_channels the sweep of a
-     * layer that fits the LDS whole starts after the first 16 channels instead of after all of them.  LDS = n x (chunk_channels x tile
-     * plane + the chunk's A fragments), see mr_conv2d_lds_bytes.  The summation order (and so every result bit) depends on
-     * chunk_channels only, not on n. */
-    int32_t pipeline_buffers;
 } mr_conv_desc;
 
 /* number of floats of the packed weight image for a conv with the given source split and schedule

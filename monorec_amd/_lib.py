@@ -54,7 +54,6 @@ class ConvDesc(ctypes.Structure):
         ("compute_dtype", ctypes.c_int32),
         ("phase_kh", ctypes.c_int32 * 4), ("phase_kw", ctypes.c_int32 * 4),
         ("k_split_waves", ctypes.c_int32),
-        ("pipeline_buffers", ctypes.c_int32),
     ]
 
 

@@ -72,7 +72,6 @@ struct ConvKArgs {
     int dbg;                   // ablation bits (env MR_CONV_DBG): 1 skip sweep, 2 skip input DMA, 4 skip weight DMA, 8 skip stores,
                                // 16 per-workgroup timestamps (tools/wg_timeline.py)
     int ksplit, nchunks, batch, nphase;
-    int nbuf;                  // LDS pipeline buffers (ring depth): 1 .. MR_MAX_PIPELINE_BUFFERS
     int kws;                   // 1: the waves of a workgroup split K (all work on the same NB pixel blocks, reduced through LDS)
     int bf16;                  // 1: bf16 MFMA mode (weights bf16, activations rounded to bf16 in the B fragment): half-size weight blocks
     int tiles_y, ngroups, ks_shift;   // ks_shift: log2(ksplit) or -1
@@ -232,26 +231,23 @@ __device__ __forceinline__ void cursor_advance(const ConvKArgs& a, ChunkCursor& 
 //   * input tile: DMA path (direct / upsample reads): buffer_load_dword ... lds, one 256 B row of the tile per
 //     wave instruction, hardware zero fill for out-of-range offsets; no VGPRs, nothing to wait for here;
 //     register path (2x2 max-pool or input normalisation): SRD loads -> VALU -> ds_write.
-// Returns how many LDS-DMA instructions THIS wave certainly issued (wave-uniform; the ring pipeline's partial vmcnt waits count on it:
-// an undercount only makes a wait stricter, never too lax).
 template <int MB, bool DMA_IN>
-__device__ __forceinline__ int issue_chunk(const ConvKArgs& a, const ChunkCursor& c, float* ldsI, float* ldsW,
-                                            unsigned ldsI_addr, unsigned ldsW_addr,
-                                            const float* wgrp, int b, int T, int lane, int wave, int nwave, int HsWs,
-                                            const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT],
-                                            const int (&voff4)[MR_MAX_G4]) {
+__device__ __forceinline__ void issue_chunk(const ConvKArgs& a, const ChunkCursor& c, float* ldsI, float* ldsW,
+                                             unsigned ldsI_addr, unsigned ldsW_addr,
+                                             const float* wgrp, int b, int T, int lane, int wave, int nwave, int HsWs,
+                                             const int (&goff)[MR_MAX_PPT], const int (&loff)[MR_MAX_PPT],
+                                             const int (&voff4)[MR_MAX_G4]) {
     const int ck = min(a.CK, a.src_cpad[c.s] - c.c0);
     const int wfloats = T * ck * MB * (a.bf16 ? 8 : 16);
     const float* wsrc = wgrp + c.woff;
-    int issued = 0;
     const int n1k = MR_DBG(4) ? 0 : wfloats >> 8;   // 1 KiB pieces (64 lanes x 16 B)
-    for (int kb = wave; kb < n1k; kb += nwave) { dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4); ++issued; }
+    for (int kb = wave; kb < n1k; kb += nwave) dma_global_x4(ldsW_addr + kb * 1024, wsrc + kb * 256 + lane * 4);
     const int nfrag = MR_DBG(4) ? 0 : wfloats >> 6; // tail: 256 B pieces (64 lanes x 4 B)
-    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += nwave) { dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane); ++issued; }
+    for (int fr = (n1k << 2) + wave; fr < nfrag; fr += nwave) dma_global_x1(ldsW_addr + fr * 256, wsrc + fr * 64 + lane);
 
     const int creal = a.src_c[c.s] - c.c0;                            // real (unpadded) channels left
     const int sbase_bytes = (b * a.src_c[c.s] + c.c0) * HsWs * 4;     // byte offset of channel c0 of sample b
-    if (MR_DBG(2)) return issued;
+    if (MR_DBG(2)) return;
     if (DMA_IN && a.dma_x4) {
         // one buffer_load_dwordx4 ... lds = 64 lanes x 16 B = up to 256 consecutive floats of one channel plane;
         // wave w streams channels w, w+4, ... of the chunk
@@ -265,7 +261,6 @@ __device__ __forceinline__ int issue_chunk(const ConvKArgs& a, const ChunkCursor
                 if (i < a.g4pt && voff4[i] != -2)                      // -2: lane beyond the tile rows (EXEC off)
                     dma_buffer_x4(lplane + i * 1024, cok ? voff4[i] : -1, srd, so);
             }
-            issued += a.g4pt;                                          // lane 0 of group i < g4pt is always inside the tile: the instruction issues
         }
     } else if (DMA_IN) {
         const i32x4 srd = make_srd(a.src[c.s], a.src_bytes[c.s]);
@@ -296,21 +291,6 @@ __device__ __forceinline__ int issue_chunk(const ConvKArgs& a, const ChunkCursor
                 }
             }
         }
-    }
-    return issued;        // (the dword-DMA instructions of the input tile are not counted: whole waves can fall outside the tile)
-}
-
-// s_waitcnt vmcnt(N) takes an immediate: wait until at most `n` (wave-uniform, run time) of this wave's VMEM instructions are outstanding.
-// Rounding n DOWN is always safe (it waits for more).  vmcnt is a 6-bit counter; the wave cannot have more than 63 outstanding.
-#define MR_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-__device__ __forceinline__ void dma_wait_upto(int n) {
-    switch (n < 32 ? n : (n < 48 ? 32 : 48)) {
-        MR_VMCNT_CASE(0) MR_VMCNT_CASE(1) MR_VMCNT_CASE(2) MR_VMCNT_CASE(3) MR_VMCNT_CASE(4) MR_VMCNT_CASE(5) MR_VMCNT_CASE(6) MR_VMCNT_CASE(7)
-        MR_VMCNT_CASE(8) MR_VMCNT_CASE(9) MR_VMCNT_CASE(10) MR_VMCNT_CASE(11) MR_VMCNT_CASE(12) MR_VMCNT_CASE(13) MR_VMCNT_CASE(14) MR_VMCNT_CASE(15)
-        MR_VMCNT_CASE(16) MR_VMCNT_CASE(17) MR_VMCNT_CASE(18) MR_VMCNT_CASE(19) MR_VMCNT_CASE(20) MR_VMCNT_CASE(21) MR_VMCNT_CASE(22) MR_VMCNT_CASE(23)
-        MR_VMCNT_CASE(24) MR_VMCNT_CASE(25) MR_VMCNT_CASE(26) MR_VMCNT_CASE(27) MR_VMCNT_CASE(28) MR_VMCNT_CASE(29) MR_VMCNT_CASE(30) MR_VMCNT_CASE(31)
-        MR_VMCNT_CASE(32) MR_VMCNT_CASE(48)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
@@ -750,52 +730,28 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
     const int T = KH * KW;
     const float* wgrp = a.w[ph] + (long long)grp * a.wgroup_stride[ph];
 
-    // ---- software pipeline over K chunks: a ring of a.nbuf LDS buffers (round 6) ------------------------------------------
-    // The first min(nbuf, chunks) chunks go out back to back before anything is waited for; chunk q is swept after a PARTIAL vmcnt wait
-    // (everything this wave issued up to and including chunk q has landed - the younger chunks stay in flight) and ONE barrier, which
-    // also says that every wave is done with the buffer of chunk q - 1: chunk q + nbuf - 1 streams into it while q is swept.  nbuf = 2
-    // is the two-buffer pipeline of rounds 1-5 with both buffers filled from the start; with nbuf = chunks the whole K range of the
-    // workgroup is requested at once and the sweep starts when the FIRST chunk is in, instead of after all of it (the single-chunk
-    // schedules the c2 table is full of: profiles/r05_c2_wg_timeline.json, first_chunk 2.6 us exposed ahead of a 7.1 us sweep).
+    // ---- software pipeline over K chunks: chunk q+1 streams into the other buffer while q is swept ----------
     ChunkCursor cur = {0, 0, 0};
     for (int q = 0; q < q_lo; ++q) cursor_advance<MB>(a, cur, T);
-    ChunkCursor icur = cur;                            // next chunk to issue (cur: next chunk to sweep)
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds;
-    const int nq = q_hi - q_lo;
-    const int nbuf = a.nbuf;
-    int ib = 0, sb = 0, nissued = 0;                   // buffer of the next issue / sweep; chunks issued so far
-    unsigned long long fifo = 0;                       // DMA instructions of the chunks in flight, 8 bits each, oldest in the low byte
-    int depth = 0, pend = 0;                           // entries in the fifo, their sum
-    auto issue_next = [&]() {
-        const unsigned addr = lds_base + ib * bufsz * 4;
-        float* bi = lds + ib * bufsz;
-        int cnt = issue_chunk<MB, DMA_IN>(a, icur, bi, bi + ioff, addr, addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
-        cnt = cnt < 255 ? cnt : 255;                   // (an undercount only makes the wait stricter)
-        fifo |= (unsigned long long)cnt << (8 * depth);
-        ++depth;
-        pend += cnt;
-        cursor_advance<MB>(a, icur, T);
-        ib = ib + 1 == nbuf ? 0 : ib + 1;
-        ++nissued;
-    };
     dbg_stamp(a, 11);                                  // setup done, first DMA goes out
-    for (int j = 0; j < nbuf && j < nq; ++j) issue_next();
-    const int stampq = nq > 1 ? 1 : 0;                 // the chunk whose phases are stamped (diagnostic library)
-    for (int q = 0; q < nq; ++q) {
-        const int cnt = (int)(fifo & 255);
-        fifo >>= 8;
-        --depth;
-        pend -= cnt;
-        dma_wait_upto(pend);                           // this wave's share of chunk q has landed
-        if (q == stampq + 1) dbg_stamp(a, 7);
-        __syncthreads();                               // ... everyone's has, and everyone is done with the buffer of chunk q - 1
-        if (q == 0) dbg_stamp(a, 1);
-        if (q == stampq + 1) { dbg_stamp(a, 8); dbg_stamp(a, 10); }
-        if (q == stampq) { dbg_stamp(a, 4); dbg_stamp(a, 9); }
-        if (q >= 1 && nissued < nq) issue_next();
-        if (q == stampq) dbg_stamp(a, 5);
+    issue_chunk<MB, DMA_IN>(a, cur, lds, lds + ioff, lds_base, lds_base + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
+    dma_wait_all();
+    __syncthreads();
+    dbg_stamp(a, 1);
+    int pb = 0;
+    for (int q = q_lo; q < q_hi; ++q) {
         const int ck4 = min(a.CK, a.src_cpad[cur.s] - cur.c0) >> 2;
-        const float* bcur = lds + sb * bufsz;
+        float* bcur = lds + pb * bufsz;
+        float* bnxt = lds + (pb ^ 1) * bufsz;
+        cursor_advance<MB>(a, cur, T);
+        const bool stamp = q == q_lo + 1 || (q == q_lo && q_hi == q_lo + 1);
+        if (stamp) { dbg_stamp(a, 4); dbg_stamp(a, 9); }
+        if (q + 1 < q_hi) {
+            const unsigned nb_addr = lds_base + (pb ^ 1) * bufsz * 4;
+            issue_chunk<MB, DMA_IN>(a, cur, bnxt, bnxt + ioff, nb_addr, nb_addr + ioff * 4, wgrp, b, T, lane, wave, WV, HsWs, goff, loff, voff4);
+        }
+        if (stamp) dbg_stamp(a, 5);
         if (!MR_DBG(1)) {
             if (KWS) sweep_chunk_kws<MB, NB, WV>(a, acc, acck, bcur, bcur + ioff, lbase, ck4, lane, wave, KH, KW);
             else if (BF16 == 2) sweep_chunk_bf16x3<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4 >> 2, lane, KH, KW);
@@ -803,15 +759,16 @@ __global__ __launch_bounds__(WV * 64) void conv_mfma_kernel(const ConvKArgs a) {
             else if ((ck4 & 3) == 0) sweep_chunk_pipe<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KH, KW);
             else sweep_chunk<MB, NB>(a, acc, bcur, bcur + ioff, lbase, ck4, lane, KH, KW);
         }
-        if (q == stampq) dbg_stamp(a, 6);
-        cursor_advance<MB>(a, cur, T);
-        sb = sb + 1 == nbuf ? 0 : sb + 1;
+        if (stamp) dbg_stamp(a, 6);
+        dma_wait_all();                                // this wave's share of the next chunk has landed
+        if (stamp) dbg_stamp(a, 7);
+        __syncthreads();                               // ... everyone's has, and everyone is done with this buffer
+        if (stamp) { dbg_stamp(a, 8); dbg_stamp(a, 10); }
+        pb ^= 1;
     }
-    if (stampq == nq - 1) { dbg_stamp(a, 7); dbg_stamp(a, 8); dbg_stamp(a, 10); }
     // ---- KWS: the WV partial accumulators of every (cout block, pixel block) meet in LDS (the pipeline buffers are free behind
     //      one more barrier); block j = m * NB + i is summed - in wave order, deterministic - and finished by wave j % WV
     if (KWS) {
-        __syncthreads();                               // (the ring loop ends behind a sweep, not behind a barrier)
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -1113,13 +1070,11 @@ int derive(const mr_conv_desc* d, Derived* out) {
         if (c > ck_max) ck_max = c;
     }
     k.wmax_floats = taps * ck_max * mb * (bf16 == 1 ? 8 : 16);
-    // ring of pipeline buffers: pipeline_buffers = 0 -> two, or one when no workgroup ever streams a second chunk (the schedules measured
-    // in rounds 1-5); n >= 1 -> min(n, chunks of a workgroup)
-    const int wg_chunks = mr_ceil_div(nchunks, d->split_k);
-    if (d->pipeline_buffers < 0 || d->pipeline_buffers > MR_MAX_PIPELINE_BUFFERS) return MR_ERR_BAD_ARGUMENT;
-    const int want = d->pipeline_buffers < 2 ? 2 : d->pipeline_buffers;      // (a second chunk needs a second buffer: 1 means 2)
-    const int nbuf = want < wg_chunks ? want : wg_chunks;
-    k.nbuf = nbuf;
+    // two pipeline buffers - one when no workgroup ever streams a second chunk.  (Round 6 measured a ring of up to 8 buffers with partial
+    // vmcnt waits here: filling more than one buffer ahead delays the FIRST chunk - the launch's fills compete for the same fabric - and the
+    // ring's bookkeeping costs the one-chunk layers 1 %: the two-buffer loop is 4 % faster over the direct launches of a c2 keyframe, also on
+    // the layers whose table entries had chosen 3 buffers; tools/sessions/r06_s4.sh, r06_s19.sh.)
+    const int nbuf = mr_ceil_div(nchunks, d->split_k) > 1 ? 2 : 1;
     out->lds_bytes = nbuf * ((size_t)k.CK * plane + (size_t)k.wmax_floats) * sizeof(float);
     if (kws && out->lds_bytes < (size_t)wv * mb * nb * 1024) out->lds_bytes = (size_t)wv * mb * nb * 1024;   // reduction scratch
     if (out->lds_bytes > 160 * 1024) return MR_ERR_LDS_BUDGET;

@@ -125,13 +125,13 @@ def conv_geometry(out_h, out_w, kh, kw, sh, sw, nb, waves=4, kws=0):
                 tile_eff=(out_h * out_w) / (tiles * th * twb * 16), ppt=math.ceil(ih * iw / 256))
 
 
-def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False, reduce_bytes=0, nbuf=0):
-    """Dynamic LDS of one workgroup: a ring of pipeline buffers of (input tile + A fragments of the largest chunk) - `nbuf` 0: two,
-    or one when no workgroup streams a second chunk; n: min(n, chunks of a workgroup) (mirrors derive() in csrc/conv_mfma.hip);
-    `reduce_bytes`: the scratch of the K-split-across-waves reduction (waves * mb * nb KiB), which reuses the same memory."""
+def lds_bytes(geo, taps, cpads, mb, ck, split_k=1, bf16=False, reduce_bytes=0):
+    """Dynamic LDS of one workgroup: pipeline buffers of (input tile + A fragments of the largest chunk) - two,
+    or one when no workgroup streams a second chunk (mirrors derive() in csrc/conv_mfma.hip); `reduce_bytes`: the scratch of the
+    K-split-across-waves reduction (waves * mb * nb KiB), which reuses the same memory."""
     ck_max = max(min(c, ck) for c in cpads)
     nchunks = sum(math.ceil(c / ck) for c in cpads)
-    nbuf = min(max(nbuf, 2), math.ceil(nchunks / split_k))
+    nbuf = 2 if math.ceil(nchunks / split_k) > 1 else 1
     return max(nbuf * 4 * (ck * geo["plane"] + taps * ck_max * mb * (8 if int(bf16) == 1 else 16)), reduce_bytes)    # bf16x3 blocks: hi + lo = fp32 size
 
 
@@ -177,7 +177,7 @@ def _warn_env_overrides():
                       "tables / defaults (tuning aid; unset them for the measured configuration)")
 
 
-TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves[, k_split_waves[, pipeline_buffers]]]); filled from tuned_schedules.json when present
+TUNED = {}          # signature -> (mb, nb, split_k, ck[, waves[, k_split_waves]]); filled from tuned_schedules.json when present
 
 
 def _load_tuned():
@@ -389,9 +389,8 @@ def schedule_signature(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, 
             + ("u" if mixed_phases else "") + ("", "_bf16", "_bf16x3")[int(bf16)])
 
 
-def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False, ring_depths=()):
-    """All launchable (mb, nb, split_k, ck, waves, kws, nbuf) for a conv, with the workgroup count of each.  `ring_depths`: LDS ring depths
-    (mr_conv_desc.pipeline_buffers) to list besides the two-buffer pipeline (nbuf 0)."""
+def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases=1, lds_cap=80 * 1024, bf16=False):
+    """All launchable (mb, nb, split_k, ck, waves, kws) for a conv, with the workgroup count of each."""
     cb = (cout + 15) // 16
     unit = 16 if bf16 else 4
     cpads = [(c + unit - 1) // unit * unit for c in src_channels]
@@ -421,18 +420,11 @@ def candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch,
                         for sk in ((1,) if kws else (1, 2, 4, 8, 16)):
                             if sk > nchunks:
                                 break
-                            wg_chunks = math.ceil(nchunks / sk)
-                            seen_depth = set()
-                            for nbuf in (0,) + tuple(ring_depths):
-                                depth = min(nbuf or 2, wg_chunks)             # what the launch will use
-                                if nbuf and (depth <= 2 or depth in seen_depth):
-                                    continue                                  # = the two-buffer pipeline / a depth already listed
-                                seen_depth.add(depth)
-                                lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16, waves * mb * nb * 1024 if kws else 0, nbuf)
-                                if lds > lds_cap:
-                                    continue
-                                out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, kws=kws, nbuf=depth if nbuf else 0, wgs=wgs * sk, nchunks=nchunks,
-                                                eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
+                            lds = lds_bytes(geo, taps, cpads, mb, ck, sk, bf16, waves * mb * nb * 1024 if kws else 0)
+                            if lds > lds_cap:
+                                continue
+                            out.append(dict(mb=mb, nb=nb, split_k=sk, ck=ck, waves=waves, kws=kws, wgs=wgs * sk, nchunks=nchunks,
+                                            eff=geo["tile_eff"] * cb / (groups * mb), lds=lds))
     return out
 
 
@@ -518,7 +510,7 @@ def choose_schedule(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, pha
     best = None
     for lds_cap in (80 * 1024, 160 * 1024):      # prefer two workgroups per CU; a one-per-CU budget only if nothing else launches
         for c in candidate_schedules(cout, src_channels, kh, kw, sh, sw, out_h, out_w, batch, phases, lds_cap=lds_cap, bf16=bf16):
-            if c["waves"] != 4 or c.get("kws") or c.get("nbuf"):   # 8-wave / K-split-wave workgroups / deep rings only through the measured table
+            if c["waves"] != 4 or c.get("kws"):   # 8-wave / K-split-wave workgroups only through the measured table
                 continue
             reuse = (c["mb"] * c["nb"]) / (c["mb"] + c["nb"])          # MFMAs per LDS operand read
             fill = min(1.0, c["wgs"] / 768.0)
@@ -631,7 +623,7 @@ class Plan:
         h = hashlib.sha256()
         for c in self.conv_log:
             h.update(repr((c["name"], c.get("winograd", 0), c.get("wino_variant", 0), c.get("wino_axis", 0), c.get("wino_m", 0), c.get("b8", 0),
-                           c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"], c["kws"], int(c.get("bf16", 0)), int(c.get("nbuf", 0)))).encode())
+                           c["mb"], c["nb"], c["split_k"], c["ck"], c["waves"], c["kws"], int(c.get("bf16", 0)))).encode())
         h.update(f"abi{_lib.MR_ABI_VERSION}".encode())
         return h.hexdigest()[:16]
 
@@ -810,9 +802,8 @@ class Plan:
             mb, nb, split_k, ck = sched[:4]
             waves = sched[4] if len(sched) > 4 else 4
             kws = int(sched[5]) if len(sched) > 5 else 0       # K split across the waves of a workgroup
-            nbuf = int(sched[6]) if len(sched) > 6 else 0      # LDS ring depth (0: the two-buffer pipeline)
             d.cout_blocks_per_wg, d.pixel_blocks_per_wave, d.split_k, d.chunk_channels = mb, nb, split_k, ck
-            d.waves_per_wg, d.k_split_waves, d.pipeline_buffers = waves, kws, nbuf
+            d.waves_per_wg, d.k_split_waves = waves, kws
             d.workspace = 1 if split_k > 1 else None           # placeholder (non-null) until the shared workspace exists
             d.packed_weights = 1                               # (placeholders: only the geometry is validated here)
             for i in range(nph if phases is not None else 0):
@@ -835,7 +826,7 @@ class Plan:
         macs = n * out_h * out_w * cout * cin * taps
         geo = conv_geometry(out_h, out_w, kh, kw, stride[0], stride[1], nb, waves, kws)
         wgs = geo["tiles"] * math.ceil(((cout + 15) // 16) / mb) * n * split_k * nph
-        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, kws=kws, nbuf=nbuf, wgs=wgs, lds=int(lds),
+        self.conv_log.append(dict(name=name, macs=macs, ref_macs=macs if ref_macs is None else ref_macs, mb=mb, nb=nb, split_k=split_k, ck=ck, waves=waves, kws=kws, wgs=wgs, lds=int(lds),
                                   cout=cout, cin=cin, k=(kh, kw), out=(out_h, out_w), batch=n, phases=nph,
                                   sig=schedule_signature(cout, src_channels, kh, kw, stride[0], stride[1], out_h, out_w, n, nph, bf16, mixed), bf16=bf16,
                                   spec=dict(src_shapes=[tuple(s.shape) for s in srcs], w_shape=(cout, cin, kh, kw),

@@ -42,7 +42,7 @@ def main():
     if a.bf16:
         steps = [("tune_b8", [py, "tools/tune_b8.py"] + shape + ["--emit", b8])]
     else:
-        steps = [("tune_conv", [py, "tools/tune_conv.py"] + shape + ["--merge", "--ring", "3,4", "--out", sched] + ([] if a.all else ["--missing"])),
+        steps = [("tune_conv", [py, "tools/tune_conv.py"] + shape + ["--merge", "--out", sched] + ([] if a.all else ["--missing"])),
                  ("bench_wino", [py, "tools/bench_wino.py"] + shape + ["--emit", wino]),
                  ("bench_wino_t", [py, "tools/bench_wino_t.py"] + shape + ["--emit", wino]),
                  ("bench_wino1d", [py, "tools/bench_wino1d.py"] + shape + ["--emit", wino]),

@@ -93,8 +93,6 @@ def main():
     ap.add_argument("--prefer-nosplit", type=float, default=None,
                     help="take the fastest schedule WITHOUT split_k (K split across the waves included) when it is within this many per cent of "
                          "the overall fastest: one launch less per layer (no finishing kernel, no workspace round trip)")
-    ap.add_argument("--ring", default="", help="comma-separated LDS ring depths (mr_conv_desc.pipeline_buffers, ABI 19) to try besides the two-buffer pipeline, e.g. 3,4,8")
-    ap.add_argument("--ring-max-ck", type=int, default=32, help="deep rings only for chunks of at most this many channels (the point of a ring is an early first sweep)")
     ap.add_argument("--out", default=os.path.join(ROOT, "monorec_amd", "tuned_schedules.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
@@ -124,8 +122,7 @@ def main():
         src_channels = [s[1] for s in spec["src_shapes"]]
         nph = 1 if spec["phases"] is None else len(spec["phases"])
         cands = engine.candidate_schedules(cout, src_channels, kh, kw, spec["stride"][0], spec["stride"][1],
-                                           spec["grid"][0], spec["grid"][1], c["batch"], nph, lds_cap=args.lds_cap, bf16=c.get("bf16", False),
-                                           ring_depths=tuple(int(x) for x in args.ring.split(",") if x))
+                                           spec["grid"][0], spec["grid"][1], c["batch"], nph, lds_cap=args.lds_cap, bf16=c.get("bf16", False))
         # prune: split-K only while the launch is short of ~8 workgroups per CU; drop tiny grids
         keep = []
         for cd in cands:
@@ -133,8 +130,6 @@ def main():
             if cd["split_k"] > 1 and base >= 1536:
                 continue
             if cd["wgs"] > 16384:
-                continue
-            if cd.get("nbuf") and cd["ck"] > args.ring_max_ck:
                 continue
             keep.append(cd)
         keep.sort(key=lambda cd: (-min(cd["wgs"], 1024), -cd["mb"] * cd["nb"]))
@@ -148,7 +143,7 @@ def main():
         best = None
         rows = []
         for cd in keep:
-            sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"], cd["waves"], cd.get("kws", 0)) + ((cd["nbuf"],) if cd.get("nbuf") else ())
+            sched = (cd["mb"], cd["nb"], cd["split_k"], cd["ck"], cd["waves"], cd.get("kws", 0))
             try:
                 p, fn = build_candidate(spec, sched, (srcs, out, res, weight if nph == 1 else None, bias, phase_w), c.get("bf16", False))
                 t = time_op(fn, reps=args.reps) if args.streams <= 1 else time_op_streams(fn, streams, reps=args.reps)

@@ -43,7 +43,7 @@ def main():
         w = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
         b = torch.randn(cout, generator=g)
         pw = [torch.randn(cout, cin, kh, kw, generator=g) * 0.05 for _ in range(nph)] if nph > 1 else None
-        sched = (c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4), c.get("kws", 0), c.get("nbuf", 0))    # the product's schedule, split-K included
+        sched = (c["mb"], c["nb"], c["split_k"], c["ck"], c.get("waves", 4), c.get("kws", 0))    # the product's schedule, split-K included
         p, fn = build_candidate(spec, sched, (srcs, out, res_t, w if nph == 1 else None, b, pw))
         desc = [k for k in p.keep if isinstance(k, _lib.ConvDesc)][0]
         wgs = p.conv_log[0]["wgs"]

@@ -80,6 +80,11 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, long long* cyc, int
             REP4(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "+v"(e0), "+v"(e1) : "v"(ba), "v"(bb));)
             n = 8;
         }
+        // ---- third set: the same placements on the bf16 instruction of conv_b8_kernel: does VALU work hide under IT? ----
+        if (KIND == 22) { REP4(BM(c0) VA BM(c1) VA BM(c2) VA BM(c3) VA) n = 16; }                   // one v_add_u32 behind every bf16 MFMA (kind 10)
+        if (KIND == 23) { REP4(BM(c0) BM(c1) BM(c2) BM(c3) VA VA VA VA VA VA VA VA) n = 16; }       // 8 VALU grouped per 4 bf16 MFMAs (kind 15)
+        if (KIND == 24) { REP4(BM(c0) VF BM(c1) VF BM(c2) VF BM(c3) VF) n = 16; }                   // v_fma_f32 behind every bf16 MFMA (kind 17)
+        if (KIND == 25) { REP4(BM(c0) BM(c1) BM(c2) BM(c3)) n = 16; }                               // 4 accumulators alone: the reference for 22-24
         if (KIND == 19) { REP4(M1(c0) DS DS VA M1(c1) DS DS VA M1(c2) DS DS VA M1(c3) DS DS VA) n = 16; }   // the un-specialised sweep's mix: 2 LDS reads + 1 VALU per MFMA
     }
     const long long t1 = clock64();
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, long long* cyc, int
 
 template <int KIND, int THREADS>
 void run(const char* what, float* out, long long* cyc) {
-    const int iters = (KIND == 20 || KIND == 21) ? 20000 : 2000, blocks = 256;
+    const int iters = KIND >= 20 ? 20000 : 2000, blocks = 256;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<KIND, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -110,7 +115,7 @@ void run(const char* what, float* out, long long* cyc) {
     c /= blocks;
     const double per_wave = (double)h[1];
     const int wps = THREADS / 256;
-    const int flop = KIND == 7 ? 4096 : (KIND == 20 ? 16384 : (KIND == 21 ? 32768 : 2048));
+    const int flop = KIND == 7 ? 4096 : ((KIND == 20 || KIND >= 22) ? 16384 : (KIND == 21 ? 32768 : 2048));
     printf("KIND %d %-58s %d wave(s)/SIMD: %6.1f cycles per MFMA and SIMD  (%.0f MFMAs/wave, %.3f ms -> %.1f TF, clock ~%.0f MHz)\n", KIND, what, wps,
            c / (per_wave * wps), per_wave, ms, (double)blocks * THREADS / 64 * per_wave * flop / (ms * 1e-3) / 1e12, c / (ms * 1e3));
 }
@@ -132,6 +137,10 @@ int main() {
     BOTH(7, "32x32x2, 2 accumulators")
     BOTH(20, "bf16 16x16x32, 12 accumulators")
     BOTH(21, "bf16 32x32x16, 2 accumulators")
+    BOTH(25, "bf16 16x16x32, 4 accumulators")
+    BOTH(22, "4 x (bf16 16x16x32, v_add_u32) interleaved")
+    BOTH(23, "4 bf16 16x16x32 then 8 VALU grouped")
+    BOTH(24, "4 x (bf16 16x16x32, v_fma_f32) interleaved")
     BOTH(9, "4 MFMA then 4 VALU grouped")
     BOTH(10, "4 x (MFMA, VALU) interleaved")
     BOTH(11, "4 MFMA then 1 VALU")

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from golden_util import Golden
-from monorec_amd import synth
+from monorec_amd import engine, synth
 from monorec_amd.model import MonoRecModel
 from oracle import monorec_oracle as orc
 
@@ -305,6 +305,32 @@ def test_oxford_robotcar_evaluation_shape_against_the_oracle(hip_lib, batch_size
     ref_out = orc.forward(sd, batch, cv_depth_steps=32)
     assert out["result"].shape == (batch_size, 1, 320, 640) and len(out["single_frame_cvs"]) == 2
     _check_against(out, ref_out, "320x640 batch %d" % batch_size)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (192, 448)], ids=["tum_480x640_tabled", "192x448_no_entries"])
+def test_other_input_shapes_against_the_oracle(hip_lib, shape):
+    """Shapes beyond the KITTI / Oxford crops.  480x640 (TUM RGB-D class, data_loader/tum_rgbd_dataset.py) runs on the entries
+    tools/tune_all.py measured for it (tools/sessions/r06_s23.sh); 192x448 has no entry in any table: every launch is chosen by the
+    nearest-signature rules (engine.nearest_schedules / nearest_form) and validated against its own geometry by the library.  Both at the
+    1e-4 bar of the path."""
+    h, w = shape
+    model, sd = _model(32, graph=False)
+    batch = synth.make_batch(1, h, w, 2, seed=9)
+    with torch.no_grad():
+        out = model(_to_dev(batch))
+        out = {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in out.items() if k in
+               ("result", "cv_mask", "predicted_inverse_depths", "image_features", "cost_volume", "single_frame_cvs")}
+    torch.cuda.synchronize()
+    plan = next(p for k, p in model._plans.items() if k[2] == h and k[3] == w)
+    tabled = [c["sig"] for c in plan.conv_log if c.get("sig") in engine.TUNED]
+    if shape == (192, 448):
+        assert not tabled, tabled[:3]
+        assert any(c.get("winograd") for c in plan.conv_log)               # the rules still send layers to the reduced-multiply forms
+    else:
+        assert len(tabled) >= 20
+    ref_out = orc.forward(sd, batch, cv_depth_steps=32)
+    assert out["result"].shape == (1, 1, h, w)
+    _check_against(out, ref_out, "%dx%d" % shape)
 
 
 def test_c5_shape_in_fp32_and_bf16(hip_lib):

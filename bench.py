@@ -574,7 +574,8 @@ def forward_api(model, batch_dev, batch, steps=100):
     owned = out["result"].data_ptr() not in {t.data_ptr() for p in model._plans.values() for t in p.buf.values()}
     return {"value": steps * batch / dt, "unit": "keyframes/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "outputs_owned_by_caller": bool(owned),
-            "note": "model(data_dict) exactly as evaluater.py:83 calls it: sequential forwards on the caller's stream, outputs produced in caller-owned memory (no copy)"}
+            "note": "model(data_dict) exactly as evaluater.py:83 calls it: every launch on the caller's current stream (hip_forward_on_callers_stream=True, round 6), "
+                    "outputs produced in caller-owned memory (no copy); the figure to hold against an in-flight-1 prepare/submit/synchronize loop (tools/forward_rate.py)"}
 
 
 def prime_device(args, dev_index):

@@ -275,7 +275,7 @@ class MonoRecModel(nn.Module):
                  depth_large_model=False, no_cv=False, freeze_resnet=True, freeze_module=(), checkpoint_location=None,
                  mask_cp_loc=None, depth_cp_loc=None, hip_graph=False, hip_in_flight=4, hip_bf16=False, hip_bf16x3=False,
                  hip_batch_keyframes=1, hip_queue_depth=1, hip_single_stream=False, hip_exact_convs=False, hip_cv_separable=False, hip_lean_outputs=False, hip_skip_dead_layer4=False,
-                 hip_slot_streams=None, hip_streams=None):
+                 hip_slot_streams=None, hip_streams=None, hip_forward_on_callers_stream=True):
         super().__init__()
         self.inv_depth_min_max = inv_depth_min_max
         self.cv_depth_steps = cv_depth_steps
@@ -317,6 +317,9 @@ class MonoRecModel(nn.Module):
         # Measured (round 3, 48-run grid tools/sessions/r03_s3.sh): 1 is best - a forward enqueued while its slot is still busy
         # (depth 2 and more) costs 5-7 % keyframes/s, whatever stream the requests come in on.
         self._queue_depth = max(1, int(hip_queue_depth))
+        # forward() (not submit()): launch on the caller's current stream instead of the slot's streams (round 6; False = rounds 3-5: slot streams,
+        # host-side input wait, wait packet on the caller's stream)
+        self._forward_inline = bool(hip_forward_on_callers_stream)
         # profiling aid: encoder and main stages on ONE stream, so that a kernel trace of `hip_in_flight=1` shows isolated kernel
         # durations (with two streams the ResNet launches overlap the cost volume / mask encoder and inflate each other)
         self._single_stream = bool(hip_single_stream)
@@ -573,6 +576,17 @@ class MonoRecModel(nn.Module):
         prep = self._parse(data_dict)                         # checks only; the pose algebra runs behind the encoder's launches
         with torch.cuda.device(prep.device):
             slot = self._forward_slot(prep)
+            if self._forward_inline and not self._hip_graph:
+                b, h, w, nf = prep.shape
+                self._consts_for(prep.device)
+                _, plan = self._plan_for(slot, b, h, w, nf, prep.device)
+                if plan.outputs_rebindable:
+                    # Round 6: the keyframe is enqueued ON THE CALLER'S STREAM.  Stream order then says everything the host used to
+                    # wait for - inputs ready, the previous forward done with the slot's buffers, outputs ordered for the caller - so the host waits
+                    # for nothing before it launches: the gather of the 4x4s and the pose-independent encoder stage of THIS call queue up behind the
+                    # previous call's launches while those still run, and the device never idles between two forwards (the slot-stream path lost
+                    # ~0.09 ms per call to the signalling slot stream -> caller's stream -> host -> first launch).
+                    return self._submit_locked(data_dict, prep, slot=slot, own=True, inline=True)
             # Everything that needs neither the inputs nor an idle slot happens BEFORE the host waits for the caller's stream (which, in a
             # loop of forward() calls, is the wait for the previous forward): the two output arenas and the re-targeting of the plan's
             # launches (~50 us).  The previous forward's launches copied their descriptors when they were enqueued, so patching them now
@@ -728,7 +742,7 @@ class MonoRecModel(nn.Module):
         inputs_ready.record(torch.cuda.current_stream(device))
         _host_wait(inputs_ready)
 
-    def _geometry_begin(self, prep):
+    def _geometry_begin(self, prep, stream=None):
         """First half of the pose algebra of a parsed request: with the 4x4s on the device, the ONE gather launch that brings them into
         device-writable pinned host memory (its own stream; nothing waits here).  Returns the state `_geometry_finish` completes.
         forward() / an idle-device submit() call this BEFORE they enqueue the encoder stage, so that the round trip of the gather runs
@@ -742,7 +756,7 @@ class MonoRecModel(nn.Module):
         # matrices on the device: one gather launch into device-writable pinned host memory
         dm = [m if (m.dtype == torch.float32 and m.is_contiguous() and m.device == device) else
               m.to(device=device, dtype=torch.float32).contiguous() for m in mat_list]
-        if any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
+        if stream is None and any(x is not y for x, y in zip(dm, mat_list)):     # a conversion ran on the caller's stream: let it finish first
             ev = torch.cuda.Event()
             ev.record(caller)
             _host_wait(ev)
@@ -751,6 +765,8 @@ class MonoRecModel(nn.Module):
         if pinned is None:
             pinned = self._prep_pinned[pk] = (torch.empty(len(dm), b, 4, 4, dtype=torch.float32).pin_memory(), self._device_streams(device)["g"])
         hm, gs = pinned
+        if stream is not None:             # forward() on the caller's stream: the gather is ordered behind the matrices by stream order
+            gs = stream
         ptrs = (ctypes.c_void_p * len(dm))(*[m.data_ptr() for m in dm])
         _lib.check(_lib.load().mr_gather_small_f32(ptrs, len(dm), 16 * b, hm.data_ptr(), gs.cuda_stream), "mr_gather_small_f32")
         done = torch.cuda.Event()
@@ -896,7 +912,7 @@ class MonoRecModel(nn.Module):
                 m["result"] = m["predicted_inverse_depths"][0]
                 m["mask"] = m["cv_mask"]
 
-    def _submit_locked(self, data_dict, prepared, slot=None, own=False, prebound=None):
+    def _submit_locked(self, data_dict, prepared, slot=None, own=False, prebound=None, inline=False):
         """`own`: forward() - the outputs are produced in memory the caller owns (two arenas allocated here, every launch that writes
         or reads an output buffer re-targeted by Plan.rebind_outputs) instead of the slot's resident buffers; a token without
         matrices gets them formed behind the encoder's launches (the device starts on the pose-independent stage while the host
@@ -912,12 +928,22 @@ class MonoRecModel(nn.Module):
             slot = self._slot_counter[0]
             self._slot_counter[0] = (slot + 1) % self._in_flight
         key, plan = self._plan_for(slot, b, h, w, nf, device)
-        streams = self._slot_streams(slot, device, own=own)
-        main, enc = streams["main"], streams["enc"]
         caller = torch.cuda.current_stream(device)
-        # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time
-        while len(plan.enqueued) >= self._queue_depth:
-            _host_wait(plan.enqueued.popleft())
+        if inline:                                           # forward(): every launch on the caller's stream (see _forward_handle)
+            main = enc = caller
+        else:
+            streams = self._slot_streams(slot, device, own=own)
+            main, enc = streams["main"], streams["enc"]
+        # forwards of this slot enqueued on ANOTHER stream (submit() and forward() mixed on one slot): no stream order between them and the
+        # launches below, which overwrite the slot's resident buffers - the host waits for them
+        for ev, st in [e for e in plan.enqueued if e[1] != main]:
+            _host_wait(ev)
+        if any(e[1] != main for e in plan.enqueued):
+            plan.enqueued = collections.deque(e for e in plan.enqueued if e[1] == main)
+        # host run-ahead: at most `hip_queue_depth` forwards of a slot are enqueued at any time (inline: one more - the next call's gather and
+        # encoder stage are MEANT to queue up behind the running forward; the wait for the gather bounds the run-ahead by itself)
+        while len(plan.enqueued) >= (max(2, self._queue_depth) if inline else self._queue_depth):
+            _host_wait(plan.enqueued.popleft()[0])
         start_time = time.time()
         # The launches below overwrite the slot's previous outputs: the host waits for whatever the caller's stream - and any other
         # stream that took results of this slot through `.result()` - has been given to do with them so far (host waits, not stream
@@ -983,7 +1009,7 @@ class MonoRecModel(nn.Module):
                 self._run_stage(key, plan, "cv", main)
 
             if prepared.kinv is None:      # forward() / idle-device submit(): encoder launches first, the pose algebra while the device runs them
-                gstate = self._geometry_begin(prepared)       # the gather launch goes out ahead of the encoder's ~25 launches ...
+                gstate = self._geometry_begin(prepared, stream=main if inline else None)   # the gather launch goes out ahead of the encoder's ~25 launches ...
                 enc_done, tail_done = encoder_stage()
                 self._geometry_finish(prepared, gstate)       # ... and has long landed when the host gets here
                 cv_stage(prepared.kinv, prepared.proj)
@@ -998,7 +1024,7 @@ class MonoRecModel(nn.Module):
                 main.wait_event(tail_done)
             done = torch.cuda.Event()
             done.record(main)
-            plan.enqueued.append(done)
+            plan.enqueued.append((done, main))
         self.host_enqueue_stats[0] += 1
         self.host_enqueue_stats[1] += time.time() - start_time
         # (:279: host seconds spent in the cost-volume module; here: enqueueing.)  The async H2D copy below reads pinned memory some
@@ -1021,7 +1047,7 @@ class MonoRecModel(nn.Module):
             data_dict["predicted_inverse_depths"] = [owned[f"pred{i}"] for i in range(4)]
             data_dict["result"] = data_dict["predicted_inverse_depths"][0]
             data_dict["mask"] = data_dict["cv_mask"]
-            return _Pending(data_dict, done, device, None, owned=True)
+            return _Pending(data_dict, done, device, None, owned=True, stream=main if inline else None)
         data_dict["cost_volume"] = plan.buf["cost_volume"]
         if not (plan.lean_outputs and plan.b8):               # (lean: the buffer holds raw per-frame costs, not monorec_model.py:251's volumes)
             data_dict["single_frame_cvs"] = [plan.buf["sfcv"][f] for f in range(nf)]
@@ -1144,8 +1170,9 @@ class _GroupHandle:
 class _Pending:
     """Handle of an enqueued forward (MonoRecModel.submit)."""
 
-    def __init__(self, data_dict, done, device, consumers=None, owned=False):
+    def __init__(self, data_dict, done, device, consumers=None, owned=False, stream=None):
         self._data, self._done, self._device, self._consumers = data_dict, done, device, consumers
+        self._stream = stream       # forward() on the caller's stream: results are already ordered on that stream
         self.collected = False      # result() / synchronize() taken: forward() may reuse the slot's resident output buffers as a copy source
         self.owned = owned          # the outputs already live in memory the caller owns (forward())
 
@@ -1153,7 +1180,8 @@ class _Pending:
         """Order the caller's current stream after the forward and return the output dict.  The stream is remembered: the submit
         that reuses the slot orders its launches behind whatever that stream has been given to do with the outputs by then."""
         cs = torch.cuda.current_stream(self._device)
-        cs.wait_event(self._done)
+        if self._stream is None or cs != self._stream:
+            cs.wait_event(self._done)
         if self._consumers is not None and cs not in self._consumers:
             self._consumers.append(cs)
         self.collected = True

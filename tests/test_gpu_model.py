@@ -875,6 +875,47 @@ def test_forward_produces_its_outputs_in_two_caller_owned_arenas(hip_lib):
 
 
 @pytest.mark.gpu
+def test_forward_on_the_callers_stream_equals_the_slot_stream_path(hip_lib):
+    """Round 6: forward() enqueues the keyframe on the CALLER'S stream (default) - no host wait, the next call's gather and encoder
+    stage queue up behind the running forward.  A run of forwards with nothing between them (the host runs ahead), on the default stream and on a
+    side stream, with matrices on the device and on the host, must give bit for bit what the slot-stream path of rounds 3-5
+    (hip_forward_on_callers_stream=False) gives; the outputs stay owned; a submit() on the same slot afterwards is ordered behind them."""
+    batches = [synth.make_batch(1, 64, 96, 2, seed=40 + i) for i in range(4)]
+    results = {}
+    for inline in (True, False):
+        m, sd = _model(8, graph=False, hip_forward_on_callers_stream=inline)
+        outs = []
+        with torch.no_grad():
+            devb = [_to_dev(b) for b in batches]
+            for k in ("keyframe_intrinsics", "keyframe_pose", "intrinsics", "poses"):      # one request with its 4x4s on the host
+                devb[1][k] = batches[1][k]
+            torch.cuda.synchronize()
+            for b in devb[:3]:
+                outs.append(m(dict(b)))                                                    # no synchronisation in between
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                outs.append(m(dict(devb[3])))
+                outs.append(m(dict(devb[0])))
+            torch.cuda.current_stream().wait_stream(side)
+            plan = next(iter(m._plans.values()))
+            resident = {t.data_ptr() for t in plan.buf.values()}
+            assert all(o["result"].data_ptr() not in resident for o in outs)
+            view = m.submit(dict(devb[2])).synchronize()                                   # slot 0 on its own stream: behind the forwards
+            torch.cuda.synchronize()
+            assert torch.equal(view["result"], outs[2]["result"])
+        results[inline] = [{k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in o.items()
+                            if k in ("result", "cv_mask", "cost_volume", "single_frame_cvs", "image_features", "predicted_inverse_depths")} for o in outs]
+    for a, b in zip(results[True], results[False]):
+        for k in a:
+            if torch.is_tensor(a[k]):
+                assert torch.equal(a[k], b[k]), k
+            else:
+                assert all(torch.equal(x, y) for x, y in zip(a[k], b[k])), k
+    assert torch.equal(results[True][0]["result"], results[True][4]["result"])             # the same request on the two streams
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pretrain_mode", [0, 1])
 def test_forward_between_a_submit_and_its_result_leaves_the_handle_intact(hip_lib, pretrain_mode):
     """submit(a); model(b); a.result() - the forward must not overwrite the outputs the pending handle views.  The full

@@ -29,7 +29,7 @@ a = ap.parse_args()
 dev = "cuda:0"
 sd = None
 models = {}
-for name, kw in (("forward", {}), ("loop1", {"hip_in_flight": 1})):
+for name, kw in (("forward", {}), ("forward_slot_streams", {"hip_forward_on_callers_stream": False}), ("loop1", {"hip_in_flight": 1})):
     m = MonoRecModel(cv_depth_steps=32, **kw)
     sd = sd or synth.seeded_state_dict(m.state_dict(), seed=0)
     m.load_state_dict(sd)
@@ -54,7 +54,7 @@ def leg_loop1(m, n):
     return pending.popleft().synchronize()
 
 
-legs = {"forward": leg_forward, "loop1": leg_loop1}
+legs = {"forward": leg_forward, "forward_slot_streams": leg_forward, "loop1": leg_loop1}
 rates = {k: [] for k in legs}
 with torch.no_grad():
     for k in legs:
@@ -68,5 +68,5 @@ with torch.no_grad():
             torch.cuda.synchronize()
             rates[k].append(a.steps / (time.perf_counter() - t0))
 med = {k: statistics.median(v) for k, v in rates.items()}
-print(json.dumps({"forward": round(med["forward"], 1), "loop1": round(med["loop1"], 1),
-                  "ratio": round(med["forward"] / med["loop1"], 4), "all": {k: [round(x, 1) for x in v] for k, v in rates.items()}}))
+print(json.dumps({"forward": round(med["forward"], 1), "forward_slot_streams": round(med["forward_slot_streams"], 1), "loop1": round(med["loop1"], 1),
+                  "ratio": round(med["forward"] / med["loop1"], 4), "ratio_slot_streams": round(med["forward_slot_streams"] / med["loop1"], 4), "all": {k: [round(x, 1) for x in v] for k, v in rates.items()}}))

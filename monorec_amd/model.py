@@ -691,7 +691,8 @@ class MonoRecModel(nn.Module):
         with self._lock, torch.cuda.device(prep.device):
             self._wait_inputs(prep.device)
             # (A parse-only token for the first request on an idle device - pose algebra behind the encoder stage's launches, as forward() does it - was
-            # built and measured in round 5: 705-709 against 716-718 keyframes/s on 20-step lines, r05_s6.  Not kept.)
+            # built and measured in round 5: 705-709 against 716-718 keyframes/s on 20-step lines, r05_s6; again in round 6 with one stream per slot:
+            # 764-783 against 760-772, r06_s30 - the cold first round trip is paid inside submit() instead.  Not kept.)
             self._geometry(prep)
         return prep
 
